@@ -1,0 +1,132 @@
+"""Closed-form weights and seeded synthetic inputs (TEST INFRASTRUCTURE, see __init__).
+
+Fixtures carry outputs only: both the imported reference (gen_golden.py, build container)
+and the oracle / HIP path (anywhere) regenerate identical weights from ``formula_fill`` and
+identical inputs from ``make_inputs``.  Nothing here depends on /root/reference.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+
+import numpy as np
+import torch
+
+# ---- configurations ---------------------------------------------------
+CONFIGS = {
+    # BASELINE.json configs[0]: 1 enc / 1 dec / 4 heads, 2 levels, 128x128, bs 2, Q=10, S=320
+    "cfg0": dict(d_model=256, nheads=4, enc_layers=1, dec_layers=1, d_ffn=1024, n_levels=2, n_points=4,
+                 num_queries=10, n_classes=21, dropout=0.1, strides=[8, 16], num_channels=[256, 256],
+                 image_hw=(128, 128), level_hw=[(16, 16), (8, 8)], batch=2),
+    # small config that exercises the extra 3x3-s2 level, padding masks and 2 layers each
+    "tiny": dict(d_model=64, nheads=4, enc_layers=2, dec_layers=2, d_ffn=128, n_levels=3, n_points=4,
+                 num_queries=6, n_classes=5, dropout=0.1, strides=[8, 16], num_channels=[32, 48],
+                 image_hw=(96, 128), level_hw=[(12, 16), (6, 8), (3, 4)], batch=2),
+    # BASELINE.json configs[1]/[2]: YCB-V
+    "ycbv": dict(d_model=256, nheads=16, enc_layers=5, dec_layers=5, d_ffn=1024, n_levels=4, n_points=4,
+                 num_queries=20, n_classes=21, dropout=0.1, strides=[8, 16, 32], num_channels=[256, 256, 256],
+                 image_hw=(480, 640), level_hw=[(60, 80), (30, 40), (15, 20), (8, 10)], batch=16),
+    # BASELINE.json configs[3]: LM-O RCNN-shape
+    "lmo": dict(d_model=256, nheads=16, enc_layers=5, dec_layers=5, d_ffn=1024, n_levels=4, n_points=4,
+                num_queries=10, n_classes=8, dropout=0.1, strides=[16, 32, 64], num_channels=[256, 256, 256],
+                image_hw=(480, 640), level_hw=[(30, 40), (15, 20), (8, 10), (4, 5)], batch=32),
+    # BASELINE.json configs[4]: high-res
+    "hires": dict(d_model=256, nheads=16, enc_layers=6, dec_layers=6, d_ffn=1024, n_levels=4, n_points=4,
+                  num_queries=50, n_classes=21, dropout=0.1, strides=[8, 16, 32], num_channels=[256, 256, 256],
+                  image_hw=(960, 1280), level_hw=[(120, 160), (60, 80), (30, 40), (15, 20)], batch=8),
+}
+
+
+def n_backbone_levels(cfg):
+    return len(cfg["strides"])
+
+
+# ---- closed-form weights -------------------------------------------------------------------------
+def _phase(name: str) -> float:
+    return (zlib.crc32(name.encode()) % 6283) * 1e-3
+
+
+def _wave(numel: int, name: str, freq: float = 0.37) -> torch.Tensor:
+    i = torch.arange(numel, dtype=torch.float64)
+    return torch.sin(freq * i + _phase(name))
+
+
+@torch.no_grad()
+def formula_fill(model: torch.nn.Module) -> None:
+    """Deterministic, name-keyed fill of every parameter.  Amplitudes are chosen so activations
+    stay O(1) through the stack and sampling offsets cover in-range and out-of-range points."""
+    for name, p in model.named_parameters():
+        n = p.numel()
+        leaf = name.split(".")[-1]
+        if "sampling_offsets" in name:
+            if leaf == "weight":
+                val = 0.02 * _wave(n, name)                       # queries move the points by ~+-0.5 px
+            else:                                                # keep the directional grid, perturb it
+                val = p.detach().double().flatten() + 0.3 * _wave(n, name)
+        elif "attention_weights" in name:
+            val = (0.05 if leaf == "weight" else 0.5) * _wave(n, name)
+        elif "norm" in name or (name.startswith("input_proj") and ".1." in name):
+            val = (1.0 + 0.1 * _wave(n, name)) if leaf == "weight" else 0.05 * _wave(n, name)
+        elif "level_embed" in name:
+            val = 0.5 * _wave(n, name)
+        elif p.dim() >= 2:
+            fan_in = p[0].numel()
+            val = math.sqrt(3.0 / fan_in) * 1.2 * _wave(n, name)
+        else:
+            val = 0.05 * _wave(n, name)
+        p.copy_(val.view_as(p).to(p.dtype))
+
+
+# ---- seeded synthetic inputs ---------------------------------------------------------------------
+def _rand_rotation(rng: np.random.Generator) -> np.ndarray:
+    q, r = np.linalg.qr(rng.standard_normal((3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 2] = -q[:, 2]
+    return q
+
+
+def make_inputs(cfg: dict, seed: int = 1234, batch: int | None = None, pad: bool = False):
+    """Returns (features list[(N,C,H,W) f32], image_sizes [(h,w)..], targets list[dict]).
+
+    ``pad=True`` gives images of different sizes inside the batch, so masks / valid ratios
+    are non-trivial (right/bottom padding as util/misc.py:326-343 produces).
+    """
+    rng = np.random.default_rng(seed)
+    n = batch or cfg["batch"]
+    nb = n_backbone_levels(cfg)
+    feats = [torch.from_numpy(rng.standard_normal((n, cfg["num_channels"][l], *cfg["level_hw"][l])).astype(np.float32))
+             for l in range(nb)]
+    ih, iw = cfg["image_hw"]
+    sizes = []
+    for i in range(n):
+        if pad and i > 0:
+            sizes.append((int(ih * (0.6 + 0.1 * (i % 3))) // 8 * 8, int(iw * (0.85 - 0.1 * (i % 2))) // 8 * 8))
+        else:
+            sizes.append((ih, iw))
+    q, c = cfg["num_queries"], cfg["n_classes"]
+    targets = []
+    for i in range(n):
+        k = int(rng.integers(3, q + 1)) if q >= 3 else q
+        boxes = np.concatenate([rng.uniform(0.2, 0.8, (k, 2)), rng.uniform(0.05, 0.25, (k, 2))], 1).astype(np.float32)
+        labels = rng.integers(1, c + 1, (k,)).astype(np.int64)
+        pos = (rng.standard_normal((k, 3)) * np.array([0.2, 0.2, 0.3]) + np.array([0.0, 0.0, 1.0])).astype(np.float32)
+        rot = np.stack([_rand_rotation(rng) for _ in range(k)]).astype(np.float32)
+        targets.append({"boxes": torch.from_numpy(boxes), "labels": torch.from_numpy(labels),
+                        "relative_position": torch.from_numpy(pos), "relative_rotation": torch.from_numpy(rot)})
+    return feats, sizes, targets
+
+
+def make_samples(cfg: dict, sizes):
+    """Image batch as a list of (3,h,w) zero images -- content is irrelevant (backbone is synthetic),
+    only the sizes (=> masks) matter."""
+    return [torch.zeros(3, h, w) for (h, w) in sizes]
+
+
+def checksum(t: torch.Tensor):
+    """Per-tensor L2 norm + 8 strided samples -- used for gradient fixtures."""
+    f = t.detach().double().flatten()
+    if f.numel() == 0:
+        return np.zeros(9)
+    idx = torch.linspace(0, f.numel() - 1, 8).long()
+    return np.concatenate([[float(f.norm())], f[idx].numpy()])

@@ -1,0 +1,223 @@
+"""Golden-vector generator (TEST INFRASTRUCTURE; runs in the BUILD CONTAINER only).
+
+Imports the REAL reference from /root/reference (never copied, never shipped), fills it with the
+closed-form weights of oracle/formula.py, runs it in eval() on the seeded synthetic inputs and
+writes the outputs to tests/golden/*.npz.  Re-run:  python -m oracle.gen_golden
+
+Two import shims are injected into sys.modules:
+  * ``torchvision``  -- import surface only (util/misc.py:33-63, util/box_ops.py:18,
+    models/backbone_maskrcnn.py:9-11); no arithmetic on the hot path comes from it.
+  * ``deformable_attention`` -- the un-vendored CUDA op (models/deformable_transformer.py:24);
+    its stand-in is oracle.poet_ref.MSDeformAttn (upstream's grid_sample formulation), so the
+    goldens pin everything AROUND the MSDA core; the core itself is cross-checked against HF
+    transformers' independent restatement in a separate process (``--hf``).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def _install_shims():
+    import torch.nn as nn
+    from oracle import poet_ref
+
+    tv = types.ModuleType("torchvision")
+    tv.__version__ = "0.25.0"
+    ops = types.ModuleType("torchvision.ops")
+    boxes = types.ModuleType("torchvision.ops.boxes")
+    boxes.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    misc = types.ModuleType("torchvision.ops.misc")
+    misc.interpolate = torch.nn.functional.interpolate
+    models = types.ModuleType("torchvision.models")
+    det = types.ModuleType("torchvision.models.detection")
+    mrcnn = types.ModuleType("torchvision.models.detection.mask_rcnn")
+    mrcnn.MaskRCNN = type("MaskRCNN", (nn.Module,), {})
+    bbu = types.ModuleType("torchvision.models.detection.backbone_utils")
+    bbu.resnet_fpn_backbone = None
+    rpn = types.ModuleType("torchvision.models.detection.rpn")
+    rpn.AnchorGenerator = None
+    rpn.concat_box_prediction_layers = None
+    tv.ops, ops.boxes, ops.misc = ops, boxes, misc
+    tv.models, models.detection = models, det
+    det.mask_rcnn, det.backbone_utils, det.rpn = mrcnn, bbu, rpn
+    for m in (tv, ops, boxes, misc, models, det, mrcnn, bbu, rpn):
+        sys.modules[m.__name__] = m
+
+    da = types.ModuleType("deformable_attention")
+    da.MSDeformAttn = poet_ref.MSDeformAttn
+    sys.modules["deformable_attention"] = da
+    sys.path.insert(0, REF)
+
+
+def _ref_model(cfg, feats):
+    """Build the reference's own PoET around a Joiner-like synthetic backbone."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from models.deformable_transformer import DeformableTransformer
+    from models.pose_estimation_transformer import PoET, SetCriterion
+    from models.matcher import PoseMatcher
+    from models.position_encoding import PositionEmbeddingSine
+    from util.misc import NestedTensor
+    from oracle.poet_ref import build_weight_dict
+
+    class Joinerish(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.strides, self.num_channels = cfg["strides"], cfg["num_channels"]
+            self.pe = PositionEmbeddingSine(cfg["d_model"] // 2, normalize=True)
+
+        def __getitem__(self, i):
+            return self if i == 0 else self.pe
+
+        def forward(self, samples):
+            out, pos = [], []
+            for f in feats:
+                m = F.interpolate(samples.mask[None].float(), size=f.shape[-2:]).to(torch.bool)[0]
+                out.append(NestedTensor(f, m))
+            for x in out:
+                pos.append(self.pe(x).to(x.tensors.dtype))
+            return out, pos, None
+
+    tr = DeformableTransformer(d_model=cfg["d_model"], nhead=cfg["nheads"], num_encoder_layers=cfg["enc_layers"],
+                               num_decoder_layers=cfg["dec_layers"], dim_feedforward=cfg["d_ffn"],
+                               dropout=cfg["dropout"], activation="relu", return_intermediate_dec=True,
+                               num_feature_levels=cfg["n_levels"], dec_n_points=cfg["n_points"],
+                               enc_n_points=cfg["n_points"])
+    model = PoET(Joinerish(), tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
+                 n_classes=cfg["n_classes"], bbox_mode="gt", ref_points_mode="bbox", query_embedding_mode="bbox",
+                 rotation_mode="6d", class_mode="specific", aleatoric=False, aux_loss=True, backbone_type="yolo")
+    crit = SetCriterion(PoseMatcher(bbox_mode="gt", class_mode="specific"), build_weight_dict(cfg["dec_layers"]),
+                        ["translation", "rotation"])
+    return model, crit
+
+
+def _run_model(name, batch, pad, full):
+    from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples, checksum
+    from util.misc import nested_tensor_from_tensor_list
+
+    cfg = CONFIGS[name]
+    feats, sizes, targets = make_inputs(cfg, seed=1234, batch=batch, pad=pad)
+    model, crit = _ref_model(cfg, feats)
+    formula_fill(model)
+    model.eval()
+    crit.eval()
+    samples = nested_tensor_from_tensor_list(make_samples(cfg, sizes))
+
+    captured = {}
+    hook = model.transformer.encoder.register_forward_hook(lambda m, i, o: captured.__setitem__("memory", o.detach()))
+    hook2 = model.transformer.register_forward_hook(lambda m, i, o: captured.__setitem__("hs", o[0].detach()))
+    out, n_boxes = model(samples, targets)
+    hook.remove(); hook2.remove()
+    losses = crit(out, targets, n_boxes)
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    model.zero_grad()
+    total.backward()
+
+    rec = {
+        "pred_translation": out["pred_translation"].detach().numpy(),
+        "pred_rotation": out["pred_rotation"].detach().numpy(),
+        "aux_translation": np.stack([a["pred_translation"].detach().numpy() for a in out["aux_outputs"]])
+        if out["aux_outputs"] else np.zeros((0,)),
+        "aux_rotation": np.stack([a["pred_rotation"].detach().numpy() for a in out["aux_outputs"]])
+        if out["aux_outputs"] else np.zeros((0,)),
+        "n_boxes": np.asarray(n_boxes),
+        "loss_total": np.asarray(float(total)),
+        "loss_names": np.asarray(sorted(losses)),
+        "loss_values": np.asarray([float(losses[k]) for k in sorted(losses)]),
+    }
+    if full:
+        rec["memory"] = captured["memory"].numpy()
+        rec["hs"] = captured["hs"].numpy()
+    else:
+        rec["memory_checksum"] = checksum(captured["memory"])
+        rec["hs_checksum"] = checksum(captured["hs"])
+    names, sums = [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        sums.append(checksum(p.grad) if p.grad is not None else np.full(9, np.nan))
+    rec["grad_names"] = np.asarray(names)
+    rec["grad_checksums"] = np.stack(sums)
+    tag = f"{name}_b{batch}{'_pad' if pad else ''}"
+    np.savez_compressed(os.path.join(GOLD, f"poet_{tag}.npz"), **rec)
+    print("wrote", tag, "loss", float(total))
+
+
+def _small_units():
+    from models.position_encoding import PositionEmbeddingSine, BoundingBoxEmbeddingSine
+    from models.pose_estimation_transformer import PoET
+    from util.misc import NestedTensor
+
+    rng = np.random.default_rng(7)
+    # G1: sine position embedding on right/bottom padded masks
+    mask = torch.zeros(3, 12, 16, dtype=torch.bool)
+    mask[1, 9:, :] = True
+    mask[1, :, 13:] = True
+    mask[2, :, 10:] = True
+    pe = PositionEmbeddingSine(128, normalize=True)(NestedTensor(torch.zeros(3, 1, 12, 16), mask))
+    # G2: bbox embedding incl. the dummy box
+    boxes = torch.from_numpy(np.concatenate([rng.uniform(0, 1, (7, 4)), -np.ones((1, 4))]).astype(np.float32))
+    be = BoundingBoxEmbeddingSine(num_pos_feats=256 / 8)(boxes)
+    # G10: 6D -> R on random and near-degenerate inputs
+    r6 = rng.standard_normal((2, 6, 6)).astype(np.float32)
+    r6[0, 0, 3:] = r6[0, 0, :3] * 2.0 + 1e-4          # m2 almost parallel to m1
+    r6[0, 1, :3] *= 1e-6                               # tiny m1
+    rm = PoET.rotation_6d_to_matrix(None, torch.from_numpy(r6))
+    np.savez_compressed(os.path.join(GOLD, "units.npz"), pe_mask=mask.numpy(), pe_out=pe.numpy(),
+                        bbox_in=boxes.numpy(), bbox_out=be.numpy(), rot6d_in=r6, rot6d_out=rm.numpy())
+    print("wrote units")
+
+
+def _hf_msda():
+    """Separate process (no torchvision stub on the path): HF transformers' own pure-PyTorch MSDA."""
+    from transformers.models.deformable_detr.modeling_deformable_detr import MultiScaleDeformableAttention
+    rng = np.random.default_rng(11)
+    shapes = [(6, 8), (3, 4)]
+    n, m, d, lq, p = 2, 4, 16, 9, 4
+    s = sum(h * w for h, w in shapes)
+    value = torch.from_numpy(rng.standard_normal((n, s, m, d)).astype(np.float32)).requires_grad_()
+    loc = torch.from_numpy(rng.uniform(-0.3, 1.3, (n, lq, m, len(shapes), p, 2)).astype(np.float32)).requires_grad_()
+    w = torch.softmax(torch.from_numpy(rng.standard_normal((n, lq, m, len(shapes) * p)).astype(np.float32)), -1)
+    w = w.view(n, lq, m, len(shapes), p).detach().requires_grad_()
+    core = MultiScaleDeformableAttention()
+    out = core(value, torch.tensor(shapes), shapes, None, loc, w, 64)
+    gout = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32))
+    (out * gout).sum().backward()
+    np.savez_compressed(os.path.join(GOLD, "msda_core_hf.npz"), shapes=np.asarray(shapes), value=value.detach().numpy(),
+                        loc=loc.detach().numpy(), attn=w.detach().numpy(), out=out.detach().numpy(), grad_out=gout.numpy(),
+                        d_value=value.grad.numpy(), d_loc=loc.grad.numpy(), d_attn=w.grad.numpy())
+    print("wrote msda_core_hf")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    if "--hf" in sys.argv:
+        _hf_msda()
+        return
+    if not os.path.isdir(REF):
+        raise SystemExit("gen_golden needs /root/reference (build container only)")
+    _install_shims()
+    _small_units()
+    _run_model("tiny", 2, True, True)
+    _run_model("tiny", 2, False, True)
+    _run_model("cfg0", 2, False, True)
+    _run_model("cfg0", 2, True, False)
+    _run_model("ycbv", 1, False, False)
+    subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", "--hf"], cwd=ROOT)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    main()

@@ -1,0 +1,541 @@
+"""fp32 PyTorch-CPU restatement of the PoET hot path (TEST INFRASTRUCTURE, see __init__).
+
+Every class cites the reference lines it restates (paths relative to /root/reference).
+state_dict keys are identical to the reference's so one formula fill drives both.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+# ----------------------------------------------------------------------------------------------
+# util/misc.py:346-371 NestedTensor, :326-343 nested_tensor_from_tensor_list
+# ----------------------------------------------------------------------------------------------
+class NestedTensor:
+    def __init__(self, tensors, mask):
+        self.tensors, self.mask = tensors, mask
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    def to(self, device):
+        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
+
+
+def nested_from_list(images: Sequence[torch.Tensor]) -> NestedTensor:
+    c = images[0].shape[0]
+    hmax = max(int(im.shape[1]) for im in images)
+    wmax = max(int(im.shape[2]) for im in images)
+    batch = torch.zeros(len(images), c, hmax, wmax, dtype=images[0].dtype)
+    mask = torch.ones(len(images), hmax, wmax, dtype=torch.bool)
+    for i, im in enumerate(images):
+        batch[i, :, : im.shape[1], : im.shape[2]] = im
+        mask[i, : im.shape[1], : im.shape[2]] = False
+    return NestedTensor(batch, mask)
+
+
+# ----------------------------------------------------------------------------------------------
+# MSDeformAttn -- EXTERNAL op (not in /root/reference).  Spec: SURVEY.md Appendix A.
+# Reference call sites: models/deformable_transformer.py:24,58-59,177,201,248,283.
+# ----------------------------------------------------------------------------------------------
+def msda_core(value, spatial_shapes, sampling_locations, attention_weights):
+    """value (N,S,M,D); spatial_shapes [(H,W)..]; loc (N,Lq,M,L,P,2) in [0,1]; w (N,Lq,M,L,P).
+
+    Upstream's documented CPU formulation: per level a bilinear grid_sample with zero
+    padding and align_corners=False, multiplied by the weights and summed over (L,P).
+    """
+    n, s, m, d = value.shape
+    _, lq, _, l, p, _ = sampling_locations.shape
+    shapes = [(int(h), int(w)) for h, w in spatial_shapes]
+    chunks = value.split([h * w for h, w in shapes], dim=1)
+    grids = 2.0 * sampling_locations - 1.0
+    sampled = []
+    for lvl, (h, w) in enumerate(shapes):
+        v = chunks[lvl].flatten(2).transpose(1, 2).reshape(n * m, d, h, w)
+        g = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)          # (N*M, Lq, P, 2)
+        sampled.append(F.grid_sample(v, g, mode="bilinear", padding_mode="zeros", align_corners=False))
+    wts = attention_weights.transpose(1, 2).reshape(n * m, 1, lq, l * p)
+    out = (torch.stack(sampled, dim=-2).flatten(-2) * wts).sum(-1)      # (N*M, D, Lq)
+    return out.view(n, m * d, lq).transpose(1, 2).contiguous()
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads:
+            raise ValueError("d_model must be divisible by n_heads")
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        nn.init.constant_(self.sampling_offsets.weight, 0.0)
+        theta = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid = torch.stack([theta.cos(), theta.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2)
+        grid = grid.repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.view(-1))
+        nn.init.constant_(self.attention_weights.weight, 0.0)
+        nn.init.constant_(self.attention_weights.bias, 0.0)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.0)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        n, lq, _ = query.shape
+        _, s, _ = input_flatten.shape
+        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == s
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        m, l, p = self.n_heads, self.n_levels, self.n_points
+        value = value.view(n, s, m, self.d_model // m)
+        off = self.sampling_offsets(query).view(n, lq, m, l, p, 2)
+        w = F.softmax(self.attention_weights(query).view(n, lq, m, l * p), -1).view(n, lq, m, l, p)
+        if reference_points.shape[-1] != 2:
+            raise ValueError("only 2-d reference points are reachable from PoET")
+        norm = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(query.dtype)
+        loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        out = msda_core(value, input_spatial_shapes.tolist(), loc, w)
+        return self.output_proj(out)
+
+
+# ----------------------------------------------------------------------------------------------
+# models/position_encoding.py:24-60 and :63-84
+# ----------------------------------------------------------------------------------------------
+class PositionEmbeddingSine(nn.Module):
+    def __init__(self, num_pos_feats=128, temperature=10000, normalize=True, scale=None):
+        super().__init__()
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, tensor_list: NestedTensor):
+        keep = ~tensor_list.mask
+        ey = keep.cumsum(1, dtype=torch.float32)
+        ex = keep.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            ey = (ey - 0.5) / (ey[:, -1:, :] + 1e-6) * self.scale
+            ex = (ex - 0.5) / (ex[:, :, -1:] + 1e-6) * self.scale
+        idx = torch.arange(self.num_pos_feats, dtype=torch.float32)
+        div = self.temperature ** (2 * (idx // 2) / self.num_pos_feats)
+        px = ex[..., None] / div
+        py = ey[..., None] / div
+        px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+        py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)
+
+
+class BoundingBoxEmbeddingSine(nn.Module):
+    def __init__(self, num_pos_feats=32):
+        super().__init__()
+        self.num_pos_feats = num_pos_feats
+
+    def forward(self, boxes):
+        mult = 2 ** torch.arange(self.num_pos_feats, dtype=torch.float32)
+        parts = []
+        for c in range(4):
+            arg = boxes[:, c, None] * mult
+            parts += [arg.sin(), arg.cos()]
+        return torch.cat(parts, dim=-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# models/deformable_transformer.py:169-238 encoder, :241-340 decoder, :27-166 wrapper
+# ----------------------------------------------------------------------------------------------
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, d_ffn, dropout, n_levels, n_heads, n_points):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, ref, shapes, lsi, padding_mask=None):
+        a = self.self_attn(src + pos, ref, src, shapes, lsi, padding_mask)
+        src = self.norm1(src + self.dropout1(a))
+        f = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        return self.norm2(src + self.dropout3(f))
+
+
+class Encoder(nn.Module):
+    def __init__(self, layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    @staticmethod
+    def reference_grid(shapes, valid_ratios):
+        """deformable_transformer.py:217-230."""
+        pieces = []
+        for lvl, (h, w) in enumerate(shapes.tolist()):
+            ys = torch.linspace(0.5, h - 0.5, h, dtype=torch.float32)
+            xs = torch.linspace(0.5, w - 0.5, w, dtype=torch.float32)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            gy = gy.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * h)
+            gx = gx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * w)
+            pieces.append(torch.stack((gx, gy), -1))
+        ref = torch.cat(pieces, 1)
+        return ref[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, shapes, lsi, valid_ratios, pos=None, padding_mask=None):
+        ref = self.reference_grid(shapes, valid_ratios)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, ref, shapes, lsi, padding_mask)
+        return out
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d_model, d_ffn, dropout, n_levels, n_heads, n_points):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    def forward(self, tgt, query_pos, ref, src, shapes, lsi, padding_mask=None):
+        qk = tgt + query_pos
+        a = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(a))
+        c = self.cross_attn(tgt + query_pos, ref, src, shapes, lsi, padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(c))
+        f = self.linear2(self.dropout3(F.relu(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(f))
+
+
+class Decoder(nn.Module):
+    def __init__(self, layer, num_layers, return_intermediate=True):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+
+    def forward(self, tgt, ref, src, shapes, lsi, valid_ratios, query_pos=None, padding_mask=None):
+        assert ref.shape[-1] == 2
+        out, inter, inter_ref = tgt, [], []
+        for layer in self.layers:
+            ref_in = ref[:, :, None] * valid_ratios[:, None]          # :317
+            out = layer(out, query_pos, ref_in, src, shapes, lsi, padding_mask)
+            if self.return_intermediate:
+                inter.append(out)
+                inter_ref.append(ref)
+        if self.return_intermediate:
+            return torch.stack(inter), torch.stack(inter_ref)
+        return out, ref
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=1024, dropout=0.1, return_intermediate_dec=True,
+                 num_feature_levels=4, dec_n_points=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.encoder = Encoder(EncoderLayer(d_model, dim_feedforward, dropout, num_feature_levels,
+                                            nhead, enc_n_points), num_encoder_layers)
+        self.decoder = Decoder(DecoderLayer(d_model, dim_feedforward, dropout, num_feature_levels,
+                                            nhead, dec_n_points), num_decoder_layers,
+                               return_intermediate_dec)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.reference_points = nn.Linear(d_model, 2)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """deformable_transformer.py:52-62."""
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for mod in self.modules():
+            if isinstance(mod, MSDeformAttn):
+                mod._reset_parameters()
+        nn.init.xavier_uniform_(self.reference_points.weight, gain=1.0)
+        nn.init.constant_(self.reference_points.bias, 0.0)
+        nn.init.normal_(self.level_embed)
+
+    @staticmethod
+    def valid_ratio(mask):
+        _, h, w = mask.shape
+        vh = (~mask[:, :, 0]).sum(1).float() / h
+        vw = (~mask[:, 0, :]).sum(1).float() / w
+        return torch.stack([vw, vh], -1)
+
+    def forward(self, srcs, masks, pos_embeds, query_embed=None, reference_points=None):
+        assert query_embed is not None
+        flat_src, flat_mask, flat_pos, shapes = [], [], [], []
+        for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, pos_embeds)):
+            shapes.append(tuple(src.shape[-2:]))
+            flat_src.append(src.flatten(2).transpose(1, 2))
+            flat_mask.append(mask.flatten(1))
+            flat_pos.append(pos.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
+        src = torch.cat(flat_src, 1)
+        mask = torch.cat(flat_mask, 1)
+        pos = torch.cat(flat_pos, 1)
+        shapes = torch.as_tensor(shapes, dtype=torch.long)
+        lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.stack([self.valid_ratio(m) for m in masks], 1)
+        memory = self.encoder(src, shapes, lsi, valid_ratios, pos, mask)
+
+        c = memory.shape[-1]
+        if query_embed.dim() == 2:
+            query_pos, tgt = torch.split(query_embed, c, dim=1)
+            query_pos = query_pos[None].expand(memory.shape[0], -1, -1)
+            tgt = tgt[None].expand(memory.shape[0], -1, -1)
+        else:
+            query_pos, tgt = torch.split(query_embed, c, dim=2)
+        if reference_points is None:
+            reference_points = self.reference_points(query_pos).sigmoid()
+        hs, inter_refs = self.decoder(tgt, reference_points, memory, shapes, lsi, valid_ratios, query_pos, mask)
+        return hs, reference_points, inter_refs, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# models/pose_estimation_transformer.py:677-689 MLP, :434-451 6D->R, :32-451 PoET
+# ----------------------------------------------------------------------------------------------
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, lin in enumerate(self.layers):
+            x = lin(x)
+            if i + 1 < self.num_layers:
+                x = F.relu(x)
+        return x
+
+
+def rotation_6d_to_matrix(rot_6d):
+    bs, nq, _ = rot_6d.shape
+    r = rot_6d.reshape(-1, 6)
+    x = F.normalize(r[:, 0:3], p=2, dim=1)
+    z = F.normalize(torch.cross(x, r[:, 3:6], dim=1), p=2, dim=1)
+    y = torch.cross(z, x, dim=1)
+    return torch.stack((x, y, z), dim=2).view(bs, nq, 3, 3)          # x,y,z are the COLUMNS
+
+
+class SyntheticBackbone(nn.Module):
+    """Stands at the backbone interface (models/backbone.py:26-50 ``Joiner``): frozen, returns
+    pre-made multi-scale feature maps as NestedTensors, their sine encodings, and no detections.
+    ``self[1]`` is the position embedding (pose_estimation_transformer.py:332)."""
+
+    def __init__(self, features: List[torch.Tensor], strides, num_channels, pos_feats=128):
+        super().__init__()
+        self.features = features
+        self.strides, self.num_channels = list(strides), list(num_channels)
+        self.position_embedding = PositionEmbeddingSine(pos_feats, normalize=True)
+        self.train_backbone = False
+
+    def __getitem__(self, idx):
+        return self if idx == 0 else self.position_embedding
+
+    def forward(self, samples: NestedTensor):
+        outs, pos = [], []
+        for f in self.features:
+            m = F.interpolate(samples.mask[None].float(), size=f.shape[-2:]).to(torch.bool)[0]
+            outs.append(NestedTensor(f, m))
+        for x in outs:
+            pos.append(self.position_embedding(x).to(x.tensors.dtype))
+        return outs, pos, None
+
+
+class PoET(nn.Module):
+    def __init__(self, backbone, transformer, num_queries, num_feature_levels, n_classes,
+                 bbox_mode="gt", class_mode="specific", aux_loss=True):
+        super().__init__()
+        self.transformer, self.backbone = transformer, backbone
+        d = transformer.d_model
+        self.hidden_dim, self.n_queries, self.n_classes = d, num_queries, n_classes + 1
+        self.bbox_mode, self.class_mode, self.aux_loss = bbox_mode, class_mode, aux_loss
+        self.num_feature_levels = num_feature_levels
+        mult = self.n_classes if class_mode == "specific" else 1
+        n_pred = transformer.decoder.num_layers
+        self.translation_head = nn.ModuleList([MLP(d, d, 3 * mult, 3) for _ in range(n_pred)])
+        self.rotation_head = nn.ModuleList([MLP(d, d, 6 * mult, 3) for _ in range(n_pred)])
+        projs = []
+        n_bb = len(backbone.strides)
+        cin = None
+        for i in range(n_bb):
+            cin = backbone.num_channels[i]
+            projs.append(nn.Sequential(nn.Conv2d(cin, d, kernel_size=1), nn.GroupNorm(32, d)))
+        for _ in range(num_feature_levels - n_bb):
+            projs.append(nn.Sequential(nn.Conv2d(cin, d, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, d)))
+            cin = d
+        self.input_proj = nn.ModuleList(projs)
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.bbox_embedding = BoundingBoxEmbeddingSine(num_pos_feats=d / 8)
+
+    def assemble_queries(self, targets):
+        """pose_estimation_transformer.py:203-239,309-311 ('gt' mode)."""
+        boxes_all, cls_all, emb_all, n_boxes = [], [], [], []
+        for t in targets:
+            boxes = t["boxes"]
+            nb = len(boxes)
+            n_boxes.append(nb)
+            cls = t["labels"]
+            emb = self.bbox_embedding(boxes).repeat(1, 2)
+            pad = self.n_queries - nb
+            if pad > 0:
+                boxes = torch.vstack((boxes, torch.full((pad, 4), -1.0)))
+                emb = torch.cat([emb, torch.full((pad, 2 * self.hidden_dim), -10.0)], 0)
+                cls = torch.cat((cls, torch.full((pad,), -1, dtype=torch.int32)))
+            boxes_all.append(boxes)
+            emb_all.append(emb)
+            cls_all.append(cls)
+        return torch.stack(emb_all), torch.stack(boxes_all), torch.stack(cls_all), n_boxes
+
+    def forward(self, samples: NestedTensor, targets):
+        features, pos, _ = self.backbone(samples)
+        query_embeds, pred_boxes, pred_classes, n_boxes = self.assemble_queries(targets)
+        srcs, masks = [], []
+        for lvl, feat in enumerate(features):
+            src, mask = feat.decompose()
+            srcs.append(self.input_proj[lvl](src))
+            masks.append(mask)
+        for lvl in range(len(srcs), self.num_feature_levels):
+            inp = features[-1].tensors if lvl == len(features) else srcs[-1]
+            src = self.input_proj[lvl](inp)
+            mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
+            pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+            srcs.append(src)
+            masks.append(mask)
+        ref = pred_boxes[:, :, :2]
+        hs, _, _, _, _ = self.transformer(srcs, masks, pos, query_embeds, ref)
+
+        bs = pred_classes.shape[0]
+        idx = torch.where(pred_classes > 0, pred_classes, 0).view(-1).long()
+        rows = torch.arange(bs * self.n_queries)
+        rots, trans = [], []
+        for lvl in range(hs.shape[0]):
+            r = self.rotation_head[lvl](hs[lvl])
+            t = self.translation_head[lvl](hs[lvl])
+            if self.class_mode == "specific":
+                r = r.view(bs * self.n_queries, self.n_classes, -1)[rows, idx].view(bs, self.n_queries, -1)
+                t = t.view(bs * self.n_queries, self.n_classes, -1)[rows, idx].view(bs, self.n_queries, -1)
+            rots.append(rotation_6d_to_matrix(r))
+            trans.append(t)
+        rots, trans = torch.stack(rots), torch.stack(trans)
+        out = {"pred_translation": trans[-1], "pred_rotation": rots[-1],
+               "pred_boxes": pred_boxes, "pred_classes": pred_classes}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_translation": t, "pred_rotation": r, "pred_boxes": pred_boxes,
+                                   "pred_classes": pred_classes} for t, r in zip(trans[:-1], rots[:-1])]
+        return out, n_boxes
+
+
+# ----------------------------------------------------------------------------------------------
+# models/matcher.py:104-229 PoseMatcher ('gt' mode) and pose_estimation_transformer.py:454-674
+# ----------------------------------------------------------------------------------------------
+class PoseMatcher(nn.Module):
+    def __init__(self, cost_bbox=1.0, cost_class=1.0, bbox_mode="gt"):
+        super().__init__()
+        assert bbox_mode == "gt"
+        self.cost_bbox, self.cost_class = cost_bbox, cost_class
+
+    @torch.no_grad()
+    def forward(self, outputs, targets, n_boxes):
+        from scipy.optimize import linear_sum_assignment
+        bs, nq = outputs["pred_boxes"].shape[:2]
+        out_bbox = outputs["pred_boxes"].flatten(0, 1)
+        tgt_bbox = torch.cat([t["boxes"] for t in targets])
+        cost = (self.cost_bbox * torch.cdist(out_bbox, tgt_bbox, p=1)).view(bs, nq, -1).cpu()
+        sizes = [len(t["boxes"]) for t in targets]
+        res = []
+        for i, c in enumerate(cost.split(sizes, -1)):
+            r, cidx = linear_sum_assignment(c[i][: n_boxes[i]])
+            res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
+        return res
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, matcher, weight_dict):
+        super().__init__()
+        self.matcher, self.weight_dict = matcher, weight_dict
+
+    @staticmethod
+    def _src_idx(indices):
+        b = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        s = torch.cat([src for (src, _) in indices])
+        return b, s
+
+    def _losses(self, outputs, targets, indices):
+        idx = self._src_idx(indices)
+        st = outputs["pred_translation"][idx]
+        tt = torch.cat([t["relative_position"][j] for t, (_, j) in zip(targets, indices)], 0)
+        n_obj = len(tt)
+        loss_t = torch.sqrt(((st - tt) ** 2).sum(1)).sum() / n_obj
+        sr = outputs["pred_rotation"][idx]
+        tr = torch.cat([t["relative_rotation"][j] for t, (_, j) in zip(targets, indices)], 0)
+        prod = torch.bmm(sr, tr.transpose(1, 2))
+        trace = prod[:, torch.eye(3).bool()].sum(1)
+        theta = torch.clamp(0.5 * (trace - 1), -1 + 1e-6, 1 - 1e-6)
+        loss_r = torch.acos(theta).sum() / n_obj
+        return {"loss_trans": loss_t, "loss_rot": loss_r}
+
+    def forward(self, outputs, targets, n_boxes):
+        main = {k: v for k, v in outputs.items() if k != "aux_outputs"}
+        losses = dict(self._losses(outputs, targets, self.matcher(main, targets, n_boxes)))
+        for i, aux in enumerate(outputs.get("aux_outputs", [])):
+            part = self._losses(aux, targets, self.matcher(aux, targets, n_boxes))
+            losses.update({f"{k}_{i}": v for k, v in part.items()})
+        return losses
+
+
+def build_weight_dict(dec_layers, t_coef=1.0, r_coef=1.0, aux=True):
+    wd = {"loss_trans": t_coef, "loss_rot": r_coef}
+    if aux:
+        for i in range(dec_layers - 1):
+            wd.update({f"loss_trans_{i}": t_coef, f"loss_rot_{i}": r_coef})
+    return wd
+
+
+def param_groups(model, lr=2e-4, lr_backbone=2e-5, proj_names=("reference_points", "sampling_offsets"), proj_mult=0.1):
+    """main.py:253-271."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    is_bb = lambda n: "backbone.0" in n
+    is_pr = lambda n: any(k in n for k in proj_names)
+    return [
+        {"params": [p for n, p in named if not is_bb(n) and not is_pr(n)], "lr": lr},
+        {"params": [p for n, p in named if is_bb(n)], "lr": lr_backbone},
+        {"params": [p for n, p in named if is_pr(n)], "lr": lr * proj_mult},
+    ]
+
+
+def build_poet(cfg, features):
+    """cfg: dict(d_model, nheads, enc_layers, dec_layers, d_ffn, n_levels, n_points, num_queries,
+    n_classes, dropout, strides, num_channels)."""
+    bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2)
+    tr = DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"],
+                               cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"])
+    model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], "gt", "specific", True)
+    crit = SetCriterion(PoseMatcher(), build_weight_dict(cfg["dec_layers"]))
+    return model, crit

@@ -1,0 +1,27 @@
+"""Shared helper: run the CPU oracle on a named config (tests only)."""
+import numpy as np
+import torch
+
+from oracle import poet_ref
+from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples
+
+
+def run_oracle(name, batch, pad, seed=1234, backward=True, train=False):
+    cfg = CONFIGS[name]
+    feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
+    model, crit = poet_ref.build_poet(cfg, feats)
+    formula_fill(model)
+    model.train(train)
+    samples = poet_ref.nested_from_list(make_samples(cfg, sizes))
+    cap = {}
+    h1 = model.transformer.encoder.register_forward_hook(lambda m, i, o: cap.__setitem__("memory", o.detach()))
+    h2 = model.transformer.register_forward_hook(lambda m, i, o: cap.__setitem__("hs", o[0].detach()))
+    out, n_boxes = model(samples, targets)
+    h1.remove(); h2.remove()
+    losses = crit(out, targets, n_boxes)
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    if backward:
+        model.zero_grad()
+        total.backward()
+    return dict(cfg=cfg, model=model, crit=crit, out=out, n_boxes=n_boxes, losses=losses, total=total,
+                memory=cap["memory"], hs=cap["hs"], feats=feats, sizes=sizes, targets=targets, samples=samples)

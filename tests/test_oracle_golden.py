@@ -1,0 +1,97 @@
+"""The CPU oracle (oracle/poet_ref.py) must reproduce the imported reference's outputs
+(tests/golden/*.npz, written by oracle/gen_golden.py from /root/reference itself)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import poet_ref, msda_explicit
+from oracle.formula import checksum
+from tests.oracle_runner import run_oracle
+
+ATOL = 2e-5
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_position_embedding_sine(golden_dir):
+    g = _load(golden_dir, "units.npz")
+    mask = torch.from_numpy(g["pe_mask"])
+    pe = poet_ref.PositionEmbeddingSine(128, normalize=True)(poet_ref.NestedTensor(torch.zeros(3, 1, 12, 16), mask))
+    np.testing.assert_allclose(pe.numpy(), g["pe_out"], atol=1e-6, rtol=0)
+
+
+def test_bbox_embedding_sine(golden_dir):
+    g = _load(golden_dir, "units.npz")
+    be = poet_ref.BoundingBoxEmbeddingSine(256 / 8)(torch.from_numpy(g["bbox_in"]))
+    np.testing.assert_allclose(be.numpy(), g["bbox_out"], atol=1e-6, rtol=0)
+
+
+def test_rotation_6d(golden_dir):
+    g = _load(golden_dir, "units.npz")
+    r = poet_ref.rotation_6d_to_matrix(torch.from_numpy(g["rot6d_in"]))
+    np.testing.assert_allclose(r.numpy(), g["rot6d_out"], atol=1e-6, rtol=0)
+
+
+def test_msda_core_vs_hf(golden_dir):
+    """grid_sample restatement and float64 closed form vs HF transformers' independent restatement."""
+    g = _load(golden_dir, "msda_core_hf.npz")
+    shapes = [tuple(int(x) for x in r) for r in g["shapes"]]
+    value = torch.from_numpy(g["value"]).requires_grad_()
+    loc = torch.from_numpy(g["loc"]).requires_grad_()
+    attn = torch.from_numpy(g["attn"]).requires_grad_()
+    out = poet_ref.msda_core(value, shapes, loc, attn)
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], atol=1e-6)
+    (out * torch.from_numpy(g["grad_out"])).sum().backward()
+    np.testing.assert_allclose(value.grad.numpy(), g["d_value"], atol=1e-5)
+    np.testing.assert_allclose(loc.grad.numpy(), g["d_loc"], atol=2e-4)
+    np.testing.assert_allclose(attn.grad.numpy(), g["d_attn"], atol=1e-5)
+    # closed form
+    o2 = msda_explicit.msda_forward(g["value"], shapes, g["loc"], g["attn"])
+    np.testing.assert_allclose(o2, g["out"], atol=2e-6)
+    dv, dl, da = msda_explicit.msda_backward(g["value"], shapes, g["loc"], g["attn"], g["grad_out"])
+    np.testing.assert_allclose(dv, g["d_value"], atol=1e-5)
+    np.testing.assert_allclose(dl, g["d_loc"], atol=2e-4)
+    np.testing.assert_allclose(da, g["d_attn"], atol=1e-5)
+
+
+@pytest.mark.parametrize("name,batch,pad,full", [("tiny", 2, True, True), ("tiny", 2, False, True),
+                                                 ("cfg0", 2, False, True), ("cfg0", 2, True, False)])
+def test_poet_vs_reference(golden_dir, name, batch, pad, full):
+    g = _load(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}.npz")
+    r = run_oracle(name, batch, pad)
+    np.testing.assert_allclose(r["out"]["pred_translation"].detach().numpy(), g["pred_translation"], atol=ATOL)
+    np.testing.assert_allclose(r["out"]["pred_rotation"].detach().numpy(), g["pred_rotation"], atol=ATOL)
+    if g["aux_translation"].size:
+        aux_t = np.stack([a["pred_translation"].detach().numpy() for a in r["out"]["aux_outputs"]])
+        aux_r = np.stack([a["pred_rotation"].detach().numpy() for a in r["out"]["aux_outputs"]])
+        np.testing.assert_allclose(aux_t, g["aux_translation"], atol=ATOL)
+        np.testing.assert_allclose(aux_r, g["aux_rotation"], atol=ATOL)
+    assert list(g["n_boxes"]) == list(r["n_boxes"])
+    names = sorted(r["losses"])
+    assert names == [str(x) for x in g["loss_names"]]
+    np.testing.assert_allclose([float(r["losses"][k]) for k in names], g["loss_values"], rtol=1e-5, atol=1e-6)
+    if full:
+        np.testing.assert_allclose(r["memory"].numpy(), g["memory"], atol=ATOL)
+        np.testing.assert_allclose(r["hs"].numpy(), g["hs"], atol=ATOL)
+    else:
+        np.testing.assert_allclose(checksum(r["memory"]), g["memory_checksum"], rtol=1e-5, atol=1e-5)
+    grads = dict(r["model"].named_parameters())
+    for n, ref_sum in zip(g["grad_names"], g["grad_checksums"]):
+        p = grads[str(n)]
+        if np.isnan(ref_sum).all():
+            assert p.grad is None, n
+            continue
+        got = checksum(p.grad)
+        scale = max(1.0, abs(ref_sum[0]))
+        np.testing.assert_allclose(got, ref_sum, atol=2e-4 * scale, err_msg=str(n))
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    """The compatibility contract: parameter names equal the reference's."""
+    g = _load(golden_dir, "poet_tiny_b2.npz")
+    r = run_oracle("tiny", 2, False, backward=False)
+    assert [str(x) for x in g["grad_names"]] == [n for n, _ in r["model"].named_parameters()]
