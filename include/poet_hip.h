@@ -1,0 +1,256 @@
+/* poet_hip.h -- C ABI of libpoet_hip.so: the MI355X (gfx950) kernels of the PoET encoder-decoder
+ * hot path.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Contract for EVERY entry point:
+ *   - device pointers are caller-owned (the Python host allocates them as torch tensors and
+ *     passes data_ptr()); the library allocates nothing and keeps no mutable global state
+ *     apart from a thread-local last-error string;
+ *   - work is only ENQUEUED on `stream` (a hipStream_t passed as void*); no device sync;
+ *   - returns POET_OK (0) or a negative POET_ERR_* code and never throws;
+ *     poet_hip_last_error() describes the last failure on the calling thread;
+ *   - dtype codes: POET_F32 = fp32 storage, POET_BF16 = bfloat16 storage (fp32 accumulate);
+ *   - host pointers are marked _host.
+ *
+ * What each function replaces in the reference (paths relative to aau-cns/poet):
+ *   poet_msda_fwd / poet_msda_bwd
+ *       the un-vendored CUDA extension behind `from deformable_attention import MSDeformAttn`
+ *       (models/deformable_transformer.py:24): upstream's pybind pair
+ *       ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc,
+ *       attn_weight, im2col_step) / ms_deform_attn_backward(..., grad_output).
+ *   poet_msda_fused_fwd / _bwd
+ *       the same sampling with MSDeformAttn.forward's softmax over L*P logits and the
+ *       loc = ref + offset/(W,H) arithmetic folded in (models/deformable_transformer.py:201,283).
+ *   poet_gemm
+ *       every nn.Linear / 1x1 nn.Conv2d on the path (deformable_transformer.py:182,185,258,261,
+ *       the 4 Linears of MSDeformAttn, nn.MultiheadAttention's in/out projections :253,
+ *       pose_estimation_transformer.py:106-122,684-688) and their backward contractions.
+ *   poet_ln_fwd / poet_ln_bwd
+ *       `x = norm(x + dropout(y))`  (deformable_transformer.py:202-203,195-196,279-287,271-272).
+ *   poet_mha_fwd / poet_mha_bwd
+ *       nn.MultiheadAttention core over <=64 queries (deformable_transformer.py:277-278).
+ *   poet_pos_sine / poet_bbox_sine
+ *       models/position_encoding.py:40-60 and :71-84.
+ *   poet_groupnorm_* / poet_im2col3x3s2 / poet_nchw_to_tokens / poet_tokens_to_nchw
+ *       input_proj and the flatten/transposes (pose_estimation_transformer.py:100-135,313-335;
+ *       deformable_transformer.py:128-141).
+ *   poet_enc_ref_points        deformable_transformer.py:217-230.
+ *   poet_pose_finish_fwd/_bwd  class-slice gather + 6D->R (pose_estimation_transformer.py:354-393,434-451).
+ *   poet_adamw / poet_sqnorm   optimizer.step + clip_grad_norm_ over the flat arenas (engine.py:75-81).
+ */
+#ifndef POET_HIP_H
+#define POET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POET_ABI_VERSION 1
+
+#define POET_F32 0
+#define POET_BF16 1
+
+#define POET_OK 0
+#define POET_ERR_ARG (-1)
+#define POET_ERR_UNSUPPORTED (-2)
+#define POET_ERR_LAUNCH (-3)
+
+int poet_hip_version(void);
+const char* poet_hip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused prologue/epilogue:  C = epilogue( alpha * opA(A [+A2]) . opB(B) )
+ *   A is [M,K] (a_kmajor=0, row stride lda) or stored [K,M] (a_kmajor=1, row stride lda);
+ *   B is [N,K] (b_kmajor=0, i.e. nn.Linear weight layout) or stored [K,N] (b_kmajor=1).
+ *   compute = POET_BF16 -> v_mfma_f32_16x16x32_bf16, POET_F32 -> v_mfma_f32_16x16x4_f32.
+ *   epilogue order: +bias[col] -> act -> gate (gate_ref[row,col] > 0 ? v*gate_scale : 0)
+ *                   -> dropout(drop_p, seed; index = row*N+col) -> +add_src[row,col]
+ *                   -> row_mask (row_mask[row] != 0 -> 0) -> store.
+ *   out_mode 0: C[row*ldc + col].  out_mode 1 (head-major value maps): row=(n,s), col=(m,d) ->
+ *               C[((n*hm_M + m)*hm_S + s)*hm_D + d].
+ *   batch > 1: A/B/C advance by strideA/B/C elements per batch index (bias shared or strided by
+ *   stride_bias).  splitk > 1 or atomic != 0: fp32 atomicAdd into C (C must be f32, pre-zeroed
+ *   or holding the value to accumulate onto); bias/act/gate are then not allowed.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct PoetGemmDesc {
+    const void* A;
+    const void* A2;        /* optional, same dtype/layout as A, added on load */
+    const void* B;
+    void* C;
+    const float* bias;     /* optional [N] */
+    const void* add_src;   /* optional, dtype c_dtype, [M, ld_add] */
+    const void* gate_ref;  /* optional, dtype c_dtype, [M, ldc] */
+    const uint8_t* row_mask; /* optional [M] */
+    int32_t M, N, K;
+    int64_t lda, ldb, ldc, ld_add;
+    int32_t a_kmajor, b_kmajor;
+    int32_t a_dtype, b_dtype, c_dtype, compute;
+    int32_t batch;
+    int64_t strideA, strideB, strideC, stride_bias;
+    int32_t splitk, atomic;
+    int32_t act;           /* 0 none, 1 relu */
+    float alpha;
+    float gate_scale;
+    float drop_p;
+    uint32_t seed;
+    int32_t out_mode, hm_M, hm_S, hm_D;
+} PoetGemmDesc;
+int poet_gemm(const PoetGemmDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention core (upstream boundary).  Layouts as upstream:
+ *   value (N,S,M,D), sampling_loc (N,Lq,M,L,P,2) in [0,1], attn_weight (N,Lq,M,L,P), out (N,Lq,M*D),
+ *   spatial_shapes_host (L,2) int64 = (H_l, W_l), level_start_host (L,) int64.
+ *   All device tensors share `dtype`.  grad_value is ALWAYS fp32 (N,S,M,D) and is zero-filled by
+ *   the call before accumulation (atomics); grad_loc / grad_attn have `dtype`.
+ * ---------------------------------------------------------------------------------------------- */
+int poet_msda_fwd(const void* value, const int64_t* spatial_shapes_host, const int64_t* level_start_host,
+                  const void* sampling_loc, const void* attn_weight, void* out,
+                  int N, int S, int M, int D, int L, int P, int Lq, int dtype, void* stream);
+int poet_msda_bwd(const void* value, const int64_t* spatial_shapes_host, const int64_t* level_start_host,
+                  const void* sampling_loc, const void* attn_weight, const void* grad_out,
+                  float* grad_value, void* grad_loc, void* grad_attn,
+                  int N, int S, int M, int D, int L, int P, int Lq, int dtype, void* stream);
+
+/* Fused form: `offattn` (N,Lq,ldq) holds the raw outputs of the sampling_offsets Linear at columns
+ * [0, M*L*P*2) and of the attention_weights Linear at columns [logit_col, logit_col + M*L*P).
+ * ref (Nref,Lq,L,2) fp32 are the reference points already multiplied by valid ratios; Nref is 1
+ * (ref_batch_stride = 0) or N.  value is addressed by element strides (vs_n, vs_s, vs_m), so both
+ * the upstream (N,S,M,D) and the head-major (N,M,S,D) layouts are accepted.  out (N,Lq,M*D) q_dtype.
+ * Backward: grad_value fp32, same strides as value, accumulated atomically (caller zero-fills);
+ * grad_offattn (N,Lq,ldq) q_dtype receives d/d(offsets) and d/d(logits) (softmax backward folded). */
+int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m,
+                        const int64_t* spatial_shapes_host, const int64_t* level_start_host,
+                        const void* offattn, int64_t ldq, int logit_col,
+                        const float* ref, int64_t ref_batch_stride, void* out,
+                        int N, int S, int M, int D, int L, int P, int Lq,
+                        int v_dtype, int q_dtype, void* stream);
+int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m,
+                        const int64_t* spatial_shapes_host, const int64_t* level_start_host,
+                        const void* offattn, int64_t ldq, int logit_col,
+                        const float* ref, int64_t ref_batch_stride, const void* grad_out,
+                        float* grad_value, void* grad_offattn,
+                        int N, int S, int M, int D, int L, int P, int Lq,
+                        int v_dtype, int q_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * y = LayerNorm(res + dropout(x)) over the last dim d (d % 4 == 0, d <= 1024), one wave per row.
+ * Two storage types: the branch side (x, z_out, dx_out) has dtype_x, the residual-stream side
+ * (res, y, dy, dz_out) has dtype_r -- (bf16,bf16), (f32,f32) or the mixed (bf16 branch, f32 stream).
+ * z_out (optional) receives the pre-norm sum; mean/rstd (fp32 [rows]) are saved for backward.
+ * Backward: dz = dLN(dy); d_res := dz (written to dz_out); dx_out (optional, may alias dz_out when
+ * drop_p == 0) := dz * keepmask/(1-p).  dgamma/dbeta (fp32 [d]) are ACCUMULATED atomically.
+ * ---------------------------------------------------------------------------------------------- */
+int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                void* y, void* z_out, float* mean, float* rstd,
+                int64_t rows, int d, float eps, float drop_p, uint32_t seed, int dtype_x, int dtype_r, void* stream);
+int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                void* dz_out, void* dx_out, float* dgamma, float* dbeta,
+                int64_t rows, int d, float drop_p, uint32_t seed, int dtype_x, int dtype_r, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small multi-head self-attention core (nn.MultiheadAttention without the projections):
+ * q,k,v (N,Q,M*hd) fp32 with row stride ld (so they may be column slices of one packed buffer);
+ * out (N,Q,M*hd).  Q <= 64, hd <= 64.  softmax(q k^T / sqrt(hd)) with dropout(p) on the
+ * probabilities, no key-padding mask (the reference passes none).
+ * ---------------------------------------------------------------------------------------------- */
+int poet_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, float* out, int64_t ld_out,
+                 int N, int Q, int M, int hd, float drop_p, uint32_t seed, void* stream);
+int poet_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dout, int64_t ld_out,
+                 float* dq, float* dk, float* dv, int64_t ld_d,
+                 int N, int Q, int M, int hd, float drop_p, uint32_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Position encodings (fp32 math, full-range sinf/cosf).
+ * poet_pos_sine: mask (N,H,W) uint8 (1 = padded) -> out token-major (N, tok_stride rows, 2F) written
+ *   at rows [tok_off, tok_off+H*W): first F channels y-features, then F x-features
+ *   (position_encoding.py:40-60, normalize=True, scale 2*pi); dim_t (F) fp32 is the host-computed
+ *   constant table temperature^(2*(i//2)/F) (a 1-ulp difference in it flips sin() where fully
+ *   masked rows/columns push the argument to ~1e6, so it is taken as data, not recomputed); optional
+ *   level_embed (2F) fp32 is added (deformable_transformer.py:137).  out dtype = dtype.
+ * poet_bbox_sine: boxes (n,4) fp32 -> (n, 8F) fp32, [sin(c*2^k) | cos(c*2^k)] per coordinate; rows with
+ *   valid[i] == 0 (optional) are the padded dummy queries and get the constant `fill` (-10,
+ *   pose_estimation_transformer.py:225-236).
+ * ---------------------------------------------------------------------------------------------- */
+int poet_pos_sine(const uint8_t* mask, void* out, const float* level_embed, const float* dim_t,
+                  int N, int H, int W, int F, int64_t tok_off, int64_t tok_stride, int dtype, void* stream);
+int poet_bbox_sine(const float* boxes, const uint8_t* valid, float* out, int n, int F, float fill, void* stream);
+
+/* encoder reference points (deformable_transformer.py:217-230): valid_ratios (N,L,2) fp32 (w,h)
+ * -> ref (N,S,L,2) fp32. */
+int poet_enc_ref_points(const float* valid_ratios, const int64_t* spatial_shapes_host, float* ref,
+                        int N, int L, int S, void* stream);
+/* decoder reference points (deformable_transformer.py:317): ref (N,Q,2) x valid_ratios (N,L,2)
+ * -> (N,Q,L,2). */
+int poet_dec_ref_points(const float* ref, const float* valid_ratios, float* out, int N, int Q, int L, void* stream);
+/* valid ratios of a padding mask (deformable_transformer.py:111-118): mask (N,H,W) uint8 ->
+ * out[n*out_stride + 0..1] = (valid_w/W, valid_h/H) fp32. */
+int poet_valid_ratio(const uint8_t* mask, float* out, int64_t out_stride, int N, int H, int W, void* stream);
+/* nearest-neighbour mask resize == F.interpolate(mask[None].float(), size).bool()
+ * (pose_estimation_transformer.py:328-329): src index = floor(dst * in / out). */
+int poet_mask_nearest(const uint8_t* src, uint8_t* dst, int N, int H, int W, int Ho, int Wo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / layout helpers.
+ * ---------------------------------------------------------------------------------------------- */
+int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* x[row, :] += vec[:] for rows [row0, row0+rows) of every batch item (batch stride in rows). */
+int poet_add_rowvec(void* x, const float* vec, int batch, int64_t batch_stride_rows, int64_t row0, int64_t rows,
+                    int cols, int dtype, void* stream);
+int poet_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* out[seg, col] += sum over rows of segment seg.  x (batch, rows_per_batch, cols) row stride ld;
+ * seg_start_host (nseg+1) row boundaries inside one batch item.  out fp32 (nseg, cols) accumulated. */
+int poet_colsum(const void* x, int64_t ld, float* out, int batch, int64_t rows_per_batch, int cols,
+                const int64_t* seg_start_host, int nseg, int dtype, void* stream);
+/* fp32 value-gradient maps (addressed by strides, see fused MSDA) -> (N*S, M*D) row-major `dtype`,
+ * rows with row_mask != 0 zeroed (masked_fill backward). */
+int poet_vgrad_to_rows(const float* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
+                       void* out, int N, int S, int M, int D, int dtype, void* stream);
+/* NCHW (N,C,H,W) <-> token-major rows [tok_off, tok_off+H*W) of (N, tok_stride, C). */
+int poet_nchw_to_tokens(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
+                        int src_dtype, int dst_dtype, void* stream);
+int poet_tokens_to_nchw(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
+                        int src_dtype, int dst_dtype, void* stream);
+/* im2col for the 3x3 stride-2 pad-1 conv of the extra level: src NCHW -> (N*Ho*Wo, C*9) with
+ * k = c*9 + ky*3 + kx (the flattening of nn.Conv2d's weight). */
+int poet_im2col3x3s2(const void* src, void* dst, int N, int C, int H, int W, int Ho, int Wo,
+                     int src_dtype, int dst_dtype, void* stream);
+
+/* GroupNorm over token-major maps.  x (and dx) live at rows [x_off, x_off+HW) of (N, x_stride, C);
+ * y (and dy) at rows [y_off, y_off+HW) of (N, y_stride, C) -- so the conv output can stay compact
+ * while the normalised map lands directly in the flattened multi-level sequence.  G groups,
+ * stats (N,G,2) fp32 = (mean, rstd).  Backward accumulates dgamma/dbeta (fp32 [C]). */
+int poet_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                       int N, int HW, int C, int G, int64_t x_off, int64_t x_stride,
+                       int64_t y_off, int64_t y_stride, float eps, int dtype_x, int dtype_y, void* stream);
+int poet_groupnorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma,
+                       void* dx, float* dgamma, float* dbeta,
+                       int N, int HW, int C, int G, int64_t x_off, int64_t x_stride,
+                       int64_t y_off, int64_t y_stride, int dtype_x, int dtype_y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pose heads tail: rot_all (R, ncls*6), trans_all (R, ncls*3) fp32, cls (R,) int32 (<=0 -> slot 0)
+ * -> rot (R,3,3) via Gram-Schmidt with x,y,z as COLUMNS, trans (R,3).  Backward scatters into the
+ * selected class slot (other slots get zero).
+ * ---------------------------------------------------------------------------------------------- */
+int poet_pose_finish_fwd(const float* rot_all, const float* trans_all, const int32_t* cls,
+                         float* rot, float* trans, int R, int ncls, void* stream);
+int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* drot, const float* dtrans,
+                         float* drot_all, float* dtrans_all, int R, int ncls, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat-arena optimizer pieces.  poet_sqnorm: out[0] += sum(g^2) (fp32, caller zero-fills).
+ * poet_adamw: torch.optim.AdamW semantics on a flat fp32 range; grads are first multiplied by
+ * clip = min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) when sqnorm != NULL; optionally writes the
+ * bf16 shadow copy of the updated parameters.
+ * ---------------------------------------------------------------------------------------------- */
+int poet_sqnorm(const float* g, int64_t n, float* out, void* stream);
+int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
+               float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+               const float* sqnorm, float max_norm, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POET_HIP_H */

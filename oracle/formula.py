@@ -71,7 +71,7 @@ def formula_fill(model: torch.nn.Module) -> None:
             val = 0.5 * _wave(n, name)
         elif p.dim() >= 2:
             fan_in = p[0].numel()
-            val = math.sqrt(3.0 / fan_in) * 1.2 * _wave(n, name)
+            val = math.sqrt(2.0 / fan_in) * _wave(n, name)          # variance 1/fan_in == xavier_uniform for square maps
         else:
             val = 0.05 * _wave(n, name)
         p.copy_(val.view_as(p).to(p.dtype))

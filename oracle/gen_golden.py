@@ -102,14 +102,29 @@ def _ref_model(cfg, feats):
     return model, crit
 
 
-def _run_model(name, batch, pad, full):
+INIT_SEED = 4321
+
+
+def _run_model(name, batch, pad, full, default_init=False):
     from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples, checksum
     from util.misc import nested_tensor_from_tensor_list
 
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=1234, batch=batch, pad=pad)
-    model, crit = _ref_model(cfg, feats)
-    formula_fill(model)
+    if default_init:
+        # the reference's own initialisation under a fixed seed; the oracle / HIP modules consume the RNG in the
+        # same order, which is asserted here against the oracle and re-checked in the tests via param checksums
+        from oracle import poet_ref
+        torch.manual_seed(INIT_SEED)
+        model, crit = _ref_model(cfg, feats)
+        torch.manual_seed(INIT_SEED)
+        omodel, _ = poet_ref.build_poet(cfg, feats)
+        osd = omodel.state_dict()
+        for k, v in model.state_dict().items():
+            assert torch.equal(v, osd[k]), f"default init differs at {k}"
+    else:
+        model, crit = _ref_model(cfg, feats)
+        formula_fill(model)
     model.eval()
     crit.eval()
     samples = nested_tensor_from_tensor_list(make_samples(cfg, sizes))
@@ -148,7 +163,10 @@ def _run_model(name, batch, pad, full):
         sums.append(checksum(p.grad) if p.grad is not None else np.full(9, np.nan))
     rec["grad_names"] = np.asarray(names)
     rec["grad_checksums"] = np.stack(sums)
-    tag = f"{name}_b{batch}{'_pad' if pad else ''}"
+    if default_init:
+        rec["param_names"] = np.asarray([n for n, _ in model.named_parameters()])
+        rec["param_checksums"] = np.stack([checksum(p) for _, p in model.named_parameters()])
+    tag = f"{name}_b{batch}{'_pad' if pad else ''}{'_init' if default_init else ''}"
     np.savez_compressed(os.path.join(GOLD, f"poet_{tag}.npz"), **rec)
     print("wrote", tag, "loss", float(total))
 
@@ -215,6 +233,8 @@ def main():
     _run_model("cfg0", 2, False, True)
     _run_model("cfg0", 2, True, False)
     _run_model("ycbv", 1, False, False)
+    _run_model("ycbv", 1, False, False, default_init=True)
+    _run_model("tiny", 2, True, True, default_init=True)
     subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", "--hf"], cwd=ROOT)
 
 

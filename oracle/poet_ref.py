@@ -377,8 +377,9 @@ class PoET(nn.Module):
         self.num_feature_levels = num_feature_levels
         mult = self.n_classes if class_mode == "specific" else 1
         n_pred = transformer.decoder.num_layers
-        self.translation_head = nn.ModuleList([MLP(d, d, 3 * mult, 3) for _ in range(n_pred)])
-        self.rotation_head = nn.ModuleList([MLP(d, d, 6 * mult, 3) for _ in range(n_pred)])
+        # construction order (and hence RNG consumption) as pose_estimation_transformer.py:85-144
+        self.translation_head = t_head = MLP(d, d, 3 * mult, 3)    # registered first, replaced by the ModuleList below
+        self.rotation_head = r_head = MLP(d, d, 6 * mult, 3)       # (keeps the reference's parameter order)
         projs = []
         n_bb = len(backbone.strides)
         cin = None
@@ -392,6 +393,8 @@ class PoET(nn.Module):
         for proj in self.input_proj:
             nn.init.xavier_uniform_(proj[0].weight, gain=1)
             nn.init.constant_(proj[0].bias, 0)
+        self.translation_head = nn.ModuleList([copy.deepcopy(t_head) for _ in range(n_pred)])
+        self.rotation_head = nn.ModuleList([copy.deepcopy(r_head) for _ in range(n_pred)])
         self.bbox_embedding = BoundingBoxEmbeddingSine(num_pos_feats=d / 8)
 
     def assemble_queries(self, targets):

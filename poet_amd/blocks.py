@@ -1,0 +1,313 @@
+"""Forward/backward kernel programs of the PoET hot path (no autograd here).
+
+Each function is a straight-line sequence of libpoet_hip.so launches on torch-owned buffers.
+Reference arithmetic restated (paths relative to aau-cns/poet):
+  value_proj_* / sample_*   MSDeformAttn.forward (external op; call sites
+                            models/deformable_transformer.py:201,283; spec SURVEY.md App. A)
+  proj_ln_*                 `x = norm(x + dropout(proj(y)))`  deformable_transformer.py:202-203,279-287
+  ffn_*                     forward_ffn  deformable_transformer.py:193-197,269-273
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+_seed_state = {"base": 0x1234567, "count": 0}
+EXP = {}     # experiment knobs (dtype overrides), empty in production
+
+
+def manual_seed(seed: int):
+    _seed_state["base"] = (int(seed) * 2654435761 + 12345) & 0xFFFFFFFF
+    _seed_state["count"] = 0
+
+
+def next_seed() -> int:
+    _seed_state["count"] += 1
+    return (_seed_state["base"] + _seed_state["count"] * 0x9E3779B1) & 0xFFFFFFFF
+
+
+def empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+class GradSink:
+    """Hands out fp32 gradient buffers for parameters.  A parameter that carries `_grad_view`
+    (a slice of the flat gradient arena, see poet_amd.engine.ParamArena) is written in place and
+    autograd gets None for it; otherwise a zero-filled tensor is created and returned to autograd."""
+
+    def __init__(self, names, params):
+        self.index = {n: i for i, n in enumerate(names)}
+        self.params = params
+        self.ret = [None] * len(params)
+
+    def __call__(self, name):
+        i = self.index[name]
+        p = self.params[i]
+        gv = getattr(p, "_grad_view", None)
+        if gv is not None:
+            return gv
+        if self.ret[i] is None:
+            self.ret[i] = torch.zeros_like(p, dtype=torch.float32)
+        return self.ret[i]
+
+
+def vstrides(M, S, D):
+    """element strides (n, s, m) of a head-major (N,M,S,D) value map"""
+    return (M * S * D, D, S * D)
+
+
+# ---- (a) value projection ------------------------------------------------------------------------
+def value_proj_fwd(inp2d, W, b, row_mask, N, S, M, D, act=None):
+    V = empty((N, M, S, D), act or inp2d.dtype, inp2d)
+    ops.linear_fwd(inp2d, W, b, V, row_mask=row_mask, head_major=(M, S, D))
+    return V
+
+
+def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate, act=None):
+    rows, d = N * S, M * D
+    dVr = empty((rows, d), act or inp2d.dtype, inp2d)
+    ops.vgrad_to_rows(dV, vstrides(M, S, D), row_mask, dVr, N, S, M, D)
+    ops.linear_dw(dVr, inp2d, gW, rows=rows)
+    ops.colsum(dVr, d, gb, 1, rows, d)
+    if dinp is not None:
+        ops.linear_dx(dVr, W, dinp, rows=rows, add_src=dinp if accumulate else None)
+
+
+# ---- (b) offsets/logits projection + fused deformable sampling ----------------------------------
+def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P, act=None):
+    mlp = M * geom.L * P
+    ldq, rows = 3 * mlp, N * Lq
+    OA = empty((rows, ldq), act or q2d.dtype, q2d)
+    ops.linear_fwd(q2d, so_w, so_b, OA, ldc=ldq)
+    ops.linear_fwd(q2d, aw_w, aw_b, OA[:, 2 * mlp:], ldc=ldq)
+    out = empty((rows, M * D), OA.dtype, q2d)
+    ops.msda_fused_fwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq)
+    return out, OA
+
+
+def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P, dV, g_so_w, g_so_b, g_aw_w, g_aw_b,
+               dq, dq_accumulate, seg_sums=None):
+    mlp = M * geom.L * P
+    ldq, rows = 3 * mlp, N * Lq
+    dOA = torch.empty_like(OA)
+    ops.msda_fused_bwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq)
+    ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldq)
+    ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldq)
+    if seg_sums is not None:      # per-level column sums (encoder): feeds both the biases and level_embed
+        ops.colsum(dOA, ldq, seg_sums, N, Lq, ldq, geom.c_segs, geom.L)
+        ops.colsum(seg_sums, ldq, g_so_b, 1, geom.L, 2 * mlp)
+        ops.colsum(seg_sums[:, 2 * mlp:], ldq, g_aw_b, 1, geom.L, mlp)
+    else:
+        ops.colsum(dOA, ldq, g_so_b, 1, rows, 2 * mlp)
+        ops.colsum(dOA[:, 2 * mlp:], ldq, g_aw_b, 1, rows, mlp)
+    if dq is not None:
+        ops.linear_dx(dOA, so_w, dq, rows=rows, ldy=ldq, add_src=dq if dq_accumulate else None)
+        ops.linear_dx(dOA[:, 2 * mlp:], aw_w, dq, rows=rows, ldy=ldq, add_src=dq)
+
+
+# ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
+def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed):
+    rows, d = res.shape[0], W.shape[0]
+    tmp = empty((rows, d), x_in.dtype, res)          # branch dtype
+    ops.linear_fwd(x_in, W, b, tmp)
+    y = torch.empty_like(res)                        # residual-stream dtype
+    z = torch.empty_like(tmp)
+    mean = empty((rows,), torch.float32, res)
+    rstd = empty((rows,), torch.float32, res)
+    ops.ln_fwd(tmp, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, p, seed)
+    return y, (z, mean, rstd)
+
+
+def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_ref=None, gate_scale=1.0):
+    z, mean, rstd = saved
+    rows, d = z.shape
+    dz = torch.empty_like(dy)
+    separate = p > 0 or z.dtype != dy.dtype
+    dxo = torch.empty_like(z) if separate else dz
+    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dxo if separate else None, ggamma, gbeta, rows, d, p, seed)
+    ops.linear_dw(dxo, x_in, gW, rows=rows)
+    ops.colsum(dxo, d, gb, 1, rows, d)
+    dx_in = empty((rows, W.shape[1]), x_in.dtype, x_in)
+    ops.linear_dx(dxo, W, dx_in, rows=rows, gate_ref=gate_ref, gate_scale=gate_scale)
+    return dz, dx_in
+
+
+# ---- (d) FFN block -------------------------------------------------------------------------------
+def ffn_fwd(x, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None):
+    rows = x.shape[0]
+    Hd = empty((rows, W1.shape[0]), act or x.dtype, x)
+    ops.linear_fwd(x, W1, b1, Hd, act=1, drop_p=p_h, seed=seed_h)
+    y, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o)
+    return y, (Hd, ln_saved)
+
+
+def ffn_bwd(dy, x, W1, W2, gamma, saved, p_h, p_o, seed_o, gW1, gb1, gW2, gb2, ggamma, gbeta):
+    Hd, ln_saved = saved
+    rows, f = Hd.shape
+    dz, dh = proj_ln_bwd(dy, Hd, W2, gamma, ln_saved, p_o, seed_o, gW2, gb2, ggamma, gbeta,
+                         gate_ref=Hd, gate_scale=1.0 / (1.0 - p_h) if p_h > 0 else 1.0)
+    ops.linear_dw(dh, x, gW1, rows=rows)
+    ops.colsum(dh, f, gb1, 1, rows, f)
+    ops.linear_dx(dh, W1, dz, rows=rows, add_src=dz)
+    return dz
+
+
+# ---- encoder layer ---------------------------------------------------------------------------------
+ENC_PARAMS = ("self_attn.sampling_offsets.weight", "self_attn.sampling_offsets.bias",
+              "self_attn.attention_weights.weight", "self_attn.attention_weights.bias",
+              "self_attn.value_proj.weight", "self_attn.value_proj.bias",
+              "self_attn.output_proj.weight", "self_attn.output_proj.bias",
+              "norm1.weight", "norm1.bias", "linear1.weight", "linear1.bias",
+              "linear2.weight", "linear2.bias", "norm2.weight", "norm2.bias")
+
+
+def enc_layer_fwd(src, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None):
+    """src,pos (N*S,d) T.  P_: dict name->param.  Returns (out, saved)."""
+    S, d = geom.S, src.shape[1]
+    D = d // M
+    pd = p if training else 0.0
+    seeds = [next_seed() for _ in range(3)]
+    q = torch.empty_like(src)
+    ops.add(src, pos, q)
+    V = value_proj_fwd(src, P_["self_attn.value_proj.weight"], P_["self_attn.value_proj.bias"], mask, N, S, M, D,
+                       EXP.get("v", act))
+    out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
+                           P_["self_attn.attention_weights.weight"], P_["self_attn.attention_weights.bias"],
+                           V, geom, ref, ref_bs, N, S, M, D, npts, EXP.get("oa", act))
+    x1, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
+                          P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0])
+    x2, ffn = ffn_fwd(x1, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
+                      P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], EXP.get("h", act))
+    saved = dict(src=src, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1, ffn=ffn, seeds=seeds, pd=pd)
+    return x2, saved
+
+
+def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_level):
+    """G: GradSink; pre: name prefix of this layer's params.  Returns d(src)."""
+    S, d = geom.S, dx2.shape[1]
+    D = d // M
+    pd, seeds = sv["pd"], sv["seeds"]
+    g = lambda n: G(pre + n)
+    dx1 = ffn_bwd(dx2, sv["x1"], P_["linear1.weight"], P_["linear2.weight"], P_["norm2.weight"], sv["ffn"], pd, pd,
+                  seeds[2], g("linear1.weight"), g("linear1.bias"), g("linear2.weight"), g("linear2.bias"),
+                  g("norm2.weight"), g("norm2.bias"))
+    dsrc, d_out_m = proj_ln_bwd(dx1, sv["out_m"], P_["self_attn.output_proj.weight"], P_["norm1.weight"], sv["ln1"], pd,
+                                seeds[0], g("self_attn.output_proj.weight"), g("self_attn.output_proj.bias"),
+                                g("norm1.weight"), g("norm1.bias"))
+    dV = torch.zeros(sv["V"].shape, dtype=torch.float32, device=dx2.device)
+    mlp = M * geom.L * npts
+    seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
+    sample_bwd(d_out_m, sv["q"], sv["OA"], P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"],
+               sv["V"], geom, ref, ref_bs, N, S, M, D, npts, dV,
+               g("self_attn.sampling_offsets.weight"), g("self_attn.sampling_offsets.bias"),
+               g("self_attn.attention_weights.weight"), g("self_attn.attention_weights.bias"),
+               dsrc, True, seg_sums=seg)
+    # d(level_embed)[l] += colsum_l(dOA) @ [W_so ; W_aw]   (pos = sine + level_embed, q = src + pos)
+    if g_level is not None:
+        so_w, aw_w = P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"]
+        ops.gemm(seg, so_w, g_level, geom.L, d, 2 * mlp, lda=3 * mlp, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
+        ops.gemm(seg[:, 2 * mlp:], aw_w, g_level, geom.L, d, mlp, lda=3 * mlp, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
+    value_proj_bwd(dV, sv["src"], P_["self_attn.value_proj.weight"], mask, N, S, M, D,
+                   g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), dsrc, True, sv["V"].dtype)
+    return dsrc
+
+
+# ---- decoder layer ---------------------------------------------------------------------------------
+DEC_PARAMS = ("cross_attn.sampling_offsets.weight", "cross_attn.sampling_offsets.bias",
+              "cross_attn.attention_weights.weight", "cross_attn.attention_weights.bias",
+              "cross_attn.value_proj.weight", "cross_attn.value_proj.bias",
+              "cross_attn.output_proj.weight", "cross_attn.output_proj.bias",
+              "norm1.weight", "norm1.bias",
+              "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+              "norm2.weight", "norm2.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+              "norm3.weight", "norm3.bias")
+
+
+def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training):
+    """tgt,qpos (N*Q,d) fp32; V head-major value map of the encoder memory for this layer."""
+    d = tgt.shape[1]
+    D, rows = d // M, N * Q
+    pd = p if training else 0.0
+    seeds = [next_seed() for _ in range(5)]
+    Win, bin_ = P_["self_attn.in_proj_weight"], P_["self_attn.in_proj_bias"]
+    qk = torch.empty_like(tgt)
+    ops.add(tgt, qpos, qk)
+    packed = empty((rows, 3 * d), torch.float32, tgt)
+    ops.linear_fwd(qk, Win[: 2 * d], bin_[: 2 * d], packed, ldc=3 * d)
+    ops.linear_fwd(tgt, Win[2 * d:], bin_[2 * d:], packed[:, 2 * d:], ldc=3 * d)
+    att = empty((rows, d), torch.float32, tgt)
+    ops.mha_fwd(packed, packed[:, d:], packed[:, 2 * d:], 3 * d, att, d, N, Q, M, D, pd, seeds[0])
+    t1, ln2 = proj_ln_fwd(att, P_["self_attn.out_proj.weight"], P_["self_attn.out_proj.bias"], tgt,
+                          P_["norm2.weight"], P_["norm2.bias"], pd, seeds[1])
+    q2 = torch.empty_like(t1)
+    ops.add(t1, qpos, q2)
+    out_m, OA = sample_fwd(q2, P_["cross_attn.sampling_offsets.weight"], P_["cross_attn.sampling_offsets.bias"],
+                           P_["cross_attn.attention_weights.weight"], P_["cross_attn.attention_weights.bias"],
+                           V, geom, ref_in, Q * geom.L * 2, N, Q, M, D, npts)
+    t2, ln1 = proj_ln_fwd(out_m, P_["cross_attn.output_proj.weight"], P_["cross_attn.output_proj.bias"], t1,
+                          P_["norm1.weight"], P_["norm1.bias"], pd, seeds[2])
+    t3, ffn = ffn_fwd(t2, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
+                      P_["norm3.weight"], P_["norm3.bias"], pd, pd, seeds[3], seeds[4])
+    saved = dict(tgt=tgt, qk=qk, packed=packed, att=att, ln2=ln2, t1=t1, q2=q2, OA=OA, out_m=out_m, ln1=ln1, t2=t2,
+                 ffn=ffn, seeds=seeds, pd=pd, V=V)
+    return t3, saved
+
+
+def dec_layer_bwd(dt3, sv, P_, G, pre, ref_in, geom, N, Q, M, npts, dV):
+    """Returns d(tgt).  dV (fp32, zeroed) receives the value-map gradient of this layer."""
+    d = dt3.shape[1]
+    D, rows = d // M, N * Q
+    pd, seeds = sv["pd"], sv["seeds"]
+    g = lambda n: G(pre + n)
+    dt2 = ffn_bwd(dt3, sv["t2"], P_["linear1.weight"], P_["linear2.weight"], P_["norm3.weight"], sv["ffn"], pd, pd,
+                  seeds[4], g("linear1.weight"), g("linear1.bias"), g("linear2.weight"), g("linear2.bias"),
+                  g("norm3.weight"), g("norm3.bias"))
+    dt1, d_out_m = proj_ln_bwd(dt2, sv["out_m"], P_["cross_attn.output_proj.weight"], P_["norm1.weight"], sv["ln1"], pd,
+                               seeds[2], g("cross_attn.output_proj.weight"), g("cross_attn.output_proj.bias"),
+                               g("norm1.weight"), g("norm1.bias"))
+    sample_bwd(d_out_m, sv["q2"], sv["OA"], P_["cross_attn.sampling_offsets.weight"], P_["cross_attn.attention_weights.weight"],
+               sv["V"], geom, ref_in, Q * geom.L * 2, N, Q, M, D, npts, dV,
+               g("cross_attn.sampling_offsets.weight"), g("cross_attn.sampling_offsets.bias"),
+               g("cross_attn.attention_weights.weight"), g("cross_attn.attention_weights.bias"), dt1, True)
+    dtgt, datt = proj_ln_bwd(dt1, sv["att"], P_["self_attn.out_proj.weight"], P_["norm2.weight"], sv["ln2"], pd, seeds[1],
+                             g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), g("norm2.weight"), g("norm2.bias"))
+    packed = sv["packed"]
+    dpk = torch.empty_like(packed)
+    ops.mha_bwd(packed, packed[:, d:], packed[:, 2 * d:], 3 * d, datt, d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, D,
+                pd, seeds[0])
+    Win = P_["self_attn.in_proj_weight"]
+    gWin, gbin = g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias")
+    ops.linear_dw(dpk, sv["qk"], gWin[: 2 * d], rows=rows, ldy=3 * d)
+    ops.linear_dw(dpk[:, 2 * d:], sv["tgt"], gWin[2 * d:], rows=rows, ldy=3 * d)
+    ops.colsum(dpk, 3 * d, gbin, 1, rows, 3 * d)
+    ops.linear_dx(dpk, Win[: 2 * d], dtgt, rows=rows, ldy=3 * d, add_src=dtgt)
+    ops.linear_dx(dpk[:, 2 * d:], Win[2 * d:], dtgt, rows=rows, ldy=3 * d, add_src=dtgt)
+    return dtgt
+
+
+# ---- pose heads -------------------------------------------------------------------------------------
+def mlp3_fwd(h, Ws, bs):
+    a = empty((h.shape[0], Ws[0].shape[0]), torch.float32, h)
+    ops.linear_fwd(h, Ws[0], bs[0], a, act=1)
+    b = empty((h.shape[0], Ws[1].shape[0]), torch.float32, h)
+    ops.linear_fwd(a, Ws[1], bs[1], b, act=1)
+    c = empty((h.shape[0], Ws[2].shape[0]), torch.float32, h)
+    ops.linear_fwd(b, Ws[2], bs[2], c)
+    return c, (a, b)
+
+
+def mlp3_bwd(dc, h, Ws, saved, gWs, gbs, dh, accumulate):
+    a, b = saved
+    rows = h.shape[0]
+    ops.linear_dw(dc, b, gWs[2], rows=rows)
+    ops.colsum(dc, dc.shape[1], gbs[2], 1, rows, dc.shape[1])
+    db_ = torch.empty_like(b)
+    ops.linear_dx(dc, Ws[2], db_, rows=rows, gate_ref=b)
+    ops.linear_dw(db_, a, gWs[1], rows=rows)
+    ops.colsum(db_, db_.shape[1], gbs[1], 1, rows, db_.shape[1])
+    da = torch.empty_like(a)
+    ops.linear_dx(db_, Ws[1], da, rows=rows, gate_ref=a)
+    ops.linear_dw(da, h, gWs[0], rows=rows)
+    ops.colsum(da, da.shape[1], gbs[0], 1, rows, da.shape[1])
+    ops.linear_dx(da, Ws[0], dh, rows=rows, add_src=dh if accumulate else None)

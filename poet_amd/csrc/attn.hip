@@ -1,0 +1,213 @@
+// Small-Q multi-head self-attention core (decoder self-attention over <= 64 object queries;
+// reference: nn.MultiheadAttention at models/deformable_transformer.py:253,277-278, called with
+// q = k = tgt + query_pos, v = tgt, NO key-padding mask: dummy queries attend and are attended).
+// One wave per (image, head): Q x Q scores live in LDS, one lane per query row, fp32 throughout.
+// The in/out projections are poet_gemm calls; this kernel is only softmax(q k^T / sqrt(hd)) v with
+// dropout on the probabilities (same counter RNG in forward and backward, nothing stored).
+#include "common.cuh"
+
+namespace poet {
+
+struct MhaP {
+    const float *q, *k, *v, *dout;
+    float *out, *dq, *dk, *dv;
+    int64_t ld, ld_out, ld_d;
+    int N, Q, M;
+    float scale;
+    uint32_t thresh, seed;
+    float dscale;
+};
+
+template <int HD>
+__global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Q = p.Q, PH = HD + 1;
+    float* sk = smem;                 // [Q][HD+1]
+    float* sv = sk + Q * PH;          // [Q][HD+1]
+    float* sp = sv + Q * PH;          // [Q][Q+1]
+    const int n = blockIdx.x / p.M, m = blockIdx.x % p.M;
+    const int lane = threadIdx.x;
+    const int64_t rbase = (int64_t)n * Q;
+    for (int i = lane; i < Q * HD; i += 64) {
+        const int r = i / HD, c = i % HD;
+        sk[r * PH + c] = p.k[(rbase + r) * p.ld + m * HD + c];
+        sv[r * PH + c] = p.v[(rbase + r) * p.ld + m * HD + c];
+    }
+    __syncthreads();
+    if (lane >= Q) return;
+    float qr[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) qr[c] = p.q[(rbase + lane) * p.ld + m * HD + c] * p.scale;
+    float mx = -3.0e38f;
+    for (int j = 0; j < Q; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) s += qr[c] * sk[j * PH + c];
+        sp[lane * (Q + 1) + j] = s;
+        mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < Q; ++j) {
+        const float e = __expf(sp[lane * (Q + 1) + j] - mx);
+        sp[lane * (Q + 1) + j] = e;
+        sum += e;
+    }
+    const float inv = 1.f / sum;
+    float acc[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+    const uint32_t ibase = ((uint32_t)blockIdx.x * Q + lane) * Q;
+    for (int j = 0; j < Q; ++j) {
+        float pj = sp[lane * (Q + 1) + j] * inv;
+        if (p.thresh) pj = drop_keep(p.seed, ibase + j, p.thresh) ? pj * p.dscale : 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) acc[c] += pj * sv[j * PH + c];
+    }
+#pragma unroll
+    for (int c = 0; c < HD; ++c) p.out[(rbase + lane) * p.ld_out + m * HD + c] = acc[c];
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Q = p.Q, PH = HD + 1, PQ = Q + 1;
+    float* sq = smem;                 // scaled q
+    float* sk = sq + Q * PH;
+    float* sv = sk + Q * PH;
+    float* sdo = sv + Q * PH;
+    float* spd = sdo + Q * PH;        // dropped probabilities  [Q][Q+1]
+    float* sds = spd + Q * PQ;        // dS                      [Q][Q+1]
+    const int n = blockIdx.x / p.M, m = blockIdx.x % p.M;
+    const int lane = threadIdx.x;
+    const int64_t rbase = (int64_t)n * Q;
+    for (int i = lane; i < Q * HD; i += 64) {
+        const int r = i / HD, c = i % HD;
+        sq[r * PH + c] = p.q[(rbase + r) * p.ld + m * HD + c] * p.scale;
+        sk[r * PH + c] = p.k[(rbase + r) * p.ld + m * HD + c];
+        sv[r * PH + c] = p.v[(rbase + r) * p.ld + m * HD + c];
+        sdo[r * PH + c] = p.dout[(rbase + r) * p.ld_out + m * HD + c];
+    }
+    __syncthreads();
+    if (lane < Q) {
+        float qr[HD], dor[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { qr[c] = sq[lane * PH + c]; dor[c] = sdo[lane * PH + c]; }
+        float mx = -3.0e38f;
+        for (int j = 0; j < Q; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) s += qr[c] * sk[j * PH + c];
+            spd[lane * PQ + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < Q; ++j) {
+            const float e = __expf(spd[lane * PQ + j] - mx);
+            spd[lane * PQ + j] = e;
+            sum += e;
+        }
+        const float inv = 1.f / sum;
+        const uint32_t ibase = ((uint32_t)blockIdx.x * Q + lane) * Q;
+        float dot = 0.f;
+        for (int j = 0; j < Q; ++j) {
+            const float pj = spd[lane * PQ + j] * inv;
+            float keep = 1.f;
+            if (p.thresh) keep = drop_keep(p.seed, ibase + j, p.thresh) ? p.dscale : 0.f;
+            float dpd = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) dpd += dor[c] * sv[j * PH + c];
+            const float dp = dpd * keep;
+            spd[lane * PQ + j] = pj * keep;
+            sds[lane * PQ + j] = dp;            // temporarily dP
+            dot += pj * dp;
+        }
+        float dqr[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) dqr[c] = 0.f;
+        for (int j = 0; j < Q; ++j) {
+            // recover p_j from the dropped value is not possible when keep == 0, so recompute it
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) s += qr[c] * sk[j * PH + c];
+            const float pj = __expf(s - mx) * inv;
+            const float ds = pj * (sds[lane * PQ + j] - dot);
+            sds[lane * PQ + j] = ds;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) dqr[c] += ds * sk[j * PH + c];
+        }
+#pragma unroll
+        for (int c = 0; c < HD; ++c) p.dq[(rbase + lane) * p.ld_d + m * HD + c] = dqr[c] * p.scale;
+    }
+    __syncthreads();
+    if (lane < Q) {
+        float dkr[HD], dvr[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { dkr[c] = 0.f; dvr[c] = 0.f; }
+        for (int i = 0; i < Q; ++i) {
+            const float ds = sds[i * PQ + lane], pd = spd[i * PQ + lane];
+#pragma unroll
+            for (int c = 0; c < HD; ++c) {
+                dkr[c] += ds * sq[i * PH + c];      // sq already carries the 1/sqrt(hd) scale
+                dvr[c] += pd * sdo[i * PH + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            p.dk[(rbase + lane) * p.ld_d + m * HD + c] = dkr[c];
+            p.dv[(rbase + lane) * p.ld_d + m * HD + c] = dvr[c];
+        }
+    }
+}
+
+static int mha_common(MhaP& p, int N, int Q, int M, int hd, float drop_p, uint32_t seed) {
+    POET_CHECK(N > 0 && M > 0 && Q > 0 && Q <= 64, POET_ERR_UNSUPPORTED, "mha: Q=%d must be in 1..64", Q);
+    POET_CHECK(hd == 16 || hd == 32 || hd == 64, POET_ERR_UNSUPPORTED, "mha: head dim %d not in {16,32,64}", hd);
+    POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "mha: drop_p");
+    p.N = N; p.Q = Q; p.M = M;
+    p.scale = 1.f / sqrtf((float)hd);
+    p.thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+    p.dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    p.seed = seed;
+    return POET_OK;
+}
+
+}  // namespace poet
+
+using namespace poet;
+
+extern "C" int poet_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, float* out, int64_t ld_out,
+                            int N, int Q, int M, int hd, float drop_p, uint32_t seed, void* stream) {
+    MhaP p{};
+    int rc = mha_common(p, N, Q, M, hd, drop_p, seed);
+    if (rc) return rc;
+    POET_CHECK(q && k && v && out, POET_ERR_ARG, "mha_fwd: null pointer");
+    p.q = q; p.k = k; p.v = v; p.out = out; p.ld = ld; p.ld_out = ld_out;
+    const size_t lds = sizeof(float) * (2 * Q * (hd + 1) + Q * (Q + 1));
+    POET_CHECK(lds <= 64 * 1024, POET_ERR_UNSUPPORTED, "mha_fwd: LDS %zu > 64 KiB", lds);
+    dim3 grid(N * M), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 16) hipLaunchKernelGGL(mha_fwd_kernel<16>, grid, block, lds, st, p);
+    else if (hd == 32) hipLaunchKernelGGL(mha_fwd_kernel<32>, grid, block, lds, st, p);
+    else hipLaunchKernelGGL(mha_fwd_kernel<64>, grid, block, lds, st, p);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dout, int64_t ld_out,
+                            float* dq, float* dk, float* dv, int64_t ld_d, int N, int Q, int M, int hd, float drop_p,
+                            uint32_t seed, void* stream) {
+    MhaP p{};
+    int rc = mha_common(p, N, Q, M, hd, drop_p, seed);
+    if (rc) return rc;
+    POET_CHECK(q && k && v && dout && dq && dk && dv, POET_ERR_ARG, "mha_bwd: null pointer");
+    p.q = q; p.k = k; p.v = v; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv; p.ld = ld; p.ld_out = ld_out; p.ld_d = ld_d;
+    const size_t lds = sizeof(float) * (4 * Q * (hd + 1) + 2 * Q * (Q + 1));
+    POET_CHECK(lds <= 64 * 1024, POET_ERR_UNSUPPORTED, "mha_bwd: LDS %zu > 64 KiB", lds);
+    dim3 grid(N * M), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 16) hipLaunchKernelGGL(mha_bwd_kernel<16>, grid, block, lds, st, p);
+    else if (hd == 32) hipLaunchKernelGGL(mha_bwd_kernel<32>, grid, block, lds, st, p);
+    else hipLaunchKernelGGL(mha_bwd_kernel<64>, grid, block, lds, st, p);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}

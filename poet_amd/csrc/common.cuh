@@ -1,0 +1,125 @@
+// Shared device helpers for the PoET gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/poet_hip.h"
+
+namespace poet {
+
+typedef uint16_t bf16_t;                                   // raw bfloat16 bits
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (host) ---------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define POET_CHECK(cond, code, ...)      \
+    do {                                 \
+        if (!(cond)) {                   \
+            poet::set_error(__VA_ARGS__); \
+            return (code);               \
+        }                                \
+    } while (0)
+#define POET_LAUNCH_CHECK()                                                              \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess) {                                                         \
+            poet::set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return POET_ERR_LAUNCH;                                                      \
+        }                                                                                \
+    } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, same as torch) ---------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;           // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct io;
+template <> struct io<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct io<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// load/store N (4 or 8) consecutive elements as floats; p must be aligned to N*sizeof(T)
+template <typename T, int N> struct vec;
+template <> struct vec<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float* o) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <> struct vec<float, 8> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) {
+        vec<float, 4>::ld(p, o);
+        vec<float, 4>::ld(p + 4, o + 4);
+    }
+    static __device__ __forceinline__ void st(float* p, const float* o) {
+        vec<float, 4>::st(p, o);
+        vec<float, 4>::st(p + 4, o + 4);
+    }
+};
+template <> struct vec<bf16_t, 4> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+    }
+};
+template <> struct vec<bf16_t, 8> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]),
+                                                  pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+    }
+};
+
+// ---- counter-based dropout RNG -------------------------------------------------------------------
+// keep(seed, idx): lowbias32 hash of (idx ^ seed-mix) -> 24-bit uniform; regenerated in backward
+// from the same (seed, idx), so no mask is ever stored.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thresh24) {
+    return (hash32(idx ^ (seed * 0x9E3779B9u)) >> 8) >= thresh24;
+}
+__host__ __device__ __forceinline__ uint32_t drop_thresh(float p) { return (uint32_t)(p * 16777216.0f); }
+
+// ---- wave-level reductions (64 lanes) ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace poet

@@ -1,0 +1,561 @@
+// Elementwise / layout / encoding / optimizer kernels of the PoET hot path (gfx950).
+// All HBM-bound byte movers: vectorised 16-B lane accesses, grid-stride where the size warrants it.
+#include "common.cuh"
+
+namespace poet {
+
+// ---- add / cast ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        float x[8], y[8];
+        vec<T, 8>::ld(a + i, x);
+        vec<T, 8>::ld(b + i, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        vec<T, 8>::st(o + i, x);
+    } else {
+        for (int64_t j = i; j < n; ++j) io<T>::st(o + j, io<T>::ld(a + j) + io<T>::ld(b + j));
+    }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        float x[8];
+        vec<S, 8>::ld(s + i, x);
+        vec<D, 8>::st(d + i, x);
+    } else {
+        for (int64_t j = i; j < n; ++j) io<D>::st(d + j, io<S>::ld(s + j));
+    }
+}
+
+// ---- segmented column sums (bias gradients; per-level sums for level_embed) -----------------------
+constexpr int CS_MAXSEG = 8;
+struct ColsumP {
+    const void* x;
+    int64_t ld;
+    float* out;
+    int64_t rows_per_batch;
+    int cols;
+    int64_t seg[CS_MAXSEG + 1];
+    int nseg;
+    int rows_per_block;
+    int aligned;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const ColsumP p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * p.rows_per_block;
+    const int64_t r1 = min(p.rows_per_batch, r0 + p.rows_per_block);
+    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)blockIdx.z * p.rows_per_batch * p.ld;
+    if (c0 >= p.cols) return;
+    const bool full = (c0 + 4 <= p.cols) && p.aligned;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int seg = 0;
+    auto flush = [&](int s) {
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < p.cols && acc[e] != 0.f) atomicAdd(p.out + (int64_t)s * p.cols + c0 + e, acc[e]);
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+    };
+    for (int64_t r = r0 + wid; r < r1; r += 4) {
+        int s = seg;
+        while (s + 1 < p.nseg && r >= p.seg[s + 1]) ++s;
+        if (s != seg) { flush(seg); seg = s; }
+        if (full) {
+            float v[4];
+            vec<T, 4>::ld(xb + r * p.ld + c0, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < p.cols) acc[e] += io<T>::ld(xb + r * p.ld + c0 + e);
+        }
+    }
+    flush(seg);
+}
+
+// ---- fp32 value-gradient maps -> row-major activations -------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vgrad_rows_kernel(const float* __restrict__ gv, int64_t vs_n, int64_t vs_s, int64_t vs_m,
+                                                         const uint8_t* __restrict__ mask, T* __restrict__ out,
+                                                         int S, int M, int D, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int groups = M * D / 8;
+    const int64_t row = t / groups;
+    const int c8 = (int)(t - row * groups);
+    const int ch = c8 * 8, m = ch / D, d = ch - m * D;
+    const int n = (int)(row / S), s = (int)(row - (int64_t)n * S);
+    float v[8];
+    vec<float, 8>::ld(gv + (int64_t)n * vs_n + (int64_t)s * vs_s + (int64_t)m * vs_m + d, v);
+    if (mask && mask[row]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    vec<T, 8>::st(out + row * ((int64_t)M * D) + ch, v);
+}
+
+// ---- NCHW <-> token-major (LDS tile transpose) ---------------------------------------------------
+template <typename S, typename D, bool TO_TOKENS>
+__global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ src, D* __restrict__ dst, int C, int HW,
+                                                        int64_t tok_off, int64_t tok_stride) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    if (TO_TOKENS) {
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, hw = hw0 + tx;
+            tile[i][tx] = (c < C && hw < HW) ? io<S>::ld(src + ((int64_t)n * C + c) * HW + hw) : 0.f;
+        }
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            const int hw = hw0 + i, c = c0 + tx;
+            if (c < C && hw < HW) io<D>::st(dst + ((int64_t)n * tok_stride + tok_off + hw) * C + c, tile[tx][i]);
+        }
+    } else {
+        for (int i = ty; i < 32; i += 8) {
+            const int hw = hw0 + i, c = c0 + tx;
+            tile[i][tx] = (c < C && hw < HW) ? io<S>::ld(src + ((int64_t)n * tok_stride + tok_off + hw) * C + c) : 0.f;
+        }
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, hw = hw0 + tx;
+            if (c < C && hw < HW) io<D>::st(dst + ((int64_t)n * C + c) * HW + hw, tile[tx][i]);
+        }
+    }
+}
+
+// ---- im2col for the 3x3 stride-2 pad-1 extra-level conv -----------------------------------------
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void im2col_kernel(const S* __restrict__ src, D* __restrict__ dst, int C, int H, int W,
+                                                     int Ho, int Wo, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int K = C * 9;
+    const int64_t row = t / K;
+    const int k = (int)(t - row * K);
+    const int c = k / 9, r9 = k - c * 9, ky = r9 / 3, kx = r9 - ky * 3;
+    const int n = (int)(row / (Ho * Wo)), o = (int)(row - (int64_t)n * Ho * Wo);
+    const int oy = o / Wo, ox = o - oy * Wo;
+    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = io<S>::ld(src + (((int64_t)n * C + c) * H + iy) * W + ix);
+    io<D>::st(dst + t, v);
+}
+
+// ---- position encodings --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pos_sine_kernel(const uint8_t* __restrict__ mask, T* __restrict__ out,
+                                                       const float* __restrict__ level_embed,
+                                                       const float* __restrict__ dim_t, int H, int W, int F,
+                                                       int64_t tok_off, int64_t tok_stride) {
+    extern __shared__ float sm[];          // ey[W], ex[W]
+    float* ey = sm;
+    float* ex = sm + W;
+    const int n = blockIdx.x / H, y = blockIdx.x % H;
+    const uint8_t* mb = mask + (int64_t)n * H * W;
+    const float two_pi = 6.283185307179586f;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int cy = 0, ty = 0, cx = 0, tx = 0;
+        for (int r = 0; r < H; ++r) { const int u = mb[r * W + x] ? 0 : 1; ty += u; if (r <= y) cy += u; }
+        for (int c = 0; c < W; ++c) { const int u = mb[y * W + c] ? 0 : 1; tx += u; if (c <= x) cx += u; }
+        ey[x] = ((float)cy - 0.5f) / ((float)ty + 1e-6f) * two_pi;
+        ex[x] = ((float)cx - 0.5f) / ((float)tx + 1e-6f) * two_pi;
+    }
+    __syncthreads();
+    const int C2 = 2 * F;
+    for (int i = threadIdx.x; i < W * C2; i += 256) {
+        const int x = i / C2, c = i - x * C2;
+        const int cc = (c < F) ? c : c - F;
+        const float e = (c < F) ? ey[x] : ex[x];
+        const float arg = e / dim_t[cc];
+        float v = (cc & 1) ? cosf(arg) : sinf(arg);
+        if (level_embed) v += level_embed[c];
+        io<T>::st(out + ((int64_t)n * tok_stride + tok_off + (int64_t)y * W + x) * C2 + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void bbox_sine_kernel(const float* __restrict__ boxes, const uint8_t* __restrict__ valid,
+                                                        float* __restrict__ out, int n, int F, float fill) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * 4 * F) return;
+    const int b = t / (4 * F), r = t - b * 4 * F, c = r / F, k = r - c * F;
+    if (valid && !valid[b]) {
+        out[(int64_t)b * 8 * F + c * 2 * F + k] = fill;
+        out[(int64_t)b * 8 * F + c * 2 * F + F + k] = fill;
+        return;
+    }
+    const float arg = boxes[b * 4 + c] * exp2f((float)k);          // exact power-of-two scaling
+    out[(int64_t)b * 8 * F + c * 2 * F + k] = sinf(arg);            // full-range reduction: args reach 2^31
+    out[(int64_t)b * 8 * F + c * 2 * F + F + k] = cosf(arg);
+}
+
+__global__ __launch_bounds__(256) void dec_ref_kernel(const float* __restrict__ ref, const float* __restrict__ vr,
+                                                      float* __restrict__ out, int N, int Q, int L) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * Q * L) return;
+    const int l = t % L, nq = t / L, n = nq / Q;
+    out[t * 2 + 0] = ref[nq * 2 + 0] * vr[(n * L + l) * 2 + 0];
+    out[t * 2 + 1] = ref[nq * 2 + 1] * vr[(n * L + l) * 2 + 1];
+}
+
+__global__ __launch_bounds__(64) void valid_ratio_kernel(const uint8_t* __restrict__ mask, float* __restrict__ out,
+                                                         int64_t out_stride, int H, int W) {
+    const int n = blockIdx.x;
+    const uint8_t* mb = mask + (int64_t)n * H * W;
+    float vh = 0.f, vw = 0.f;
+    for (int y = threadIdx.x; y < H; y += 64) vh += mb[y * W] ? 0.f : 1.f;      // ~mask[:, :, 0]
+    for (int x = threadIdx.x; x < W; x += 64) vw += mb[x] ? 0.f : 1.f;          // ~mask[:, 0, :]
+    vh = wave_sum(vh);
+    vw = wave_sum(vw);
+    if (threadIdx.x == 0) { out[n * out_stride + 0] = vw / (float)W; out[n * out_stride + 1] = vh / (float)H; }
+}
+
+__global__ __launch_bounds__(256) void mask_nearest_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                           int N, int H, int W, int Ho, int Wo) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * Ho * Wo) return;
+    const int n = t / (Ho * Wo), o = t - n * Ho * Wo, oy = o / Wo, ox = o - oy * Wo;
+    // torch 'nearest': src = floor(dst * scale) with scale = in/out computed in fp32
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    const int iy = min((int)floorf((float)oy * sy), H - 1), ix = min((int)floorf((float)ox * sx), W - 1);
+    dst[t] = src[((int64_t)n * H + iy) * W + ix];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_rowvec_kernel(T* __restrict__ x, const float* __restrict__ vec, int64_t batch_stride_rows,
+                                                         int64_t row0, int64_t rows, int cols) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * cols) return;
+    const int64_t r = t / cols;
+    const int c = (int)(t - r * cols);
+    T* p = x + ((int64_t)blockIdx.y * batch_stride_rows + row0 + r) * cols + c;
+    io<T>::st(p, io<T>::ld(p) + vec[c]);
+}
+
+struct RefP {
+    const float* vr;
+    float* ref;
+    int N, L, S;
+    int H[4], W[4], start[4];
+};
+__global__ __launch_bounds__(256) void enc_ref_kernel(const RefP p) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)p.N * p.S) return;
+    const int n = (int)(t / p.S), s = (int)(t - (int64_t)n * p.S);
+    int lq = 0;
+    while (lq + 1 < p.L && s >= p.start[lq + 1]) ++lq;
+    const int o = s - p.start[lq];
+    const int y = o / p.W[lq], x = o - y * p.W[lq];
+    const float* vr = p.vr + (int64_t)n * p.L * 2;
+    const float rx = ((float)x + 0.5f) / (vr[lq * 2 + 0] * (float)p.W[lq]);
+    const float ry = ((float)y + 0.5f) / (vr[lq * 2 + 1] * (float)p.H[lq]);
+    for (int l = 0; l < p.L; ++l) {
+        p.ref[(t * p.L + l) * 2 + 0] = rx * vr[l * 2 + 0];
+        p.ref[(t * p.L + l) * 2 + 1] = ry * vr[l * 2 + 1];
+    }
+}
+
+// ---- pose heads tail: class-slot gather + 6D -> rotation matrix -----------------------------------
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ __launch_bounds__(256) void pose_fwd_kernel(const float* __restrict__ rot_all, const float* __restrict__ trans_all,
+                                                       const int32_t* __restrict__ cls, float* __restrict__ rot,
+                                                       float* __restrict__ trans, int R, int ncls) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int c = cls[r] > 0 ? cls[r] : 0;
+    const float* p6 = rot_all + (int64_t)r * ncls * 6 + c * 6;
+    const float m1[3] = {p6[0], p6[1], p6[2]}, m2[3] = {p6[3], p6[4], p6[5]};
+    const float nx = fmaxf(sqrtf(m1[0] * m1[0] + m1[1] * m1[1] + m1[2] * m1[2]), 1e-12f);
+    const float x[3] = {m1[0] / nx, m1[1] / nx, m1[2] / nx};
+    float zp[3];
+    cross3(x, m2, zp);
+    const float nz = fmaxf(sqrtf(zp[0] * zp[0] + zp[1] * zp[1] + zp[2] * zp[2]), 1e-12f);
+    const float z[3] = {zp[0] / nz, zp[1] / nz, zp[2] / nz};
+    float y[3];
+    cross3(z, x, y);
+    float* o = rot + (int64_t)r * 9;
+    for (int i = 0; i < 3; ++i) { o[i * 3 + 0] = x[i]; o[i * 3 + 1] = y[i]; o[i * 3 + 2] = z[i]; }
+    for (int i = 0; i < 3; ++i) trans[(int64_t)r * 3 + i] = trans_all[(int64_t)r * ncls * 3 + c * 3 + i];
+}
+
+__global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__ rot_all, const int32_t* __restrict__ cls,
+                                                       const float* __restrict__ drot, const float* __restrict__ dtrans,
+                                                       float* __restrict__ drot_all, float* __restrict__ dtrans_all,
+                                                       int R, int ncls) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int c = cls[r] > 0 ? cls[r] : 0;
+    const float* p6 = rot_all + (int64_t)r * ncls * 6 + c * 6;
+    const float m1[3] = {p6[0], p6[1], p6[2]}, m2[3] = {p6[3], p6[4], p6[5]};
+    const float n1 = sqrtf(m1[0] * m1[0] + m1[1] * m1[1] + m1[2] * m1[2]);
+    const float nx = fmaxf(n1, 1e-12f);
+    const float x[3] = {m1[0] / nx, m1[1] / nx, m1[2] / nx};
+    float zp[3];
+    cross3(x, m2, zp);
+    const float n2 = sqrtf(zp[0] * zp[0] + zp[1] * zp[1] + zp[2] * zp[2]);
+    const float nz = fmaxf(n2, 1e-12f);
+    const float z[3] = {zp[0] / nz, zp[1] / nz, zp[2] / nz};
+    const float* g = drot + (int64_t)r * 9;
+    float dx[3] = {g[0], g[3], g[6]}, dy[3] = {g[1], g[4], g[7]}, dz[3] = {g[2], g[5], g[8]};
+    float t[3];
+    cross3(x, dy, t);                       // y = z x x :  dz += x x dy ; dx += dy x z
+    for (int i = 0; i < 3; ++i) dz[i] += t[i];
+    cross3(dy, z, t);
+    for (int i = 0; i < 3; ++i) dx[i] += t[i];
+    float dzp[3];
+    if (n2 > 1e-12f) {
+        const float dot = z[0] * dz[0] + z[1] * dz[1] + z[2] * dz[2];
+        for (int i = 0; i < 3; ++i) dzp[i] = (dz[i] - z[i] * dot) / nz;
+    } else {
+        for (int i = 0; i < 3; ++i) dzp[i] = dz[i] / nz;
+    }
+    cross3(m2, dzp, t);                     // z' = x x m2 : dx += m2 x dz' ; dm2 = dz' x x
+    for (int i = 0; i < 3; ++i) dx[i] += t[i];
+    float dm2[3], dm1[3];
+    cross3(dzp, x, dm2);
+    if (n1 > 1e-12f) {
+        const float dot = x[0] * dx[0] + x[1] * dx[1] + x[2] * dx[2];
+        for (int i = 0; i < 3; ++i) dm1[i] = (dx[i] - x[i] * dot) / nx;
+    } else {
+        for (int i = 0; i < 3; ++i) dm1[i] = dx[i] / nx;
+    }
+    float* ro = drot_all + (int64_t)r * ncls * 6;
+    float* to = dtrans_all + (int64_t)r * ncls * 3;
+    for (int i = 0; i < ncls * 6; ++i) ro[i] = 0.f;
+    for (int i = 0; i < ncls * 3; ++i) to[i] = 0.f;
+    for (int i = 0; i < 3; ++i) { ro[c * 6 + i] = dm1[i]; ro[c * 6 + 3 + i] = dm2[i]; to[c * 3 + i] = dtrans[(int64_t)r * 3 + i]; }
+}
+
+// ---- flat-arena optimizer ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4*>(g + i);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        } else {
+            for (int64_t j = i; j < n; ++j) s += g[j] * g[j];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, uint16_t* __restrict__ pb, int64_t n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                                    const float* __restrict__ sqnorm, float max_norm, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float clip = gscale;
+    if (sqnorm) {
+        const float total = sqrtf(*sqnorm) * gscale;
+        const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
+        clip *= coef;
+    }
+    const float gi = g[i] * clip;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (pb) pb[i] = f2bf(pi);
+}
+
+}  // namespace poet
+
+using namespace poet;
+#define ST ((hipStream_t)stream)
+
+extern "C" int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    POET_CHECK(a && b && out && n > 0, POET_ERR_ARG, "add: bad args");
+    dim3 grid(cdiv(n, 2048)), block(256);
+    if (dtype == POET_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, grid, block, 0, ST, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else hipLaunchKernelGGL(add_kernel<float>, grid, block, 0, ST, (const float*)a, (const float*)b, (float*)out, n);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_cast(const void* src, void* dst, int64_t n, int sd, int dd, void* stream) {
+    POET_CHECK(src && dst && n > 0, POET_ERR_ARG, "cast: bad args");
+    dim3 grid(cdiv(n, 2048)), block(256);
+    if (sd == POET_F32 && dd == POET_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, ST, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == POET_BF16 && dd == POET_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, ST, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == POET_F32 && dd == POET_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, ST, (const float*)src, (float*)dst, n);
+    else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)src, (bf16_t*)dst, n);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_colsum(const void* x, int64_t ld, float* out, int batch, int64_t rows_per_batch, int cols,
+                           const int64_t* seg_start_host, int nseg, int dtype, void* stream) {
+    POET_CHECK(x && out && batch > 0 && rows_per_batch > 0 && cols > 0, POET_ERR_ARG, "colsum: bad args");
+    POET_CHECK(nseg >= 1 && nseg <= CS_MAXSEG, POET_ERR_UNSUPPORTED, "colsum: nseg %d not in 1..%d", nseg, CS_MAXSEG);
+    ColsumP p{};
+    p.x = x; p.ld = ld; p.out = out; p.rows_per_batch = rows_per_batch; p.cols = cols; p.nseg = nseg;
+    if (seg_start_host) for (int i = 0; i <= nseg; ++i) p.seg[i] = seg_start_host[i];
+    else { p.seg[0] = 0; p.seg[1] = rows_per_batch; }
+    p.rows_per_block = 512;
+    p.aligned = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    dim3 grid(cdiv(cols, 256), cdiv(rows_per_batch, p.rows_per_block), batch), block(256);
+    if (dtype == POET_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, ST, p);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, ST, p);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_vgrad_to_rows(const float* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
+                                  void* out, int N, int S, int M, int D, int dtype, void* stream) {
+    POET_CHECK(gv && out && D % 8 == 0, POET_ERR_ARG, "vgrad_to_rows: bad args");
+    const int64_t total = (int64_t)N * S * M * D / 8;
+    dim3 grid(cdiv(total, 256)), block(256);
+    if (dtype == POET_BF16) hipLaunchKernelGGL(vgrad_rows_kernel<bf16_t>, grid, block, 0, ST, gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, S, M, D, total);
+    else hipLaunchKernelGGL(vgrad_rows_kernel<float>, grid, block, 0, ST, gv, vs_n, vs_s, vs_m, row_mask, (float*)out, S, M, D, total);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+template <bool TO_TOKENS>
+static int transpose_dispatch(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
+                              int sd, int dd, void* stream) {
+    POET_CHECK(src && dst && N > 0 && C > 0 && HW > 0, POET_ERR_ARG, "transpose: bad args");
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), N), block(256);
+    if (sd == POET_F32 && dd == POET_F32) hipLaunchKernelGGL((transpose_kernel<float, float, TO_TOKENS>), grid, block, 0, ST, (const float*)src, (float*)dst, C, HW, tok_off, tok_stride);
+    else if (sd == POET_F32 && dd == POET_BF16) hipLaunchKernelGGL((transpose_kernel<float, bf16_t, TO_TOKENS>), grid, block, 0, ST, (const float*)src, (bf16_t*)dst, C, HW, tok_off, tok_stride);
+    else if (sd == POET_BF16 && dd == POET_F32) hipLaunchKernelGGL((transpose_kernel<bf16_t, float, TO_TOKENS>), grid, block, 0, ST, (const bf16_t*)src, (float*)dst, C, HW, tok_off, tok_stride);
+    else hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t, TO_TOKENS>), grid, block, 0, ST, (const bf16_t*)src, (bf16_t*)dst, C, HW, tok_off, tok_stride);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+extern "C" int poet_nchw_to_tokens(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride, int sd, int dd, void* stream) {
+    return transpose_dispatch<true>(src, dst, N, C, HW, tok_off, tok_stride, sd, dd, stream);
+}
+extern "C" int poet_tokens_to_nchw(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride, int sd, int dd, void* stream) {
+    return transpose_dispatch<false>(src, dst, N, C, HW, tok_off, tok_stride, sd, dd, stream);
+}
+
+extern "C" int poet_im2col3x3s2(const void* src, void* dst, int N, int C, int H, int W, int Ho, int Wo, int sd, int dd, void* stream) {
+    POET_CHECK(src && dst && N > 0 && C > 0, POET_ERR_ARG, "im2col: bad args");
+    POET_CHECK(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, POET_ERR_ARG, "im2col: output size mismatch");
+    const int64_t total = (int64_t)N * Ho * Wo * C * 9;
+    dim3 grid(cdiv(total, 256)), block(256);
+    if (sd == POET_F32 && dd == POET_F32) hipLaunchKernelGGL((im2col_kernel<float, float>), grid, block, 0, ST, (const float*)src, (float*)dst, C, H, W, Ho, Wo, total);
+    else if (sd == POET_F32 && dd == POET_BF16) hipLaunchKernelGGL((im2col_kernel<float, bf16_t>), grid, block, 0, ST, (const float*)src, (bf16_t*)dst, C, H, W, Ho, Wo, total);
+    else if (sd == POET_BF16 && dd == POET_BF16) hipLaunchKernelGGL((im2col_kernel<bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)src, (bf16_t*)dst, C, H, W, Ho, Wo, total);
+    else hipLaunchKernelGGL((im2col_kernel<bf16_t, float>), grid, block, 0, ST, (const bf16_t*)src, (float*)dst, C, H, W, Ho, Wo, total);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_pos_sine(const uint8_t* mask, void* out, const float* level_embed, const float* dim_t, int N, int H, int W,
+                             int F, int64_t tok_off, int64_t tok_stride, int dtype, void* stream) {
+    POET_CHECK(mask && out && dim_t && N > 0 && H > 0 && W > 0 && F > 0, POET_ERR_ARG, "pos_sine: bad args");
+    dim3 grid(N * H), block(256);
+    const size_t lds = sizeof(float) * 2 * W;
+    if (dtype == POET_BF16) hipLaunchKernelGGL(pos_sine_kernel<bf16_t>, grid, block, lds, ST, mask, (bf16_t*)out, level_embed, dim_t, H, W, F, tok_off, tok_stride);
+    else hipLaunchKernelGGL(pos_sine_kernel<float>, grid, block, lds, ST, mask, (float*)out, level_embed, dim_t, H, W, F, tok_off, tok_stride);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_bbox_sine(const float* boxes, const uint8_t* valid, float* out, int n, int F, float fill, void* stream) {
+    POET_CHECK(boxes && out && n > 0 && F > 0 && F <= 64, POET_ERR_ARG, "bbox_sine: bad args");
+    dim3 grid(cdiv((int64_t)n * 4 * F, 256)), block(256);
+    hipLaunchKernelGGL(bbox_sine_kernel, grid, block, 0, ST, boxes, valid, out, n, F, fill);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_dec_ref_points(const float* ref, const float* valid_ratios, float* out, int N, int Q, int L, void* stream) {
+    POET_CHECK(ref && valid_ratios && out && N > 0 && Q > 0 && L > 0, POET_ERR_ARG, "dec_ref_points: bad args");
+    hipLaunchKernelGGL(dec_ref_kernel, dim3(cdiv((int64_t)N * Q * L, 256)), dim3(256), 0, ST, ref, valid_ratios, out, N, Q, L);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_valid_ratio(const uint8_t* mask, float* out, int64_t out_stride, int N, int H, int W, void* stream) {
+    POET_CHECK(mask && out && N > 0 && H > 0 && W > 0, POET_ERR_ARG, "valid_ratio: bad args");
+    hipLaunchKernelGGL(valid_ratio_kernel, dim3(N), dim3(64), 0, ST, mask, out, out_stride, H, W);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_mask_nearest(const uint8_t* src, uint8_t* dst, int N, int H, int W, int Ho, int Wo, void* stream) {
+    POET_CHECK(src && dst && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, POET_ERR_ARG, "mask_nearest: bad args");
+    hipLaunchKernelGGL(mask_nearest_kernel, dim3(cdiv((int64_t)N * Ho * Wo, 256)), dim3(256), 0, ST, src, dst, N, H, W, Ho, Wo);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_add_rowvec(void* x, const float* vec, int batch, int64_t batch_stride_rows, int64_t row0, int64_t rows,
+                               int cols, int dtype, void* stream) {
+    POET_CHECK(x && vec && batch > 0 && rows > 0 && cols > 0, POET_ERR_ARG, "add_rowvec: bad args");
+    dim3 grid(cdiv(rows * cols, 256), batch), block(256);
+    if (dtype == POET_BF16) hipLaunchKernelGGL(add_rowvec_kernel<bf16_t>, grid, block, 0, ST, (bf16_t*)x, vec, batch_stride_rows, row0, rows, cols);
+    else hipLaunchKernelGGL(add_rowvec_kernel<float>, grid, block, 0, ST, (float*)x, vec, batch_stride_rows, row0, rows, cols);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_enc_ref_points(const float* valid_ratios, const int64_t* shapes, float* ref, int N, int L, int S, void* stream) {
+    POET_CHECK(valid_ratios && shapes && ref && L >= 1 && L <= 4, POET_ERR_ARG, "enc_ref_points: bad args");
+    RefP p{};
+    p.vr = valid_ratios; p.ref = ref; p.N = N; p.L = L; p.S = S;
+    int64_t acc = 0;
+    for (int l = 0; l < L; ++l) { p.H[l] = (int)shapes[2 * l]; p.W[l] = (int)shapes[2 * l + 1]; p.start[l] = (int)acc; acc += (int64_t)p.H[l] * p.W[l]; }
+    POET_CHECK(acc == S, POET_ERR_ARG, "enc_ref_points: sum(H*W) != S");
+    dim3 grid(cdiv((int64_t)N * S, 256)), block(256);
+    hipLaunchKernelGGL(enc_ref_kernel, grid, block, 0, ST, p);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_pose_finish_fwd(const float* rot_all, const float* trans_all, const int32_t* cls, float* rot, float* trans, int R, int ncls, void* stream) {
+    POET_CHECK(rot_all && trans_all && cls && rot && trans && R > 0 && ncls > 0, POET_ERR_ARG, "pose_finish_fwd: bad args");
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, ST, rot_all, trans_all, cls, rot, trans, R, ncls);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+extern "C" int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* drot, const float* dtrans, float* drot_all, float* dtrans_all, int R, int ncls, void* stream) {
+    POET_CHECK(rot_all && cls && drot && dtrans && drot_all && dtrans_all && R > 0 && ncls > 0, POET_ERR_ARG, "pose_finish_bwd: bad args");
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, ST, rot_all, cls, drot, dtrans, drot_all, dtrans_all, R, ncls);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_sqnorm(const float* g, int64_t n, float* out, void* stream) {
+    POET_CHECK(g && out && n > 0, POET_ERR_ARG, "sqnorm: bad args");
+    int nb = cdiv(n, 1024);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(nb), dim3(256), 0, ST, g, n, out);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int step, const float* sqnorm, float max_norm,
+                          float grad_scale, void* stream) {
+    POET_CHECK(p && g && m && v && n > 0 && step >= 1, POET_ERR_ARG, "adamw: bad args");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, sqnorm, max_norm, grad_scale);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}

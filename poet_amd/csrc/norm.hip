@@ -1,0 +1,304 @@
+// LayerNorm (+residual +dropout) and token-major GroupNorm for gfx950, forward and backward.
+// Reference call sites: deformable_transformer.py:202-203,195-196 (encoder), :279-287,271-272
+// (decoder) for `x = norm(x + dropout(y))`; pose_estimation_transformer.py:106-122 for
+// Conv+GroupNorm(32).  HBM-bound: one wave per row, 16-B (f32) / 8-B (bf16) lane accesses,
+// statistics in fp32 registers, wave-level shuffles for the reductions.
+#include "common.cuh"
+
+namespace poet {
+
+constexpr int LN_MAXIT = 4;   // d <= 1024
+
+template <typename TX, typename TR>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const TR* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     TR* __restrict__ y, TX* __restrict__ z, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int64_t rows, int d, float eps,
+                                                     uint32_t thresh, float dscale, uint32_t seed) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    float v[LN_MAXIT][4];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+        const int c = (lane + 64 * it) * 4;
+        if (c < d) {
+            float a[4];
+            vec<TX, 4>::ld(x + row * d + c, a);
+            if (thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    a[e] = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c + e), thresh) ? a[e] * dscale : 0.f;
+            }
+            if (res) {
+                float r[4];
+                vec<TR, 4>::ld(res + row * d + c, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += r[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[it][e] = a[e]; s += a[e]; }
+        }
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+        const int c = (lane + 64 * it) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = v[it][e] - mu; q += t * t; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+        const int c = (lane + 64 * it) * 4;
+        if (c < d) {
+            float g[4], b[4], o[4];
+            vec<float, 4>::ld(gamma + c, g);
+            vec<float, 4>::ld(beta + c, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * g[e] + b[e];
+            vec<TR, 4>::st(y + row * d + c, o);
+            if (z) vec<TX, 4>::st(z + row * d + c, v[it]);
+        }
+    }
+}
+
+template <typename TX, typename TR>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, const TX* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, TR* __restrict__ dz,
+                                                     TX* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int64_t rows, int d,
+                                                     uint32_t thresh, float dscale, uint32_t seed) {
+    __shared__ float red[2][4][LN_MAXIT * 256];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float ag[LN_MAXIT][4], ab[LN_MAXIT][4], gm[LN_MAXIT][4];
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+        const int c = (lane + 64 * it) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ag[it][e] = 0.f; ab[it][e] = 0.f; gm[it][e] = 0.f; }
+        if (c < d) vec<float, 4>::ld(gamma + c, gm[it]);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAXIT][4], xh[LN_MAXIT][4];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < d) {
+                float a[4], zz[4];
+                vec<TR, 4>::ld(dy + row * d + c, a);
+                vec<TX, 4>::ld(z + row * d + c, zz);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[it][e] = (zz[e] - mu) * rs;
+                    ag[it][e] += a[e] * xh[it][e];
+                    ab[it][e] += a[e];
+                    g[it][e] = a[e] * gm[it][e];
+                    c1 += g[it][e];
+                    c2 += g[it][e] * xh[it][e];
+                }
+            }
+        }
+        c1 = wave_sum(c1) / (float)d;
+        c2 = wave_sum(c2) / (float)d;
+#pragma unroll
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < d) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
+                vec<TR, 4>::st(dz + row * d + c, o);
+                if (dx && ((const void*)dx != (const void*)dz || thresh)) {
+                    if (thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c + e), thresh) ? o[e] * dscale : 0.f;
+                    }
+                    vec<TX, 4>::st(dx + row * d + c, o);
+                }
+            }
+        }
+    }
+    // block reduction of the parameter gradients, then one atomic per column per block
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wid][(lane + 64 * it) * 4 + e] = ag[it][e];
+            red[1][wid][(lane + 64 * it) * 4 + e] = ab[it][e];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        atomicAdd(dgamma + c, sg);
+        atomicAdd(dbeta + c, sb);
+    }
+}
+
+// ---- GroupNorm on token-major maps ------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wid] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+template <typename T, typename TY>
+__global__ __launch_bounds__(256) void gn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TY* __restrict__ y,
+                                                     float* __restrict__ stats, int HW, int C, int G,
+                                                     int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride,
+                                                     float eps) {
+    __shared__ float sm[4];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int cpg = C / G;
+    const T* xb = x + ((int64_t)n * x_stride + x_off) * C + g * cpg;
+    TY* yb = y + ((int64_t)n * y_stride + y_off) * C + g * cpg;
+    float s = 0.f;
+    for (int hw = threadIdx.x; hw < HW; hw += 256)
+        for (int c = 0; c < cpg; ++c) s += io<T>::ld(xb + (int64_t)hw * C + c);
+    const float cnt = (float)HW * (float)cpg;
+    const float mu = block_sum(s, sm) / cnt;
+    float q = 0.f;
+    for (int hw = threadIdx.x; hw < HW; hw += 256)
+        for (int c = 0; c < cpg; ++c) { const float t = io<T>::ld(xb + (int64_t)hw * C + c) - mu; q += t * t; }
+    const float rs = rsqrtf(block_sum(q, sm) / cnt + eps);
+    if (threadIdx.x == 0) { stats[(n * G + g) * 2] = mu; stats[(n * G + g) * 2 + 1] = rs; }
+    for (int hw = threadIdx.x; hw < HW; hw += 256)
+        for (int c = 0; c < cpg; ++c) {
+            const float v = (io<T>::ld(xb + (int64_t)hw * C + c) - mu) * rs * gamma[g * cpg + c] + beta[g * cpg + c];
+            io<TY>::st(yb + (int64_t)hw * C + c, v);
+        }
+}
+
+template <typename T, typename TY>
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const TY* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int HW, int C, int G,
+                                                     int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride) {
+    __shared__ float sm[4];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int cpg = C / G;
+    const int64_t base = ((int64_t)n * x_stride + x_off) * C + g * cpg;
+    const int64_t ybase = ((int64_t)n * y_stride + y_off) * C + g * cpg;
+    const float mu = stats[(n * G + g) * 2], rs = stats[(n * G + g) * 2 + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+        float pg = 0.f, pb = 0.f;
+        const float gmc = gamma[g * cpg + c];
+        for (int hw = threadIdx.x; hw < HW; hw += 256) {
+            const float d = io<TY>::ld(dy + ybase + (int64_t)hw * C + c);
+            const float xh = (io<T>::ld(x + base + (int64_t)hw * C + c) - mu) * rs;
+            pg += d * xh;
+            pb += d;
+        }
+        pg = block_sum(pg, sm);
+        pb = block_sum(pb, sm);
+        if (threadIdx.x == 0) { atomicAdd(dgamma + g * cpg + c, pg); atomicAdd(dbeta + g * cpg + c, pb); }
+        s1 += gmc * pb;
+        s2 += gmc * pg;
+    }
+    const float cnt = (float)HW * (float)cpg;
+    const float m1 = s1 / cnt, m2 = s2 / cnt;
+    for (int hw = threadIdx.x; hw < HW; hw += 256)
+        for (int c = 0; c < cpg; ++c) {
+            const float d = io<TY>::ld(dy + ybase + (int64_t)hw * C + c) * gamma[g * cpg + c];
+            const float xh = (io<T>::ld(x + base + (int64_t)hw * C + c) - mu) * rs;
+            io<T>::st(dx + base + (int64_t)hw * C + c, rs * (d - m1 - xh * m2));
+        }
+}
+
+}  // namespace poet
+
+using namespace poet;
+
+// dispatch over the supported (branch dtype, stream dtype) pairs
+#define POET_DT2(dx, dr, LAUNCH)                                                                     \
+    do {                                                                                             \
+        if (dx == POET_BF16 && dr == POET_BF16) LAUNCH(bf16_t, bf16_t);                              \
+        else if (dx == POET_F32 && dr == POET_F32) LAUNCH(float, float);                             \
+        else if (dx == POET_BF16 && dr == POET_F32) LAUNCH(bf16_t, float);                           \
+        else { set_error("norm: unsupported dtype pair x=%d r=%d", dx, dr); return POET_ERR_UNSUPPORTED; } \
+    } while (0)
+
+extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
+                           float* mean, float* rstd, int64_t rows, int d, float eps, float drop_p, uint32_t seed,
+                           int dtype_x, int dtype_r, void* stream) {
+    POET_CHECK(x && gamma && beta && y, POET_ERR_ARG, "ln_fwd: null pointer");
+    POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_fwd: d=%d unsupported", d);
+    POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "ln_fwd: drop_p");
+    const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+    const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed)
+    POET_DT2(dtype_x, dtype_r, LN_FWD);
+#undef LN_FWD
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                           void* dz_out, void* dx_out, float* dgamma, float* dbeta, int64_t rows, int d, float drop_p,
+                           uint32_t seed, int dtype_x, int dtype_r, void* stream) {
+    POET_CHECK(dy && z && mean && rstd && gamma && dz_out && dgamma && dbeta, POET_ERR_ARG, "ln_bwd: null pointer");
+    POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_bwd: d=%d unsupported", d);
+    POET_CHECK(!(drop_p > 0.f && dx_out == dz_out), POET_ERR_ARG, "ln_bwd: dx_out must not alias dz_out when drop_p>0");
+    POET_CHECK(!(dtype_x != dtype_r && (dx_out == nullptr || dx_out == dz_out)), POET_ERR_ARG, "ln_bwd: mixed dtypes need a separate dx_out");
+    const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+    const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    int nb = cdiv(rows, 4);
+    if (nb > 512) nb = 512;
+    dim3 grid(nb), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed)
+    POET_DT2(dtype_x, dtype_r, LN_BWD);
+#undef LN_BWD
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int N,
+                                  int HW, int C, int G, int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride,
+                                  float eps, int dtype_x, int dtype_y, void* stream) {
+    POET_CHECK(x && gamma && beta && y && stats, POET_ERR_ARG, "groupnorm_fwd: null pointer");
+    POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0, POET_ERR_ARG, "groupnorm_fwd: bad dims");
+    dim3 grid(N * G), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define GN_FWD(TX, TR) gn_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, HW, C, G, x_off, x_stride, y_off, y_stride, eps)
+    POET_DT2(dtype_x, dtype_y, GN_FWD);
+#undef GN_FWD
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_groupnorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                                  float* dgamma, float* dbeta, int N, int HW, int C, int G, int64_t x_off,
+                                  int64_t x_stride, int64_t y_off, int64_t y_stride, int dtype_x, int dtype_y, void* stream) {
+    POET_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta, POET_ERR_ARG, "groupnorm_bwd: null pointer");
+    POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0, POET_ERR_ARG, "groupnorm_bwd: bad dims");
+    dim3 grid(N * G), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define GN_BWD(TX, TR) gn_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)x, stats, gamma, (TX*)dx, dgamma, dbeta, HW, C, G, x_off, x_stride, y_off, y_stride)
+    POET_DT2(dtype_x, dtype_y, GN_BWD);
+#undef GN_BWD
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}

@@ -1,0 +1,290 @@
+"""Training-step engine around the hot path (the loop body of the reference's engine.py:55-81):
+flat parameter/gradient arenas, fused clip+AdamW, bucketed RCCL all-reduce overlapped with backward,
+and an op-for-op PyTorch counterpart of the reference's matcher/loss (kept unchanged in behaviour).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops
+
+ALIGN = 64   # elements (256 B): every parameter starts on a 16-B-aligned, vector-friendly offset
+
+
+def _bucket_of(name: str) -> str:
+    """Backward-completion order of the four autograd nodes (heads -> decoder -> encoder -> input_proj)."""
+    if name.startswith(("translation_head", "rotation_head")):
+        return "0_heads"
+    if name.startswith("transformer.decoder"):
+        return "1_decoder"
+    if name.startswith(("transformer.encoder", "transformer.level_embed")):
+        return "2_encoder"
+    return "3_input_proj"
+
+
+class ParamArena:
+    """All trainable parameters in ONE fp32 buffer (+ matching grad / Adam moment buffers).
+
+    * kernels write parameter gradients straight into the grad arena (`p._grad_view`), so autograd
+      never allocates, copies or accumulates a parameter gradient;
+    * zero_grad is one memset, clip_grad_norm_ one reduction, AdamW one launch per LR group;
+    * data parallel: buckets are contiguous arena ranges in backward-completion order, so each
+      all-reduce is a single large RCCL call launched while the rest of backward still runs.
+    Layout: [default-LR params by bucket | 0.1x-LR params (sampling_offsets, main.py:41)].
+    Parameters that never receive a gradient in this configuration (transformer.reference_points.*
+    in bbox mode; the reason the reference needs find_unused_parameters=True) stay outside, exactly as
+    torch.optim.AdamW skips parameters whose .grad is None.
+    """
+
+    def __init__(self, model: nn.Module, lr=2e-4, lr_proj_mult=0.1, proj_names=("reference_points", "sampling_offsets"),
+                 weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, exclude=("transformer.reference_points",)):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not any(e in n for e in exclude)]
+        is_proj = lambda n: any(k in n for k in proj_names)
+        main = sorted([(n, p) for n, p in named if not is_proj(n)], key=lambda t: _bucket_of(t[0]))
+        proj = [(n, p) for n, p in named if is_proj(n)]
+        dev = named[0][1].device
+        self.entries, off = [], 0
+        self.buckets: List[tuple] = []
+        cur, start = None, 0
+        for n, p in main:
+            b = _bucket_of(n)
+            if b != cur:
+                if cur is not None:
+                    self.buckets.append((cur, start, off))
+                cur, start = b, off
+            self.entries.append((n, p, off))
+            off += -(-p.numel() // ALIGN) * ALIGN
+        self.buckets.append((cur, start, off))
+        self.n_main = off
+        for n, p in proj:
+            self.entries.append((n, p, off))
+            off += -(-p.numel() // ALIGN) * ALIGN
+        if off > self.n_main:
+            self.buckets.append(("4_proj", self.n_main, off))
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        for n, p, o in self.entries:
+            k = p.numel()
+            self.flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + k].view(p.shape)
+            p._grad_view = self.grad[o:o + k].view(p.shape)
+            p.grad = p._grad_view
+        self.groups = [(0, self.n_main, lr), (self.n_main, self.total, lr * lr_proj_mult)]
+        self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
+        self.step_count = 0
+        self.world = 1
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def step(self, max_norm: float = 0.1):
+        """clip_grad_norm_(max_norm) + AdamW (engine.py:77-81) on the flat arenas."""
+        self.step_count += 1
+        gs = 1.0 / self.world
+        sq = None
+        if max_norm > 0:
+            self.sq.zero_()
+            ops.sqnorm(self.grad, self.sq)
+            sq = self.sq
+        for a, b, lr in self.groups:
+            if b > a:
+                ops.adamw(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b], b - a, lr, self.betas[0], self.betas[1],
+                          self.eps, self.weight_decay, self.step_count, sqnorm_buf=sq, max_norm=max_norm, grad_scale=gs)
+
+    def grad_norm(self) -> torch.Tensor:
+        return torch.sqrt(self.sq[0]) / self.world
+
+
+class BucketReducer:
+    """Data-parallel gradient all-reduce (the reference's DDP, main.py:282): one process per GPU,
+    `torch.distributed` backend 'nccl' == RCCL over xGMI.  Buckets are whole contiguous arena ranges;
+    `bucket_done(tag)` is called from the end of each backward node, records an event on the compute
+    stream and enqueues the all-reduce on a dedicated comm stream, so the collective of bucket k
+    overlaps the backward of bucket k+1.  Sum-reduce here, the 1/world average is folded into the
+    optimizer kernel (grad_scale)."""
+
+    def __init__(self, arena: ParamArena, group=None):
+        self.arena, self.group = arena, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        arena.world = self.world
+        self.on_gpu = arena.grad.is_cuda
+        self.comm = torch.cuda.Stream() if (self.on_gpu and self.world > 1) else None
+        self.pending = []
+        self.done = set()
+
+    def bucket_done(self, tag: str):
+        if self.world == 1:
+            return
+        for name, a, b in self.arena.buckets:
+            if name == tag and name not in self.done:
+                self.done.add(name)
+                self._reduce(a, b)
+
+    def _reduce(self, a, b):
+        buf = self.arena.grad[a:b]
+        if self.comm is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+
+    def finish(self):
+        """Reduce whatever was not announced (e.g. the 0.1x-LR tail), then make the compute stream wait."""
+        if self.world == 1:
+            return
+        for name, a, b in self.arena.buckets:
+            if name not in self.done:
+                self.done.add(name)
+                self._reduce(a, b)
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        self.done.clear()
+
+
+# ---- backward-completion hooks (set by the trainer; the autograd nodes call announce()) ----------------
+_REDUCER: Optional[BucketReducer] = None
+
+
+def set_reducer(r: Optional[BucketReducer]):
+    global _REDUCER
+    _REDUCER = r
+
+
+def announce(tag: str):
+    if _REDUCER is not None:
+        _REDUCER.bucket_done(tag)
+
+
+# ====================================================================================================
+# matcher + loss: PyTorch counterpart of models/matcher.py:104-229 ('gt' mode) and
+# models/pose_estimation_transformer.py:454-674 (translation + geodesic rotation losses)
+# ====================================================================================================
+class PoseMatcher(nn.Module):
+    def __init__(self, cost_bbox: float = 1, cost_class: float = 1, bbox_mode: str = "gt", class_mode: str = "specific"):
+        super().__init__()
+        if bbox_mode != "gt":
+            raise NotImplementedError("PoseMatcher: only bbox_mode='gt' is implemented")
+        self.cost_bbox, self.cost_class = cost_bbox, cost_class
+        self._cache = (None, None)
+
+    @torch.no_grad()
+    def forward(self, outputs, targets, n_boxes):
+        from scipy.optimize import linear_sum_assignment
+        pb = outputs["pred_boxes"]
+        if self._cache[0] is pb:            # same boxes for every decoder layer: identical assignment
+            return self._cache[1]
+        bs, nq = pb.shape[:2]
+        out_bbox = pb.flatten(0, 1).detach().cpu()
+        tgt_bbox = torch.cat([t["boxes"].detach().cpu() for t in targets])
+        cost = (self.cost_bbox * torch.cdist(out_bbox, tgt_bbox, p=1)).view(bs, nq, -1)
+        sizes = [len(t["boxes"]) for t in targets]
+        res = []
+        for i, c in enumerate(cost.split(sizes, -1)):
+            r, cidx = linear_sum_assignment(c[i][: n_boxes[i]])
+            res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
+        self._cache = (pb, res)
+        return res
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, matcher, weight_dict, losses=("translation", "rotation")):
+        super().__init__()
+        if tuple(losses) != ("translation", "rotation"):
+            raise NotImplementedError("only the translation + rotation (6d) losses are implemented")
+        self.matcher, self.weight_dict, self.losses = matcher, weight_dict, list(losses)
+
+    @staticmethod
+    def _gather_targets(targets, indices, device):
+        b = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        s = torch.cat([src for (src, _) in indices])
+        tt = torch.cat([t["relative_position"][j.to(t["relative_position"].device)] for t, (_, j) in zip(targets, indices)], 0)
+        tr = torch.cat([t["relative_rotation"][j.to(t["relative_rotation"].device)] for t, (_, j) in zip(targets, indices)], 0)
+        return b.to(device), s.to(device), tt.to(device), tr.to(device)
+
+    def _losses(self, outputs, gathered):
+        b, s, tt, tr = gathered
+        n_obj = len(tt)
+        st = outputs["pred_translation"][b, s]
+        loss_t = torch.sqrt(((st - tt) ** 2).sum(1)).sum() / n_obj
+        sr = outputs["pred_rotation"][b, s]
+        prod = torch.bmm(sr, tr.transpose(1, 2))
+        trace = prod.diagonal(dim1=1, dim2=2).sum(1)
+        theta = torch.clamp(0.5 * (trace - 1), -1 + 1e-6, 1 - 1e-6)
+        return {"loss_trans": loss_t, "loss_rot": torch.acos(theta).sum() / n_obj}
+
+    def forward(self, outputs, targets, n_boxes):
+        main = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
+        dev = outputs["pred_translation"].device
+        indices = self.matcher(main, targets, n_boxes)
+        gathered, last = self._gather_targets(targets, indices, dev), indices
+        losses = dict(self._losses(outputs, gathered))
+        for i, aux in enumerate(outputs.get("aux_outputs", [])):
+            indices = self.matcher(aux, targets, n_boxes)
+            if indices is not last:
+                gathered, last = self._gather_targets(targets, indices, dev), indices
+            losses.update({f"{k}_{i}": v for k, v in self._losses(aux, gathered).items()})
+        return losses
+
+
+def build_weight_dict(dec_layers, t_coef=1.0, r_coef=1.0, aux=True):
+    """pose_estimation_transformer.py:714,728-733 (the *_enc entries are never produced by the model)."""
+    wd = {"loss_trans": t_coef, "loss_rot": r_coef}
+    if aux:
+        for i in range(dec_layers - 1):
+            wd.update({f"loss_trans_{i}": t_coef, f"loss_rot_{i}": r_coef})
+    return wd
+
+
+def reduce_dict(loss_dict: Dict[str, torch.Tensor], average=True):
+    """util/misc.py:168-195: all-reduce the stacked loss scalars for logging."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world < 2:
+        return loss_dict
+    with torch.no_grad():
+        names = sorted(loss_dict)
+        vals = torch.stack([loss_dict[k].detach() for k in names])
+        dist.all_reduce(vals)
+        if average:
+            vals = vals / world
+        return dict(zip(names, vals))
+
+
+class Trainer:
+    """One training step == engine.py:55-81 (forward, loss, zero_grad, backward, clip, AdamW)."""
+
+    def __init__(self, model: nn.Module, criterion: SetCriterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1,
+                 distributed: Optional[bool] = None):
+        self.model, self.criterion, self.max_norm = model, criterion, max_norm
+        self.arena = ParamArena(model, lr=lr, weight_decay=weight_decay)
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.reducer = BucketReducer(self.arena) if distributed else None
+        if self.reducer is not None and self.reducer.world > 1:
+            dist.broadcast(self.arena.flat, src=0)      # DDP's initial parameter sync
+
+    def step(self, samples, targets):
+        set_reducer(self.reducer)
+        out, n_boxes = self.model(samples, targets)
+        loss_dict = self.criterion(out, targets, n_boxes)
+        wd = self.criterion.weight_dict
+        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        self.arena.zero_grad()
+        total.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.arena.step(self.max_norm)
+        set_reducer(None)
+        return total.detach(), loss_dict

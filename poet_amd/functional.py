@@ -1,0 +1,299 @@
+"""torch.autograd.Function wrappers: four coarse nodes (input_proj, encoder, decoder, heads) plus the
+stand-alone MSDeformAttn node.  Each forward/backward is a hand-written kernel program
+(poet_amd.blocks) -- autograd only carries the tensors across the few node boundaries."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+from . import blocks as B
+from . import ops
+from .engine import announce
+
+
+def _pdict(names: Sequence[str], params: Sequence[torch.Tensor], prefix: str):
+    n = len(prefix)
+    return {k[n:]: p for k, p in zip(names, params) if k.startswith(prefix)}
+
+
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src_dtype = x.dtype
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+        ops.cast(x.contiguous(), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out = torch.empty(g.shape, dtype=ctx.src_dtype, device=g.device)
+        ops.cast(g.contiguous(), out)
+        return out, None
+
+
+# ====================================================================================================
+# Encoder: all layers in one node
+# ====================================================================================================
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, pos, level_embed, ref, mask, geom, cfg, names, *params):
+        """src,pos (N,S,d) T; ref (N,S,L,2) fp32; mask (N*S) uint8 or None; cfg dict(M,P,p,training,n_layers)."""
+        N, S, d = src.shape
+        x = src.reshape(N * S, d)
+        pos2 = pos.reshape(N * S, d)
+        saved = []
+        for i in range(cfg["n_layers"]):
+            P_ = _pdict(names, params, f"layers.{i}.")
+            x, sv = B.enc_layer_fwd(x, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"], cfg["training"],
+                                       cfg.get("act"))
+            saved.append(sv)
+        ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
+        ctx.ref, ctx.mask, ctx.level_embed, ctx.shape = ref, mask, level_embed, (N, S, d)
+        ctx.need_src = src.requires_grad
+        return x.view(N, S, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, S, d = ctx.shape
+        cfg, geom, names, params = ctx.cfg, ctx.geom, ctx.names, ctx.params
+        G = B.GradSink(list(names) + ["level_embed"], list(params) + [ctx.level_embed])
+        g_level = G("level_embed") if ctx.level_embed.requires_grad else None
+        dx = dout.contiguous().view(N * S, d)
+        for i in reversed(range(cfg["n_layers"])):
+            pre = f"layers.{i}."
+            dx = B.enc_layer_bwd(dx, ctx.saved[i], _pdict(names, params, pre), G, pre, ctx.ref, S * geom.L * 2, ctx.mask, geom,
+                                 N, cfg["M"], cfg["P"], g_level)
+            ctx.saved[i] = None
+        announce("2_encoder")
+        dsrc = dx.view(N, S, d) if ctx.need_src else None
+        return (dsrc, None, G.ret[-1], None, None, None, None, None, *G.ret[:-1])
+
+
+# ====================================================================================================
+# Decoder: memory value projections + all layers in one node
+# ====================================================================================================
+class DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, memory, tgt, qpos, ref_in, mask, geom, cfg, names, *params):
+        """memory (N,S,d) T; tgt,qpos (N,Q,d) fp32; ref_in (N,Q,L,2) fp32.  Returns hs (n_layers,N,Q,d) fp32."""
+        N, S, d = memory.shape
+        Q, M = tgt.shape[1], cfg["M"]
+        D = d // M
+        mem2 = memory.reshape(N * S, d)
+        x = tgt.reshape(N * Q, d).contiguous()
+        qp = qpos.reshape(N * Q, d).contiguous()
+        hs = torch.empty((cfg["n_layers"], N, Q, d), dtype=torch.float32, device=memory.device)
+        saved = []
+        for i in range(cfg["n_layers"]):
+            P_ = _pdict(names, params, f"layers.{i}.")
+            V = B.value_proj_fwd(mem2, P_["cross_attn.value_proj.weight"], P_["cross_attn.value_proj.bias"], mask, N, S, M, D,
+                                 cfg.get("act"))
+            x, sv = B.dec_layer_fwd(x, qp, V, P_, ref_in, geom, N, Q, M, cfg["P"], cfg["p"], cfg["training"])
+            ops.cast(x, hs[i])
+            saved.append(sv)
+        ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
+        ctx.mem2, ctx.ref_in, ctx.mask, ctx.dims = mem2, ref_in, mask, (N, S, d, Q)
+        ctx.need_mem, ctx.need_tgt = memory.requires_grad, tgt.requires_grad
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        N, S, d, Q = ctx.dims
+        cfg, geom, names, params = ctx.cfg, ctx.geom, ctx.names, ctx.params
+        M = cfg["M"]
+        D = d // M
+        G = B.GradSink(names, params)
+        dhs = dhs.contiguous()
+        dmem = torch.empty((N * S, d), dtype=ctx.mem2.dtype, device=dhs.device) if ctx.need_mem else None
+        dx = None
+        first = True
+        for i in reversed(range(cfg["n_layers"])):
+            pre = f"layers.{i}."
+            P_ = _pdict(names, params, pre)
+            dcur = dhs[i].view(N * Q, d)
+            if dx is not None:
+                ops.add(dx, dcur, dx)
+            else:
+                dx = dcur.clone()
+            dV = torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
+            dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV)
+            B.value_proj_bwd(dV, ctx.mem2, P_["cross_attn.value_proj.weight"], ctx.mask, N, S, M, D,
+                             G(pre + "cross_attn.value_proj.weight"), G(pre + "cross_attn.value_proj.bias"), dmem, not first,
+                             cfg.get("act"))
+            first = False
+            ctx.saved[i] = None
+        announce("1_decoder")
+        dmemory = dmem.view(N, S, d) if ctx.need_mem else None
+        dtgt = dx.view(N, Q, d) if ctx.need_tgt else None
+        return (dmemory, dtgt, None, None, None, None, None, None, *G.ret)
+
+
+# ====================================================================================================
+# Pose heads: per decoder layer two 3-layer MLPs + class-slot gather + 6D->R
+# ====================================================================================================
+class HeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hs, cls, ncls, names, *params):
+        """hs (L,N,Q,d) fp32; cls (N*Q) int32.  Returns rot (L,N,Q,3,3), trans (L,N,Q,3)."""
+        nl, N, Q, d = hs.shape
+        R = N * Q
+        hs = hs.contiguous()
+        rot = torch.empty((nl, N, Q, 3, 3), dtype=torch.float32, device=hs.device)
+        trans = torch.empty((nl, N, Q, 3), dtype=torch.float32, device=hs.device)
+        saved = []
+        for i in range(nl):
+            h = hs[i].view(R, d)
+            Pr = _pdict(names, params, f"rotation_head.{i}.layers.")
+            Pt = _pdict(names, params, f"translation_head.{i}.layers.")
+            r_all, rs = B.mlp3_fwd(h, [Pr[f"{k}.weight"] for k in range(3)], [Pr[f"{k}.bias"] for k in range(3)])
+            t_all, ts = B.mlp3_fwd(h, [Pt[f"{k}.weight"] for k in range(3)], [Pt[f"{k}.bias"] for k in range(3)])
+            ops.pose_finish_fwd(r_all, t_all, cls, rot[i], trans[i], R, ncls)
+            saved.append((r_all, rs, ts))
+        ctx.saved, ctx.hs, ctx.cls, ctx.ncls, ctx.names, ctx.params = saved, hs, cls, ncls, names, params
+        return rot, trans
+
+    @staticmethod
+    def backward(ctx, drot, dtrans):
+        hs, cls, ncls, names, params = ctx.hs, ctx.cls, ctx.ncls, ctx.names, ctx.params
+        nl, N, Q, d = hs.shape
+        R = N * Q
+        G = B.GradSink(names, params)
+        drot, dtrans = drot.contiguous(), dtrans.contiguous()
+        dhs = torch.empty_like(hs)
+        for i in range(nl):
+            h = hs[i].view(R, d)
+            r_all, rs, ts = ctx.saved[i]
+            pr, pt = f"rotation_head.{i}.layers.", f"translation_head.{i}.layers."
+            Pr, Pt = _pdict(names, params, pr), _pdict(names, params, pt)
+            dr_all = torch.empty_like(r_all)
+            dt_all = torch.empty((R, ncls * 3), dtype=torch.float32, device=hs.device)
+            ops.pose_finish_bwd(r_all, cls, drot[i], dtrans[i], dr_all, dt_all, R, ncls)
+            dh = dhs[i].view(R, d)
+            B.mlp3_bwd(dr_all, h, [Pr[f"{k}.weight"] for k in range(3)], rs, [G(pr + f"{k}.weight") for k in range(3)],
+                       [G(pr + f"{k}.bias") for k in range(3)], dh, False)
+            B.mlp3_bwd(dt_all, h, [Pt[f"{k}.weight"] for k in range(3)], ts, [G(pt + f"{k}.weight") for k in range(3)],
+                       [G(pt + f"{k}.bias") for k in range(3)], dh, True)
+        announce("0_heads")
+        return (dhs, None, None, None, *G.ret)
+
+
+# ====================================================================================================
+# input_proj: 1x1 conv (+3x3 s2 conv for extra levels) + GroupNorm(32), written token-major
+# ====================================================================================================
+class InputProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, geom, n_groups, dtypes, names, *params):
+        """feats: list of NCHW backbone maps (no grad).  Levels beyond len(feats) come from the 3x3 s2 conv of the
+        last backbone map (first extra level) or of the previous projected map (further ones)."""
+        N = feats[0].shape[0]
+        d = params[0].shape[0]
+        S = geom.S
+        act_dtype, stream_dtype = dtypes          # branch (conv output) dtype, residual-stream dtype
+        src = torch.empty((N, S, d), dtype=stream_dtype, device=feats[0].device)
+        saved = []
+        for lvl in range(geom.L):
+            W, b = params[names.index(f"{lvl}.0.weight")], params[names.index(f"{lvl}.0.bias")]
+            gw, gb = params[names.index(f"{lvl}.1.weight")], params[names.index(f"{lvl}.1.bias")]
+            H, Wd = geom.shapes[lvl]
+            HW = H * Wd
+            pre = torch.empty((N, HW, d), dtype=act_dtype, device=src.device)
+            if lvl < len(feats):
+                f = feats[lvl].contiguous()
+                C = f.shape[1]
+                ops.gemm(f, W, pre, HW, d, C, lda=HW, ldb=C, ldc=d, a_kmajor=True, bias=b, batch=N, strideA=C * HW, strideC=HW * d)
+                col = None
+            else:
+                if lvl == len(feats):
+                    inp = feats[-1].contiguous()
+                else:       # further extra levels: previous projected level back to NCHW
+                    Hp, Wp = geom.shapes[lvl - 1]
+                    inp = torch.empty((N, d, Hp, Wp), dtype=act_dtype, device=src.device)
+                    ops.tokens_to_nchw(src, inp, N, d, Hp * Wp, geom.starts[lvl - 1], S)
+                C, Hi, Wi = inp.shape[1:]
+                col = torch.empty((N * HW, C * 9), dtype=act_dtype, device=src.device)
+                ops.im2col3x3s2(inp, col, N, C, Hi, Wi, H, Wd)
+                ops.linear_fwd(col, W.view(d, C * 9), b, pre)
+                f = None
+            stats = torch.empty((N, n_groups, 2), dtype=torch.float32, device=src.device)
+            ops.groupnorm_fwd(pre, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S)
+            saved.append((f, col, pre, stats))
+        ctx.saved, ctx.geom, ctx.n_groups, ctx.names, ctx.params, ctx.dims = saved, geom, n_groups, names, params, (N, S, d)
+        ctx.n_feats = len(feats)
+        return src
+
+    @staticmethod
+    def backward(ctx, dsrc):
+        geom, names, params = ctx.geom, ctx.names, ctx.params
+        N, S, d = ctx.dims
+        G = B.GradSink(names, params)
+        dsrc = dsrc.contiguous()
+        if geom.L > ctx.n_feats + 1:
+            raise NotImplementedError("backward through more than one extra feature level")
+        for lvl in range(geom.L):
+            f, col, pre, stats = ctx.saved[lvl]
+            H, Wd = geom.shapes[lvl]
+            HW = H * Wd
+            gw = params[names.index(f"{lvl}.1.weight")]
+            dpre = torch.empty_like(pre)
+            ops.groupnorm_bwd(dsrc, pre, stats, gw, dpre, G(f"{lvl}.1.weight"), G(f"{lvl}.1.bias"), N, HW, d, ctx.n_groups,
+                              0, HW, geom.starts[lvl], S)
+            gW = G(f"{lvl}.0.weight")
+            ops.colsum(dpre, d, G(f"{lvl}.0.bias"), 1, N * HW, d)
+            if f is not None:
+                C = f.shape[1]
+                ops.gemm(dpre, f, gW, d, C, HW, lda=d, ldb=HW, ldc=C, a_kmajor=True, b_kmajor=False, batch=N,
+                         strideA=HW * d, strideB=C * HW, strideC=0, atomic=True, splitk=max(1, min(8, HW // 512)))
+            else:
+                ops.linear_dw(dpre.view(N * HW, d), col, gW.view(d, -1), rows=N * HW)
+        announce("3_input_proj")
+        return (None, None, None, None, None, *G.ret)
+
+
+# ====================================================================================================
+# Stand-alone MSDeformAttn (the drop-in for `deformable_attention.MSDeformAttn`)
+# ====================================================================================================
+MSDA_PARAMS = ("sampling_offsets.weight", "sampling_offsets.bias", "attention_weights.weight", "attention_weights.bias",
+               "value_proj.weight", "value_proj.bias", "output_proj.weight", "output_proj.bias")
+
+
+class MSDeformAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, query, ref, inp, mask, geom, M, npts, *params):
+        P_ = dict(zip(MSDA_PARAMS, params))
+        N, Lq, d = query.shape
+        S = inp.shape[1]
+        D = d // M
+        q2 = query.reshape(N * Lq, d).contiguous()
+        in2 = inp.reshape(N * S, d).contiguous()
+        refc = ref.contiguous().float()
+        V = B.value_proj_fwd(in2, P_["value_proj.weight"], P_["value_proj.bias"], mask, N, S, M, D)
+        out_m, OA = B.sample_fwd(q2, P_["sampling_offsets.weight"], P_["sampling_offsets.bias"], P_["attention_weights.weight"],
+                                 P_["attention_weights.bias"], V, geom, refc, Lq * geom.L * 2, N, Lq, M, D, npts)
+        out = torch.empty((N * Lq, d), dtype=query.dtype, device=query.device)
+        ops.linear_fwd(out_m, P_["output_proj.weight"], P_["output_proj.bias"], out)
+        ctx.sv = (q2, in2, refc, V, OA, out_m, mask, geom, M, npts, params, (N, Lq, S, d))
+        ctx.need = (query.requires_grad, inp.requires_grad)
+        return out.view(N, Lq, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, in2, refc, V, OA, out_m, mask, geom, M, npts, params, (N, Lq, S, d) = ctx.sv
+        P_ = dict(zip(MSDA_PARAMS, params))
+        D = d // M
+        G = B.GradSink(MSDA_PARAMS, params)
+        dy = dout.contiguous().view(N * Lq, d)
+        rows = N * Lq
+        ops.linear_dw(dy, out_m, G("output_proj.weight"), rows=rows)
+        ops.colsum(dy, d, G("output_proj.bias"), 1, rows, d)
+        d_out_m = torch.empty_like(out_m)
+        ops.linear_dx(dy, P_["output_proj.weight"], d_out_m, rows=rows)
+        dV = torch.zeros(V.shape, dtype=torch.float32, device=dy.device)
+        dq = torch.empty_like(q2) if ctx.need[0] else None
+        B.sample_bwd(d_out_m, q2, OA, P_["sampling_offsets.weight"], P_["attention_weights.weight"], V, geom, refc,
+                     Lq * geom.L * 2, N, Lq, M, D, npts, dV, G("sampling_offsets.weight"), G("sampling_offsets.bias"),
+                     G("attention_weights.weight"), G("attention_weights.bias"), dq, False)
+        dinp = torch.empty_like(in2) if ctx.need[1] else None
+        B.value_proj_bwd(dV, in2, P_["value_proj.weight"], mask, N, S, M, D, G("value_proj.weight"), G("value_proj.bias"), dinp, False)
+        return (dq.view(N, Lq, d) if dq is not None else None, None, dinp.view(N, S, d) if dinp is not None else None,
+                None, None, None, None, *G.ret)

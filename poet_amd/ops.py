@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).  torch is plumbing only: it owns the
+device buffers and the stream; every computation below is a libpoet_hip.so kernel."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, GemmDesc
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dcode(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"poet_amd: unsupported dtype {t.dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.PoetHipError(f"poet_amd: {name} must live on the GPU (no CPU path exists)")
+    return t
+
+
+def _i64arr(vals: Sequence[int]):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+class LevelGeom:
+    """Host-side multi-scale geometry: spatial shapes (H,W) per level and start offsets."""
+
+    def __init__(self, shapes: Sequence[Sequence[int]]):
+        self.shapes = [(int(h), int(w)) for h, w in shapes]
+        self.L = len(self.shapes)
+        starts, acc = [], 0
+        for h, w in self.shapes:
+            starts.append(acc)
+            acc += h * w
+        self.starts = starts
+        self.S = acc
+        self.c_shapes = _i64arr([v for hw in self.shapes for v in hw])
+        self.c_starts = _i64arr(starts)
+        self.c_segs = _i64arr(starts + [acc])
+
+    def key(self):
+        return tuple(self.shapes)
+
+
+# ---- GEMM ------------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
+         a_kmajor=False, b_kmajor=False, bias=None, act=0, add_src=None, ld_add=0, gate_ref=None, gate_scale=1.0,
+         row_mask=None, drop_p=0.0, seed=0, compute=None, batch=1, strideA=0, strideB=0, strideC=0, stride_bias=0,
+         splitk=1, atomic=False, alpha=1.0, head_major=None):
+    lib = _lib.load()
+    _req(A, "A"); _req(B, "B"); _req(Cout, "C")
+    d = GemmDesc()
+    d.A, d.A2, d.B, d.C = A.data_ptr(), None, B.data_ptr(), Cout.data_ptr()
+    d.bias, d.add_src, d.gate_ref, d.row_mask = _ptr(bias), _ptr(add_src), _ptr(gate_ref), _ptr(row_mask)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ld_add = lda, ldb, ldc, ld_add
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.a_dtype, d.b_dtype, d.c_dtype = dcode(A), dcode(B), dcode(Cout)
+    if compute is None:     # bf16 MFMA as soon as any operand is stored in bf16; pure-fp32 calls use the f32 MFMA
+        compute = BF16 if torch.bfloat16 in (A.dtype, B.dtype, Cout.dtype) else F32
+    d.compute = compute
+    d.batch, d.strideA, d.strideB, d.strideC, d.stride_bias = batch, strideA, strideB, strideC, stride_bias
+    d.splitk, d.atomic, d.act = splitk, int(atomic), act
+    d.alpha, d.gate_scale, d.drop_p, d.seed = alpha, gate_scale, drop_p, seed & 0xFFFFFFFF
+    if head_major is not None:
+        d.out_mode, d.hm_M, d.hm_S, d.hm_D = 1, *head_major
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias must be fp32")
+    _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
+    return Cout
+
+
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, *, act=0,
+               drop_p=0.0, seed=0, row_mask=None, add_src=None, head_major=None, ldc=None, ldx=None):
+    """out[rows, N] = act(x[rows, K] @ W[N, K]^T + b).  x / out may be column slices (ldx / ldc)."""
+    rows = x.numel() // x.shape[-1] if ldx is None else x.shape[0]
+    N, K = W.shape
+    return gemm(x, W, out, rows, N, K, lda=ldx or K, ldb=K, ldc=ldc or N, bias=b, act=act, drop_p=drop_p, seed=seed,
+                row_mask=row_mask, add_src=add_src, ld_add=(ldc or N), head_major=head_major)
+
+
+def linear_dx(dy: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, rows: int, ldy=None, add_src=None,
+              gate_ref=None, gate_scale=1.0, ldc=None):
+    """out[rows, K_in] = dy[rows, N_out] @ W[N_out, K_in]  (+add_src, gated)."""
+    n_out, k_in = W.shape
+    return gemm(dy, W, out, rows, k_in, n_out, lda=ldy or n_out, ldb=k_in, ldc=ldc or k_in, b_kmajor=True,
+                add_src=add_src, ld_add=(ldc or k_in), gate_ref=gate_ref, gate_scale=gate_scale)
+
+
+def _splitk_for(M, N, K):
+    big = M >= 512 and N >= 128
+    t = 128 if big else 64
+    tiles = -(-M // t) * -(-N // t)
+    return max(1, min(-(-1024 // tiles), -(-K // 256)))
+
+
+def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None):
+    """dW[N_out, K_in] += dy[rows, N_out]^T @ x[rows, K_in]   (fp32 atomics, split-K over rows)."""
+    n_out, k_in = dW.shape
+    return gemm(dy, x, dW, n_out, k_in, rows, lda=ldy or n_out, ldb=ldx or k_in, ldc=k_in, a_kmajor=True, b_kmajor=True,
+                splitk=_splitk_for(n_out, k_in, rows), atomic=True)
+
+
+# ---- MSDA ------------------------------------------------------------------------------------------
+def msda_fwd(value, geom: LevelGeom, loc, attn, out):
+    lib = _lib.load()
+    N, S, M, D = value.shape
+    Lq, P = loc.shape[1], loc.shape[4]
+    _lib.check(lib.poet_msda_fwd(_req(value, "value").data_ptr(), geom.c_shapes, geom.c_starts, loc.data_ptr(),
+                                 attn.data_ptr(), out.data_ptr(), N, S, M, D, geom.L, P, Lq, dcode(value), _stream()),
+               "poet_msda_fwd")
+    return out
+
+
+def msda_bwd(value, geom: LevelGeom, loc, attn, grad_out, grad_value, grad_loc, grad_attn):
+    lib = _lib.load()
+    N, S, M, D = value.shape
+    Lq, P = loc.shape[1], loc.shape[4]
+    _lib.check(lib.poet_msda_bwd(_req(value, "value").data_ptr(), geom.c_shapes, geom.c_starts, loc.data_ptr(),
+                                 attn.data_ptr(), grad_out.data_ptr(), grad_value.data_ptr(), grad_loc.data_ptr(),
+                                 grad_attn.data_ptr(), N, S, M, D, geom.L, P, Lq, dcode(value), _stream()),
+               "poet_msda_bwd")
+
+
+def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, out, N, M, D, P, Lq):
+    lib = _lib.load()
+    _lib.check(lib.poet_msda_fused_fwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
+                                       offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, out.data_ptr(),
+                                       N, geom.S, M, D, geom.L, P, Lq, dcode(value), dcode(offattn), _stream()),
+               "poet_msda_fused_fwd")
+    return out
+
+
+def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value,
+                   grad_offattn, N, M, D, P, Lq):
+    lib = _lib.load()
+    _lib.check(lib.poet_msda_fused_bwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
+                                       offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, grad_out.data_ptr(),
+                                       grad_value.data_ptr(), grad_offattn.data_ptr(), N, geom.S, M, D, geom.L, P, Lq,
+                                       dcode(value), dcode(offattn), _stream()), "poet_msda_fused_bwd")
+
+
+# ---- norms -----------------------------------------------------------------------------------------
+def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0):
+    lib = _lib.load()
+    _lib.check(lib.poet_ln_fwd(_req(x, "x").data_ptr(), _ptr(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(z),
+                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y), _stream()), "poet_ln_fwd")
+    return y
+
+
+def ln_bwd(dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, rows, d, drop_p=0.0, seed=0):
+    lib = _lib.load()
+    _lib.check(lib.poet_ln_bwd(_req(dy, "dy").data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                               dz.data_ptr(), _ptr(dx), dgamma.data_ptr(), dbeta.data_ptr(), rows, d, drop_p,
+                               seed & 0xFFFFFFFF, dcode(z), dcode(dy), _stream()), "poet_ln_bwd")
+
+
+def groupnorm_fwd(x, gamma, beta, y, stats, N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps=1e-5):
+    lib = _lib.load()
+    _lib.check(lib.poet_groupnorm_fwd(_req(x, "x").data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                      N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps, dcode(x), dcode(y), _stream()),
+               "poet_groupnorm_fwd")
+
+
+def groupnorm_bwd(dy, x, stats, gamma, dx, dgamma, dbeta, N, HW, Cc, G, x_off, x_stride, y_off, y_stride):
+    lib = _lib.load()
+    _lib.check(lib.poet_groupnorm_bwd(_req(dy, "dy").data_ptr(), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                                      dgamma.data_ptr(), dbeta.data_ptr(), N, HW, Cc, G, x_off, x_stride, y_off, y_stride,
+                                      dcode(x), dcode(dy), _stream()), "poet_groupnorm_bwd")
+
+
+# ---- attention -------------------------------------------------------------------------------------
+def mha_fwd(q, k, v, ld, out, ld_out, N, Q, M, hd, drop_p=0.0, seed=0):
+    lib = _lib.load()
+    _lib.check(lib.poet_mha_fwd(_req(q, "q").data_ptr(), k.data_ptr(), v.data_ptr(), ld, out.data_ptr(), ld_out, N, Q, M, hd,
+                                drop_p, seed & 0xFFFFFFFF, _stream()), "poet_mha_fwd")
+
+
+def mha_bwd(q, k, v, ld, dout, ld_out, dq, dk, dv, ld_d, N, Q, M, hd, drop_p=0.0, seed=0):
+    lib = _lib.load()
+    _lib.check(lib.poet_mha_bwd(_req(q, "q").data_ptr(), k.data_ptr(), v.data_ptr(), ld, dout.data_ptr(), ld_out, dq.data_ptr(),
+                                dk.data_ptr(), dv.data_ptr(), ld_d, N, Q, M, hd, drop_p, seed & 0xFFFFFFFF, _stream()),
+               "poet_mha_bwd")
+
+
+# ---- encodings / geometry --------------------------------------------------------------------------
+_DIM_T = {}
+
+
+def sine_dim_t(F: int, device, temperature: float = 10000.0) -> torch.Tensor:
+    """Constant table temperature^(2*(i//2)/F), computed once on the host in fp32 exactly as
+    models/position_encoding.py:52-53 does, then kept on the device."""
+    key = (F, str(device), temperature)
+    if key not in _DIM_T:
+        i = torch.arange(F, dtype=torch.float32)
+        _DIM_T[key] = (temperature ** (2 * (i // 2) / F)).to(device)
+    return _DIM_T[key]
+
+
+def pos_sine(mask_u8, out, level_embed, N, H, W, F, tok_off, tok_stride):
+    lib = _lib.load()
+    dim_t = sine_dim_t(F, out.device)
+    _lib.check(lib.poet_pos_sine(_req(mask_u8, "mask").data_ptr(), out.data_ptr(), _ptr(level_embed), dim_t.data_ptr(), N, H, W,
+                                 F, tok_off, tok_stride, dcode(out), _stream()), "poet_pos_sine")
+
+
+def bbox_sine(boxes, out, n, F, valid=None, fill=-10.0):
+    lib = _lib.load()
+    _lib.check(lib.poet_bbox_sine(_req(boxes, "boxes").data_ptr(), _ptr(valid), out.data_ptr(), n, F, fill, _stream()),
+               "poet_bbox_sine")
+
+
+def dec_ref_points(ref, valid_ratios, out, N, Q, L):
+    lib = _lib.load()
+    _lib.check(lib.poet_dec_ref_points(_req(ref, "ref").data_ptr(), valid_ratios.data_ptr(), out.data_ptr(), N, Q, L, _stream()),
+               "poet_dec_ref_points")
+
+
+def valid_ratio(mask_u8, out, out_stride, N, H, W):
+    lib = _lib.load()
+    _lib.check(lib.poet_valid_ratio(_req(mask_u8, "mask").data_ptr(), out.data_ptr(), out_stride, N, H, W, _stream()),
+               "poet_valid_ratio")
+
+
+def mask_nearest(src, dst, N, H, W, Ho, Wo):
+    lib = _lib.load()
+    _lib.check(lib.poet_mask_nearest(_req(src, "mask").data_ptr(), dst.data_ptr(), N, H, W, Ho, Wo, _stream()), "poet_mask_nearest")
+
+
+def add_rowvec(x, vec, batch, batch_stride_rows, row0, rows, cols):
+    lib = _lib.load()
+    _lib.check(lib.poet_add_rowvec(_req(x, "x").data_ptr(), vec.data_ptr(), batch, batch_stride_rows, row0, rows, cols, dcode(x),
+                                   _stream()), "poet_add_rowvec")
+
+
+def enc_ref_points(valid_ratios, geom: LevelGeom, ref, N):
+    lib = _lib.load()
+    _lib.check(lib.poet_enc_ref_points(_req(valid_ratios, "valid_ratios").data_ptr(), geom.c_shapes, ref.data_ptr(), N, geom.L,
+                                       geom.S, _stream()), "poet_enc_ref_points")
+
+
+# ---- elementwise / layout --------------------------------------------------------------------------
+def add(a, b, out):
+    lib = _lib.load()
+    _lib.check(lib.poet_add(_req(a, "a").data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), dcode(a), _stream()), "poet_add")
+    return out
+
+
+def cast(src, dst):
+    lib = _lib.load()
+    _lib.check(lib.poet_cast(_req(src, "src").data_ptr(), dst.data_ptr(), src.numel(), dcode(src), dcode(dst), _stream()), "poet_cast")
+    return dst
+
+
+def colsum(x, ld, out, batch, rows_per_batch, cols, segs=None, nseg=1):
+    lib = _lib.load()
+    _lib.check(lib.poet_colsum(_req(x, "x").data_ptr(), ld, out.data_ptr(), batch, rows_per_batch, cols, segs, nseg, dcode(x),
+                               _stream()), "poet_colsum")
+
+
+def vgrad_to_rows(gv, vstrides, row_mask, out, N, S, M, D):
+    lib = _lib.load()
+    _lib.check(lib.poet_vgrad_to_rows(_req(gv, "gv").data_ptr(), *vstrides, _ptr(row_mask), out.data_ptr(), N, S, M, D, dcode(out),
+                                      _stream()), "poet_vgrad_to_rows")
+
+
+def nchw_to_tokens(src, dst, N, Cc, HW, tok_off, tok_stride):
+    lib = _lib.load()
+    _lib.check(lib.poet_nchw_to_tokens(_req(src, "src").data_ptr(), dst.data_ptr(), N, Cc, HW, tok_off, tok_stride, dcode(src),
+                                       dcode(dst), _stream()), "poet_nchw_to_tokens")
+
+
+def tokens_to_nchw(src, dst, N, Cc, HW, tok_off, tok_stride):
+    lib = _lib.load()
+    _lib.check(lib.poet_tokens_to_nchw(_req(src, "src").data_ptr(), dst.data_ptr(), N, Cc, HW, tok_off, tok_stride, dcode(src),
+                                       dcode(dst), _stream()), "poet_tokens_to_nchw")
+
+
+def im2col3x3s2(src, dst, N, Cc, H, W, Ho, Wo):
+    lib = _lib.load()
+    _lib.check(lib.poet_im2col3x3s2(_req(src, "src").data_ptr(), dst.data_ptr(), N, Cc, H, W, Ho, Wo, dcode(src), dcode(dst),
+                                    _stream()), "poet_im2col3x3s2")
+
+
+def pose_finish_fwd(rot_all, trans_all, cls, rot, trans, R, ncls):
+    lib = _lib.load()
+    _lib.check(lib.poet_pose_finish_fwd(_req(rot_all, "rot_all").data_ptr(), trans_all.data_ptr(), cls.data_ptr(), rot.data_ptr(),
+                                        trans.data_ptr(), R, ncls, _stream()), "poet_pose_finish_fwd")
+
+
+def pose_finish_bwd(rot_all, cls, drot, dtrans, drot_all, dtrans_all, R, ncls):
+    lib = _lib.load()
+    _lib.check(lib.poet_pose_finish_bwd(_req(rot_all, "rot_all").data_ptr(), cls.data_ptr(), drot.data_ptr(), dtrans.data_ptr(),
+                                        drot_all.data_ptr(), dtrans_all.data_ptr(), R, ncls, _stream()), "poet_pose_finish_bwd")
+
+
+def sqnorm(g, out):
+    lib = _lib.load()
+    _lib.check(lib.poet_sqnorm(_req(g, "g").data_ptr(), g.numel(), out.data_ptr(), _stream()), "poet_sqnorm")
+
+
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, sqnorm_buf=None, max_norm=0.0, grad_scale=1.0, p_bf16=None):
+    lib = _lib.load()
+    _lib.check(lib.poet_adamw(_req(p, "p").data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), n, lr, beta1, beta2,
+                              eps, wd, step, _ptr(sqnorm_buf), max_norm, grad_scale, _stream()), "poet_adamw")

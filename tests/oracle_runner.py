@@ -6,11 +6,17 @@ from oracle import poet_ref
 from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples
 
 
-def run_oracle(name, batch, pad, seed=1234, backward=True, train=False):
+INIT_SEED = 4321      # oracle/gen_golden.py: seed of the reference's own default initialisation
+
+
+def run_oracle(name, batch, pad, seed=1234, backward=True, train=False, default_init=False):
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
+    if default_init:
+        torch.manual_seed(INIT_SEED)
     model, crit = poet_ref.build_poet(cfg, feats)
-    formula_fill(model)
+    if not default_init:
+        formula_fill(model)
     model.train(train)
     samples = poet_ref.nested_from_list(make_samples(cfg, sizes))
     cap = {}

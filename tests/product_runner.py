@@ -1,0 +1,34 @@
+"""Shared helper (tests only): build the HIP-backed PoET on a named config with formula weights."""
+import torch
+
+import poet_amd
+from poet_amd.synthetic import SyntheticBackbone, image_mask
+from oracle.formula import CONFIGS, formula_fill, make_inputs
+
+
+def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False):
+    if not isinstance(precision, str):
+        precision = "fp32" if precision == torch.float32 else "bf16"
+    cfg = CONFIGS[name]
+    feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
+    fd = feat_dtype or torch.float32
+    gfeats = [f.cuda().to(fd) for f in feats]
+    bb = SyntheticBackbone(gfeats, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2)
+    p = cfg["dropout"] if dropout is None else dropout
+    if default_init:
+        torch.manual_seed(4321)          # oracle/gen_golden.py INIT_SEED: the reference's own init order
+    tr = poet_amd.DeformableTransformer(d_model=cfg["d_model"], nhead=cfg["nheads"], num_encoder_layers=cfg["enc_layers"],
+                                        num_decoder_layers=cfg["dec_layers"], dim_feedforward=cfg["d_ffn"], dropout=p,
+                                        activation="relu", return_intermediate_dec=True,
+                                        num_feature_levels=cfg["n_levels"], dec_n_points=cfg["n_points"],
+                                        enc_n_points=cfg["n_points"])
+    tr.set_precision(precision)
+    model = poet_amd.PoET(bb, tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
+                          n_classes=cfg["n_classes"], bbox_mode="gt", class_mode="specific", aux_loss=True)
+    if not default_init:
+        formula_fill(model)
+    model = model.cuda()
+    crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(), poet_amd.build_weight_dict(cfg["dec_layers"]))
+    samples = poet_amd.NestedTensor(None, image_mask(sizes, "cuda"))
+    gt = [{k: v.cuda() for k, v in t.items()} for t in targets]
+    return dict(cfg=cfg, model=model, crit=crit, samples=samples, targets=gt, cpu_targets=targets, feats=feats, sizes=sizes)

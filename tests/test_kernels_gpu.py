@@ -1,0 +1,459 @@
+"""Kernel-level parity: every C-ABI kernel vs the CPU oracle / an fp32 torch statement of the
+same arithmetic, on seeded inputs.  -m gpu only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import poet_ref, msda_explicit  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from poet_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+TOL = {torch.float32: dict(atol=2e-4, rtol=2e-4), torch.bfloat16: dict(atol=6e-2, rtol=3e-2)}
+
+
+def _close(a, b, dtype, scale=1.0, msg=""):
+    a = a.float().cpu()
+    b = b.float().cpu()
+    tol = TOL[dtype]
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol["atol"] * scale + tol["rtol"] * ref, f"{msg}: max err {err} (ref max {ref})"
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 768, 256), (640, 256, 1024), (70, 66, 256), (320, 132, 256)])
+def test_gemm_nt_bias_relu(ops, dtype, M, N, K):
+    x = _rand(M, K, seed=1).to(dtype)
+    w = _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=3)
+    out = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), out, act=1)
+    wq = w.to(dtype).float() if dtype == torch.bfloat16 else w
+    ref = F.relu(x.float() @ wq.t() + b)
+    _close(out, ref, dtype, msg=f"NT {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 768), (320, 256, 66), (640, 1024, 256)])
+def test_gemm_dx_gate_add(ops, dtype, M, N, K):
+    dy = _rand(M, K, seed=4).to(dtype)
+    w = _rand(K, N, seed=5, scale=1 / math.sqrt(K))          # [N_out=K, K_in=N]
+    gate = _rand(M, N, seed=6).to(dtype)
+    addend = _rand(M, N, seed=7).to(dtype)
+    out = dev(addend.clone())
+    ops.linear_dx(dev(dy), dev(w), out, rows=M, add_src=out, gate_ref=dev(gate), gate_scale=1.25)
+    wq = w.to(dtype).float() if dtype == torch.bfloat16 else w
+    ref = (dy.float() @ wq) * (gate.float() > 0) * 1.25 + addend.float()
+    _close(out, ref, dtype, msg="dX")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,nout,kin", [(5000, 256, 256), (3000, 768, 256), (320, 66, 256), (20, 256, 1024), (2048, 1024, 256)])
+def test_gemm_dw_splitk(ops, dtype, rows, nout, kin):
+    dy = _rand(rows, nout, seed=8).to(dtype)
+    x = _rand(rows, kin, seed=9).to(dtype)
+    dw = torch.zeros(nout, kin, device="cuda")
+    ops.linear_dw(dev(dy), dev(x), dw, rows=rows)
+    ref = dy.float().t() @ x.float()
+    _close(dw, ref, dtype, scale=math.sqrt(rows), msg="dW")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nchw_batched_and_headmajor(ops, dtype):
+    # 1x1 conv on NCHW features: A K-major per image
+    N, Cin, HW, d = 3, 48, 100, 64
+    feat = _rand(N, Cin, HW, seed=10).to(dtype)
+    w = _rand(d, Cin, seed=11, scale=0.2)
+    b = _rand(d, seed=12)
+    out = torch.empty(N, HW, d, dtype=dtype, device="cuda")
+    ops.gemm(dev(feat), dev(w), out, HW, d, Cin, lda=HW, ldb=Cin, ldc=d, a_kmajor=True, bias=dev(b), batch=N,
+             strideA=Cin * HW, strideC=HW * d)
+    wq = w.to(dtype).float() if dtype == torch.bfloat16 else w
+    ref = torch.einsum("nch,dc->nhd", feat.float(), wq) + b
+    _close(out, ref, dtype, msg="nchw conv1x1")
+    # weight grad of the same conv: A = dout K-major, B = feat k-contiguous, batch accumulates atomically
+    dout = _rand(N, HW, d, seed=13).to(dtype)
+    dw = torch.zeros(d, Cin, device="cuda")
+    ops.gemm(dev(dout), dev(feat), dw, d, Cin, HW, lda=d, ldb=HW, ldc=Cin, a_kmajor=True, b_kmajor=False, batch=N,
+             strideA=HW * d, strideB=Cin * HW, strideC=0, atomic=True)
+    ref = torch.einsum("nhd,nch->dc", dout.float(), feat.float())
+    _close(dw, ref, dtype, scale=10, msg="conv dW")
+    # head-major value epilogue with row mask
+    Nn, S, M, D = 2, 150, 4, 16
+    x = _rand(Nn * S, 64, seed=14).to(dtype)
+    wv = _rand(M * D, 64, seed=15, scale=0.15)
+    mask = (torch.arange(Nn * S) % 7 == 0).to(torch.uint8)
+    v = torch.empty(Nn, M, S, D, dtype=dtype, device="cuda")
+    ops.linear_fwd(dev(x), dev(wv), None, v, row_mask=dev(mask), head_major=(M, S, D))
+    wq = wv.to(dtype).float() if dtype == torch.bfloat16 else wv
+    ref = (x.float() @ wq.t()).masked_fill(mask.bool()[:, None], 0).view(Nn, S, M, D).permute(0, 2, 1, 3)
+    _close(v, ref, dtype, msg="head-major")
+
+
+def test_gemm_dropout_statistics(ops):
+    M, N, K = 512, 256, 64
+    x = torch.ones(M, K)
+    w = torch.ones(N, K) / K
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), None, out, drop_p=0.1, seed=123)
+    o = out.cpu()
+    kept = (o != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01
+    assert torch.allclose(o[o != 0], torch.full_like(o[o != 0], 1 / 0.9), atol=1e-5)
+    out2 = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), None, out2, drop_p=0.1, seed=123)
+    assert torch.equal(out, out2)
+
+
+# ---------------------------------------------------------------------------------------------- MSDA
+def _msda_inputs(seed, shapes, n=2, m=4, d=16, lq=37, p=4):
+    rng = np.random.default_rng(seed)
+    s = sum(h * w for h, w in shapes)
+    value = rng.standard_normal((n, s, m, d)).astype(np.float32)
+    loc = rng.uniform(-0.25, 1.25, (n, lq, m, len(shapes), p, 2)).astype(np.float32)
+    attn = torch.softmax(torch.from_numpy(rng.standard_normal((n, lq, m, len(shapes) * p)).astype(np.float32)), -1)
+    attn = attn.view(n, lq, m, len(shapes), p).numpy()
+    gout = rng.standard_normal((n, lq, m * d)).astype(np.float32)
+    return value, loc, attn, gout
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shapes,m,d", [([(6, 8), (3, 4)], 4, 16), ([(12, 16), (6, 8), (3, 4), (2, 2)], 8, 32), ([(5, 7)], 2, 64),
+                                        ([(9, 11), (5, 6), (3, 3)], 4, 16)])
+def test_msda_boundary(ops, dtype, shapes, m, d):
+    value, loc, attn, gout = _msda_inputs(3, shapes, m=m, d=d)
+    geom = ops.LevelGeom(shapes)
+    tv, tl, ta, tg = (torch.from_numpy(a).to(dtype) for a in (value, loc, attn, gout))
+    out = torch.empty(tg.shape, dtype=dtype, device="cuda")
+    ops.msda_fwd(dev(tv), geom, dev(tl), dev(ta), out)
+    ref = msda_explicit.msda_forward(tv.float().numpy(), shapes, tl.float().numpy(), ta.float().numpy())
+    _close(out, torch.from_numpy(ref), dtype, msg="msda fwd")
+    gv = torch.empty(tv.shape, dtype=torch.float32, device="cuda")
+    gl = torch.empty(tl.shape, dtype=dtype, device="cuda")
+    ga = torch.empty(ta.shape, dtype=dtype, device="cuda")
+    ops.msda_bwd(dev(tv), geom, dev(tl), dev(ta), dev(tg), gv, gl, ga)
+    rv, rl, ra = msda_explicit.msda_backward(tv.float().numpy(), shapes, tl.float().numpy(), ta.float().numpy(), tg.float().numpy())
+    _close(gv, torch.from_numpy(rv), dtype, scale=3, msg="msda dvalue")
+    _close(ga, torch.from_numpy(ra), dtype, scale=3, msg="msda dattn")
+    _close(gl, torch.from_numpy(rl), dtype, scale=30, msg="msda dloc")
+
+
+@pytest.mark.parametrize("vdt,qdt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("head_major", [False, True])
+def test_msda_fused(ops, vdt, qdt, head_major):
+    shapes = [(10, 12), (5, 6), (3, 3)]
+    n, m, d, lq, p = 2, 4, 16, 29, 4
+    L = len(shapes)
+    geom = ops.LevelGeom(shapes)
+    S = geom.S
+    rng = np.random.default_rng(5)
+    value = torch.from_numpy(rng.standard_normal((n, S, m, d)).astype(np.float32)).to(vdt)
+    mlp = m * L * p
+    oa = torch.from_numpy(np.concatenate([rng.standard_normal((n, lq, 2 * mlp)) * 2.0, rng.standard_normal((n, lq, mlp))], -1)
+                          .astype(np.float32)).to(qdt)
+    ref_pts = torch.from_numpy(rng.uniform(-0.1, 1.1, (n, lq, L, 2)).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((n, lq, m * d)).astype(np.float32)).to(qdt)
+    # oracle: compose softmax + loc arithmetic + grid_sample core with autograd
+    v32 = value.float().requires_grad_()
+    oa32 = oa.float().requires_grad_()
+    off = oa32[..., : 2 * mlp].view(n, lq, m, L, p, 2)
+    w = torch.softmax(oa32[..., 2 * mlp:].view(n, lq, m, L * p), -1).view(n, lq, m, L, p)
+    norm = torch.tensor([[wd, ht] for ht, wd in shapes], dtype=torch.float32)
+    loc = ref_pts[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    out_ref = poet_ref.msda_core(v32, shapes, loc, w)
+    (out_ref * gout.float()).sum().backward()
+
+    if head_major:
+        vdev = dev(value.permute(0, 2, 1, 3).contiguous())
+        vstr = (m * S * d, d, S * d)
+    else:
+        vdev = dev(value)
+        vstr = (S * m * d, m * d, d)
+    out = torch.empty(n, lq, m * d, dtype=qdt, device="cuda")
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, dev(ref_pts), lq * L * 2, out, n, m, d, p, lq)
+    _close(out, out_ref.detach(), vdt if vdt == torch.bfloat16 else qdt, msg="fused fwd")
+    gv = torch.zeros(vdev.shape, dtype=torch.float32, device="cuda")
+    goa = torch.empty_like(dev(oa))
+    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, dev(ref_pts), lq * L * 2, dev(gout), gv, goa, n, m, d, p, lq)
+    gv_ref = v32.grad.permute(0, 2, 1, 3) if head_major else v32.grad
+    worst = torch.bfloat16 if torch.bfloat16 in (vdt, qdt) else torch.float32
+    _close(gv, gv_ref, worst, scale=3, msg="fused dvalue")
+    _close(goa, oa32.grad, worst, scale=3, msg="fused d(off|logit)")
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [256, 64])
+def test_layernorm(ops, dtype, d):
+    rows = 203
+    x = _rand(rows, d, seed=20).to(dtype)
+    r = _rand(rows, d, seed=21).to(dtype)
+    gamma = 1 + 0.1 * _rand(d, seed=22)
+    beta = 0.1 * _rand(d, seed=23)
+    y = torch.empty(rows, d, dtype=dtype, device="cuda")
+    z = torch.empty_like(y)
+    mean = torch.empty(rows, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    ops.ln_fwd(dev(x), dev(r), dev(gamma), dev(beta), y, z, mean, rstd, rows, d)
+    zr = (x.float() + r.float()).requires_grad_()
+    g32, b32 = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    yr = F.layer_norm(zr, (d,), g32, b32, 1e-5)
+    _close(y, yr.detach(), dtype, msg="ln fwd")
+    dy = _rand(rows, d, seed=24).to(dtype)
+    yr.backward(dy.float())
+    dz = torch.empty_like(y)
+    dg = torch.zeros(d, device="cuda")
+    db = torch.zeros(d, device="cuda")
+    zsaved = z if dtype == torch.float32 else dev(zr.detach().to(dtype))
+    ops.ln_bwd(dev(dy), zsaved, mean, rstd, dev(gamma), dz, None, dg, db, rows, d)
+    _close(dz, zr.grad, dtype, msg="ln dz")
+    _close(dg, g32.grad, dtype, scale=10, msg="ln dgamma")
+    _close(db, b32.grad, dtype, scale=10, msg="ln dbeta")
+
+
+def test_layernorm_dropout_consistency(ops):
+    rows, d = 64, 256
+    x = torch.ones(rows, d)
+    r = torch.zeros(rows, d)
+    g, b = torch.ones(d), torch.zeros(d)
+    y = torch.empty(rows, d, device="cuda"); z = torch.empty_like(y)
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    ops.ln_fwd(dev(x), dev(r), dev(g), dev(b), y, z, mean, rstd, rows, d, drop_p=0.25, seed=7)
+    zc = z.cpu()
+    keep = zc != 0
+    assert abs(keep.float().mean().item() - 0.75) < 0.03
+    dy = torch.ones(rows, d)
+    dz = torch.empty_like(y); dx = torch.empty_like(y)
+    dg = torch.zeros(d, device="cuda"); db = torch.zeros(d, device="cuda")
+    ops.ln_bwd(dev(dy), z, mean, rstd, dev(g), dz, dx, dg, db, rows, d, drop_p=0.25, seed=7)
+    dzc, dxc = dz.cpu(), dx.cpu()
+    assert torch.allclose(dxc[keep], dzc[keep] / 0.75, atol=1e-5)
+    assert (dxc[~keep] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_groupnorm(ops, dtype):
+    N, HW, C, G, S, off = 2, 50, 64, 32, 80, 20
+    x = _rand(N, HW, C, seed=30).to(dtype)
+    gamma = 1 + 0.1 * _rand(C, seed=31)
+    beta = 0.1 * _rand(C, seed=32)
+    y = torch.zeros(N, S, C, dtype=dtype, device="cuda")
+    stats = torch.empty(N, G, 2, device="cuda")
+    ops.groupnorm_fwd(dev(x), dev(gamma), dev(beta), y, stats, N, HW, C, G, 0, HW, off, S)
+    xr = x.float().permute(0, 2, 1).contiguous().requires_grad_()       # (N,C,HW)
+    g32, b32 = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    yr = F.group_norm(xr, G, g32, b32, 1e-5)
+    _close(y[:, off:off + HW], yr.detach().permute(0, 2, 1), dtype, msg="gn fwd")
+    dy = torch.zeros(N, S, C)
+    dy[:, off:off + HW] = _rand(N, HW, C, seed=33)
+    dy = dy.to(dtype)
+    yr.backward(dy[:, off:off + HW].float().permute(0, 2, 1))
+    dx = torch.empty(N, HW, C, dtype=dtype, device="cuda")
+    dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+    ops.groupnorm_bwd(dev(dy), dev(x), stats, dev(gamma), dx, dg, db, N, HW, C, G, 0, HW, off, S)
+    _close(dx, xr.grad.permute(0, 2, 1), dtype, msg="gn dx")
+    _close(dg, g32.grad, dtype, scale=5, msg="gn dgamma")
+    _close(db, b32.grad, dtype, scale=5, msg="gn dbeta")
+
+
+# ---------------------------------------------------------------------------------------------- MHA
+@pytest.mark.parametrize("Q,M,hd", [(20, 16, 16), (10, 4, 64), (6, 4, 16), (50, 8, 32)])
+def test_mha(ops, Q, M, hd):
+    N, d = 3, M * hd
+    packed = _rand(N * Q, 3 * d, seed=40)
+    pk = dev(packed)
+    out = torch.empty(N * Q, d, device="cuda")
+    ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd)
+    p32 = packed.clone().requires_grad_()
+    q, k, v = (p32[:, i * d:(i + 1) * d].view(N, Q, M, hd).transpose(1, 2) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1)
+    ref = (att @ v).transpose(1, 2).reshape(N * Q, d)
+    _close(out, ref.detach(), torch.float32, msg="mha fwd")
+    dout = _rand(N * Q, d, seed=41)
+    ref.backward(dout)
+    dpk = torch.empty_like(pk)
+    ops.mha_bwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, dev(dout), d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, hd)
+    _close(dpk, p32.grad, torch.float32, msg="mha bwd")
+
+
+# ---------------------------------------------------------------------------------------------- encodings & misc
+def test_pos_sine_and_valid_ratio(ops, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "units.npz"))
+    mask = torch.from_numpy(g["pe_mask"])
+    N, H, W = mask.shape
+    out = torch.empty(N, H * W, 256, device="cuda")
+    ops.pos_sine(dev(mask.to(torch.uint8)), out, None, N, H, W, 128, 0, H * W)
+    ref = torch.from_numpy(g["pe_out"]).flatten(2).transpose(1, 2)      # reference's own output
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    vr = torch.empty(N, 1, 2, device="cuda")
+    ops.valid_ratio(dev(mask.to(torch.uint8)), vr, 2, N, H, W)
+    ref_vr = poet_ref.DeformableTransformer.valid_ratio(mask)
+    assert torch.allclose(vr.cpu()[:, 0], ref_vr, atol=1e-7)
+
+
+def test_bbox_sine_full_range(ops, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "units.npz"))
+    boxes = torch.from_numpy(g["bbox_in"])
+    n = boxes.shape[0]
+    out = torch.empty(n, 256, device="cuda")
+    ops.bbox_sine(dev(boxes), out, n, 32)
+    err = (out.cpu() - torch.from_numpy(g["bbox_out"])).abs().max().item()
+    assert err < 5e-6, err                                               # args reach 2^31: needs exact range reduction
+    valid = torch.ones(n, dtype=torch.uint8); valid[-1] = 0
+    ops.bbox_sine(dev(boxes), out, n, 32, valid=dev(valid))
+    assert (out.cpu()[-1] == -10).all()
+
+
+def test_ref_points_and_misc(ops):
+    shapes = [(6, 8), (3, 4)]
+    geom = ops.LevelGeom(shapes)
+    vr = torch.tensor([[[1.0, 1.0], [1.0, 1.0]], [[0.75, 0.5], [0.75, 0.6667]]])
+    ref = torch.empty(2, geom.S, 2, 2, device="cuda")
+    ops.enc_ref_points(dev(vr), geom, ref, 2)
+    want = poet_ref.Encoder.reference_grid(torch.tensor(shapes), vr)
+    assert torch.allclose(ref.cpu(), want, atol=1e-6)
+    r2 = torch.rand(2, 5, 2)
+    o = torch.empty(2, 5, 2, 2, device="cuda")
+    ops.dec_ref_points(dev(r2), dev(vr), o, 2, 5, 2)
+    assert torch.allclose(o.cpu(), r2[:, :, None] * vr[:, None], atol=1e-7)
+    # mask nearest == F.interpolate
+    m = (torch.rand(2, 96, 128) > 0.5)
+    for size in [(12, 16), (3, 4), (8, 10)]:
+        dst = torch.empty(2, *size, dtype=torch.uint8, device="cuda")
+        ops.mask_nearest(dev(m.to(torch.uint8)), dst, 2, 96, 128, *size)
+        want = F.interpolate(m[None].float(), size=size).to(torch.bool)[0]
+        assert torch.equal(dst.cpu().bool(), want)
+    # transposes, im2col, add, cast, colsum, rowvec
+    x = _rand(2, 24, 7, 9, seed=50)
+    tok = torch.zeros(2, 100, 24, device="cuda")
+    ops.nchw_to_tokens(dev(x), tok, 2, 24, 63, 10, 100)
+    assert torch.allclose(tok.cpu()[:, 10:73], x.flatten(2).transpose(1, 2))
+    back = torch.empty(2, 24, 63, device="cuda")
+    ops.tokens_to_nchw(tok, back, 2, 24, 63, 10, 100)
+    assert torch.allclose(back.cpu(), x.flatten(2))
+    col = torch.empty(2 * 4 * 5, 24 * 9, device="cuda")
+    ops.im2col3x3s2(dev(x), col, 2, 24, 7, 9, 4, 5)
+    want = F.unfold(x, 3, padding=1, stride=2).transpose(1, 2).reshape(2 * 20, 24 * 9)
+    assert torch.allclose(col.cpu(), want)
+    a, b = _rand(1000, seed=51), _rand(1000, seed=52)
+    o = torch.empty(1000, device="cuda")
+    ops.add(dev(a), dev(b), o)
+    assert torch.allclose(o.cpu(), a + b)
+    ob = torch.empty(1000, dtype=torch.bfloat16, device="cuda")
+    ops.cast(dev(a), ob)
+    assert torch.equal(ob.cpu(), a.to(torch.bfloat16))
+    xs = _rand(3, 70, 40, seed=53)
+    cs = torch.zeros(2, 40, device="cuda")
+    ops.colsum(dev(xs), 40, cs, 3, 70, 40, ops._i64arr([0, 48, 70]), 2)
+    want = torch.stack([xs[:, :48].sum((0, 1)), xs[:, 48:].sum((0, 1))])
+    assert torch.allclose(cs.cpu(), want, atol=1e-4)
+    t = dev(xs.clone())
+    vecr = _rand(40, seed=54)
+    ops.add_rowvec(t, dev(vecr), 3, 70, 48, 22, 40)
+    w2 = xs.clone(); w2[:, 48:] += vecr
+    assert torch.allclose(t.cpu(), w2)
+
+
+def test_pose_finish(ops, golden_dir):
+    R, ncls = 40, 6
+    rot_all = _rand(R, ncls * 6, seed=60)
+    trans_all = _rand(R, ncls * 3, seed=61)
+    cls = torch.randint(-1, ncls, (R,), generator=torch.Generator().manual_seed(62), dtype=torch.int32)
+    rot = torch.empty(R, 3, 3, device="cuda"); tr = torch.empty(R, 3, device="cuda")
+    ops.pose_finish_fwd(dev(rot_all), dev(trans_all), dev(cls), rot, tr, R, ncls)
+    ra = rot_all.clone().requires_grad_(); ta = trans_all.clone().requires_grad_()
+    idx = torch.where(cls > 0, cls, 0).long()
+    r6 = ra.view(R, ncls, 6)[torch.arange(R), idx]
+    t3 = ta.view(R, ncls, 3)[torch.arange(R), idx]
+    rref = poet_ref.rotation_6d_to_matrix(r6[None])[0]
+    assert torch.allclose(rot.cpu(), rref.detach(), atol=1e-5)
+    assert torch.allclose(tr.cpu(), t3.detach())
+    drot = _rand(R, 3, 3, seed=63); dtr = _rand(R, 3, seed=64)
+    ((rref * drot).sum() + (t3 * dtr).sum()).backward()
+    dra = torch.empty(R, ncls * 6, device="cuda"); dta = torch.empty(R, ncls * 3, device="cuda")
+    ops.pose_finish_bwd(dev(rot_all), dev(cls), dev(drot), dev(dtr), dra, dta, R, ncls)
+    assert torch.allclose(dra.cpu(), ra.grad, atol=2e-4)
+    assert torch.allclose(dta.cpu(), ta.grad, atol=1e-6)
+
+
+def test_adamw_and_clip(ops):
+    n = 5000
+    p0 = _rand(n, seed=70); g = _rand(n, seed=71) * 0.01
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=2e-4, weight_decay=1e-4)
+    p = dev(p0.clone()); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gs = g * step
+        ref_p.grad = gs.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 0.1)
+        opt.step()
+        sq = torch.zeros(1, device="cuda")
+        ops.sqnorm(dev(gs), sq)
+        ops.adamw(p, dev(gs), m, v, n, 2e-4, 0.9, 0.999, 1e-8, 1e-4, step, sqnorm_buf=sq, max_norm=0.1)
+    assert torch.allclose(p.cpu(), ref_p.detach(), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- mixed precision
+def test_gemm_mixed_dtypes(ops):
+    """fp32 residual stream in, bf16 branch out (and back): the 'bf16' training policy's operand mixes."""
+    M, N, K = 700, 256, 256
+    x32 = _rand(M, K, seed=80)
+    w = _rand(N, K, seed=81, scale=1 / math.sqrt(K))
+    out_b = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.linear_fwd(dev(x32), dev(w), None, out_b)                              # (f32, f32) -> bf16, bf16 MFMA
+    ref = x32.bfloat16().float() @ w.bfloat16().float().t()
+    _close(out_b, ref, torch.bfloat16, msg="f32->bf16")
+    dy = _rand(M, N, seed=82).bfloat16()
+    acc = _rand(M, K, seed=83)
+    out32 = dev(acc.clone())
+    ops.linear_dx(dev(dy), dev(w), out32, rows=M, add_src=out32)               # bf16 x f32 -> f32 (+= stream grad)
+    ref = dy.float() @ w.bfloat16().float() + acc
+    _close(out32, ref, torch.bfloat16, msg="bf16->f32 accumulate")
+    dw = torch.zeros(N, K, device="cuda")
+    ops.linear_dw(dev(dy), dev(x32), dw, rows=M)                               # bf16^T x f32 -> f32 atomics
+    ref = dy.float().t() @ x32.bfloat16().float()
+    _close(dw, ref, torch.bfloat16, scale=math.sqrt(M), msg="mixed dW")
+
+
+def test_layernorm_mixed(ops):
+    rows, d = 130, 256
+    x = _rand(rows, d, seed=90).bfloat16()
+    r = _rand(rows, d, seed=91)
+    gamma = 1 + 0.1 * _rand(d, seed=92); beta = 0.1 * _rand(d, seed=93)
+    y = torch.empty(rows, d, device="cuda"); z = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    ops.ln_fwd(dev(x), dev(r), dev(gamma), dev(beta), y, z, mean, rstd, rows, d)
+    zr = (x.float() + r).requires_grad_()
+    yr = F.layer_norm(zr, (d,), gamma, beta, 1e-5)
+    assert y.dtype == torch.float32 and (y.cpu() - yr.detach()).abs().max().item() < 1e-5
+    dy = _rand(rows, d, seed=94)
+    yr.backward(dy)
+    dz = torch.empty(rows, d, device="cuda"); dx = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+    dg = torch.zeros(d, device="cuda"); db = torch.zeros(d, device="cuda")
+    ops.ln_bwd(dev(dy), z, mean, rstd, dev(gamma), dz, dx, dg, db, rows, d)
+    _close(dz, zr.grad, torch.bfloat16, msg="mixed ln dz")
+    _close(dx, zr.grad, torch.bfloat16, msg="mixed ln dx")

@@ -58,11 +58,15 @@ def test_msda_core_vs_hf(golden_dir):
     np.testing.assert_allclose(da, g["d_attn"], atol=1e-5)
 
 
-@pytest.mark.parametrize("name,batch,pad,full", [("tiny", 2, True, True), ("tiny", 2, False, True),
-                                                 ("cfg0", 2, False, True), ("cfg0", 2, True, False)])
-def test_poet_vs_reference(golden_dir, name, batch, pad, full):
-    g = _load(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}.npz")
-    r = run_oracle(name, batch, pad)
+@pytest.mark.parametrize("name,batch,pad,full,init", [("tiny", 2, True, True, False), ("tiny", 2, False, True, False),
+                                                      ("cfg0", 2, False, True, False), ("cfg0", 2, True, False, False),
+                                                      ("tiny", 2, True, True, True)])
+def test_poet_vs_reference(golden_dir, name, batch, pad, full, init):
+    g = _load(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz")
+    r = run_oracle(name, batch, pad, default_init=init)
+    if init:        # the oracle consumed the RNG exactly like the reference's constructors did
+        for (n, p), ref_sum in zip(r["model"].named_parameters(), g["param_checksums"]):
+            np.testing.assert_allclose(checksum(p), ref_sum, atol=0, rtol=0, err_msg=n)
     np.testing.assert_allclose(r["out"]["pred_translation"].detach().numpy(), g["pred_translation"], atol=ATOL)
     np.testing.assert_allclose(r["out"]["pred_rotation"].detach().numpy(), g["pred_rotation"], atol=ATOL)
     if g["aux_translation"].size:
