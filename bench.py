@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""Benchmark of the PoET encoder-decoder hot path on MI355X: images/s, forward + loss + backward +
+clip + AdamW (the loop body of the reference's engine.py:55-81), YCB-V config (BASELINE.json
+configs[1]: 5 enc / 5 dec / 16 heads, 256-d, 4 levels, 640x480, 20 queries, bs=16 per GPU, bf16),
+synthetic backbone features of that shape and random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
+(one process per GPU, RCCL all-reduce of the flat gradient arena overlapped with backward).
+Rank 0 prints ONE JSON line (see README / DESIGN.md section "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# BASELINE.json configs -> geometry; kept here so the product never imports oracle/
+CONFIGS = {
+    "cfg0": dict(d_model=256, nheads=4, enc_layers=1, dec_layers=1, d_ffn=1024, n_levels=2, n_points=4, num_queries=10,
+                 n_classes=21, dropout=0.1, strides=[8, 16], num_channels=[256, 256], image_hw=(128, 128),
+                 level_hw=[(16, 16), (8, 8)], batch=2),
+    "ycbv": dict(d_model=256, nheads=16, enc_layers=5, dec_layers=5, d_ffn=1024, n_levels=4, n_points=4, num_queries=20,
+                 n_classes=21, dropout=0.1, strides=[8, 16, 32], num_channels=[256, 256, 256], image_hw=(480, 640),
+                 level_hw=[(60, 80), (30, 40), (15, 20), (8, 10)], batch=16),
+    "lmo": dict(d_model=256, nheads=16, enc_layers=5, dec_layers=5, d_ffn=1024, n_levels=4, n_points=4, num_queries=10,
+                n_classes=8, dropout=0.1, strides=[16, 32, 64], num_channels=[256, 256, 256], image_hw=(480, 640),
+                level_hw=[(30, 40), (15, 20), (8, 10), (4, 5)], batch=32),
+    "hires": dict(d_model=256, nheads=16, enc_layers=6, dec_layers=6, d_ffn=1024, n_levels=4, n_points=4, num_queries=50,
+                  n_classes=21, dropout=0.1, strides=[8, 16, 32], num_channels=[256, 256, 256], image_hw=(960, 1280),
+                  level_hw=[(120, 160), (60, 80), (30, 40), (15, 20)], batch=8),
+}
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak
+
+
+def synth_batch(cfg, batch, seed, device):
+    """N(0,1) feature maps per level, all-False masks, 3..Q objects per image."""
+    rng = np.random.default_rng(seed)
+    nb = len(cfg["strides"])
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    feats = [torch.randn((batch, cfg["num_channels"][l], *cfg["level_hw"][l]), generator=g).to(device) for l in range(nb)]
+    q, c = cfg["num_queries"], cfg["n_classes"]
+    targets = []
+    for _ in range(batch):
+        k = int(rng.integers(3, q + 1))
+        boxes = np.concatenate([rng.uniform(0.2, 0.8, (k, 2)), rng.uniform(0.05, 0.25, (k, 2))], 1).astype(np.float32)
+        labels = rng.integers(1, c + 1, (k,)).astype(np.int64)
+        pos = (rng.standard_normal((k, 3)) * np.array([0.2, 0.2, 0.3]) + np.array([0.0, 0.0, 1.0])).astype(np.float32)
+        rots = []
+        for _ in range(k):
+            qm, r = np.linalg.qr(rng.standard_normal((3, 3)))
+            qm = qm * np.sign(np.diag(r))
+            if np.linalg.det(qm) < 0:
+                qm[:, 2] = -qm[:, 2]
+            rots.append(qm)
+        targets.append({"boxes": torch.from_numpy(boxes), "labels": torch.from_numpy(labels),          # host side (query assembly, matcher)
+                        "relative_position": torch.from_numpy(pos).to(device),
+                        "relative_rotation": torch.from_numpy(np.stack(rots).astype(np.float32)).to(device)})
+    return feats, targets
+
+
+def gemm_flops_per_image(cfg):
+    """Algorithmic GEMM flops, forward; fwd+bwd = 3x."""
+    d, f, M, L, P = cfg["d_model"], cfg["d_ffn"], cfg["nheads"], cfg["n_levels"], cfg["n_points"]
+    S = sum(h * w for h, w in cfg["level_hw"])
+    Q, C1 = cfg["num_queries"], cfg["n_classes"] + 1
+    mlp = M * L * P
+    enc = cfg["enc_layers"] * 2 * S * d * (3 * mlp + 2 * d + 2 * f)
+    dec = cfg["dec_layers"] * (2 * S * d * d + 2 * Q * d * (3 * d + 3 * mlp + 2 * d + 2 * f) + 4 * Q * Q * d)
+    heads = cfg["dec_layers"] * 2 * Q * (4 * d * d + 9 * d * C1)
+    nb = len(cfg["strides"])
+    proj = 2 * d * sum(cfg["level_hw"][l][0] * cfg["level_hw"][l][1] * cfg["num_channels"][l] for l in range(nb))
+    if L > nb:
+        h, w = cfg["level_hw"][nb]
+        proj += 2 * h * w * 9 * cfg["num_channels"][-1] * d
+    return enc + dec + heads + proj
+
+
+def build_model(cfg, feats, precision, device):
+    import poet_amd
+    from poet_amd.synthetic import SyntheticBackbone
+    bb = SyntheticBackbone(feats, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2)
+    tr = poet_amd.DeformableTransformer(d_model=cfg["d_model"], nhead=cfg["nheads"], num_encoder_layers=cfg["enc_layers"],
+                                        num_decoder_layers=cfg["dec_layers"], dim_feedforward=cfg["d_ffn"],
+                                        dropout=cfg["dropout"], activation="relu", return_intermediate_dec=True,
+                                        num_feature_levels=cfg["n_levels"], dec_n_points=cfg["n_points"],
+                                        enc_n_points=cfg["n_points"])
+    tr.set_precision(precision)
+    model = poet_amd.PoET(bb, tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
+                          n_classes=cfg["n_classes"], bbox_mode="gt", class_mode="specific", aux_loss=True).to(device)
+    crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(), poet_amd.build_weight_dict(cfg["dec_layers"]))
+    return model, crit
+
+
+def cpu_baseline(cfg, max_seconds=45.0):
+    """The oracle (CPU restatement of the reference's PyTorch path, grid_sample MSDA) timed on the host cores
+    of this box on a BOUNDED sample: YCB-V geometry at bs=1, 1 warm-up + up to 2 timed optimisation steps."""
+    from oracle import poet_ref
+    cores = min(os.cpu_count() or 8, 32)
+    torch.set_num_threads(cores)
+    feats, targets = synth_batch(cfg, 1, 99, "cpu")
+    torch.manual_seed(0)
+    model, crit = poet_ref.build_poet(cfg, feats)
+    model.train()
+    opt = torch.optim.AdamW(poet_ref.param_groups(model), lr=2e-4, weight_decay=1e-4)
+    ih, iw = cfg["image_hw"]
+    samples = poet_ref.nested_from_list([torch.zeros(3, ih, iw)])
+    times = []
+    t_begin = time.perf_counter()
+    for it in range(3):
+        t0 = time.perf_counter()
+        out, nb = model(samples, targets)
+        ls = crit(out, targets, nb)
+        tot = sum(ls[k] * crit.weight_dict[k] for k in ls)
+        opt.zero_grad()
+        tot.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+        if time.perf_counter() - t_begin > max_seconds:
+            if not times:
+                times.append(dt)
+            break
+    sec = float(np.mean(times))
+    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"YCB-V geometry, bs=1, {len(times)} timed fwd+loss+bwd+clip+AdamW step(s) of the CPU oracle "
+                      f"({sec:.1f} s/step, torch {torch.__version__} CPU, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="ycbv", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_pure", "fp32"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)      # 'nccl' == RCCL on ROCm
+
+    import poet_amd
+    from poet_amd import ops
+    cfg = CONFIGS[args.config]
+    batch = args.batch or cfg["batch"]
+    torch.manual_seed(1234)                                      # identical init on every rank (then broadcast anyway)
+    poet_amd.manual_seed(1234 + rank)
+    feats, targets = synth_batch(cfg, batch, 1234 + rank, device)
+    model, crit = build_model(cfg, feats, args.precision, device)
+    model.train()
+    trainer = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+    ih, iw = cfg["image_hw"]
+    samples = poet_amd.NestedTensor(None, torch.zeros((batch, ih, iw), dtype=torch.bool, device=device))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(samples, targets)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total, loss_dict = trainer.step(samples, targets)
+        poet_amd.reduce_dict(loss_dict)                          # engine.py:61 (logging all-reduce), no .item()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, prof_steps = None, 3
+    if not args.no_roofline and rank == 0 and world == 1:
+        # per-kernel HIP-event timing on the launch stream, over 3 EXTRA steps of the same workload right after the
+        # timed region (kept out of it so the events do not perturb `value`)
+        ops.PROFILE.start()
+        for _ in range(prof_steps):
+            trainer.step(samples, targets)
+        prof = ops.PROFILE.stop()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(total)
+    if not np.isfinite(loss_val):
+        raise SystemExit(f"non-finite loss {loss_val}")
+
+    if rank == 0:
+        ms = 1000.0 * elapsed / args.steps
+        value = world * batch * args.steps / elapsed
+        fl = 3 * gemm_flops_per_image(cfg) * batch
+        out = {
+            "metric": "images/sec fwd+bwd (loss + backward + clip + AdamW), PoET encoder-decoder",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"bf16": "bf16", "bf16_pure": "bf16", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['enc_layers']} enc / {cfg['dec_layers']} dec / {cfg['nheads']} heads, "
+                                   f"{cfg['d_model']}-d, {cfg['n_levels']} levels, {iw}x{ih}, {cfg['num_queries']} queries, "
+                                   f"bs={batch} per GPU, dropout {cfg['dropout']}, AdamW + clip 0.1, random init",
+                       "global_batch": world * batch, "tokens_per_image": sum(h * w for h, w in cfg["level_hw"]),
+                       "parallelism": f"dp{world}", "precision_policy": args.precision,
+                       "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
+                       "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4)},
+        }
+        if prof is not None:
+            out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)
+            out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
+                                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,7 +144,8 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
  * ---------------------------------------------------------------------------------------------- */
 int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                 void* y, void* z_out, float* mean, float* rstd,
-                int64_t rows, int d, float eps, float drop_p, uint32_t seed, int dtype_x, int dtype_r, void* stream);
+                int64_t rows, int d, float eps, float drop_p, uint32_t seed, int dtype_x, int dtype_r,
+                void* y_bf16 /* optional: bf16 copy of y, the MFMA operand of the next GEMM */, void* stream);
 int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                 void* dz_out, void* dx_out, float* dgamma, float* dbeta,
                 int64_t rows, int d, float drop_p, uint32_t seed, int dtype_x, int dtype_r, void* stream);
@@ -194,7 +195,7 @@ int poet_mask_nearest(const uint8_t* src, uint8_t* dst, int N, int H, int W, int
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / layout helpers.
  * ---------------------------------------------------------------------------------------------- */
-int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype_a, int dtype_b, int dtype_out, void* stream);
 /* x[row, :] += vec[:] for rows [row0, row0+rows) of every batch item (batch stride in rows). */
 int poet_add_rowvec(void* x, const float* vec, int batch, int64_t batch_stride_rows, int64_t row0, int64_t rows,
                     int cols, int dtype, void* stream);

@@ -52,6 +52,16 @@ class GradSink:
         return self.ret[i]
 
 
+def Wb(W, like):
+    """bf16 shadow of a weight (kept up to date by the AdamW kernel, see engine.ParamArena) when the other GEMM operand
+    is stored in bf16 -- then both MFMA operands stream in at 2 B/element; otherwise the fp32 master itself."""
+    if like.dtype == torch.bfloat16:
+        sh = getattr(W, "_bf16", None)
+        if sh is not None:
+            return sh
+    return W
+
+
 def vstrides(M, S, D):
     """element strides (n, s, m) of a head-major (N,M,S,D) value map"""
     return (M * S * D, D, S * D)
@@ -60,7 +70,7 @@ def vstrides(M, S, D):
 # ---- (a) value projection ------------------------------------------------------------------------
 def value_proj_fwd(inp2d, W, b, row_mask, N, S, M, D, act=None):
     V = empty((N, M, S, D), act or inp2d.dtype, inp2d)
-    ops.linear_fwd(inp2d, W, b, V, row_mask=row_mask, head_major=(M, S, D))
+    ops.linear_fwd(inp2d, Wb(W, inp2d), b, V, row_mask=row_mask, head_major=(M, S, D))
     return V
 
 
@@ -71,7 +81,7 @@ def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate,
     ops.linear_dw(dVr, inp2d, gW, rows=rows)
     ops.colsum(dVr, d, gb, 1, rows, d)
     if dinp is not None:
-        ops.linear_dx(dVr, W, dinp, rows=rows, add_src=dinp if accumulate else None)
+        ops.linear_dx(dVr, Wb(W, dVr), dinp, rows=rows, add_src=dinp if accumulate else None)
 
 
 # ---- (b) offsets/logits projection + fused deformable sampling ----------------------------------
@@ -79,8 +89,8 @@ def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
     OA = empty((rows, ldq), act or q2d.dtype, q2d)
-    ops.linear_fwd(q2d, so_w, so_b, OA, ldc=ldq)
-    ops.linear_fwd(q2d, aw_w, aw_b, OA[:, 2 * mlp:], ldc=ldq)
+    ops.linear_fwd(q2d, Wb(so_w, q2d), so_b, OA, ldc=ldq)
+    ops.linear_fwd(q2d, Wb(aw_w, q2d), aw_b, OA[:, 2 * mlp:], ldc=ldq)
     out = empty((rows, M * D), OA.dtype, q2d)
     ops.msda_fused_fwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq)
     return out, OA
@@ -102,21 +112,24 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
         ops.colsum(dOA, ldq, g_so_b, 1, rows, 2 * mlp)
         ops.colsum(dOA[:, 2 * mlp:], ldq, g_aw_b, 1, rows, mlp)
     if dq is not None:
-        ops.linear_dx(dOA, so_w, dq, rows=rows, ldy=ldq, add_src=dq if dq_accumulate else None)
-        ops.linear_dx(dOA[:, 2 * mlp:], aw_w, dq, rows=rows, ldy=ldq, add_src=dq)
+        ops.linear_dx(dOA, Wb(so_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq if dq_accumulate else None)
+        ops.linear_dx(dOA[:, 2 * mlp:], Wb(aw_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq)
 
 
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
 def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed):
+    """Returns (y, y16, saved): y in the residual-stream dtype; y16 = bf16 copy for the next GEMM when the stream is
+    fp32 but the branch is bf16 (else y itself)."""
     rows, d = res.shape[0], W.shape[0]
     tmp = empty((rows, d), x_in.dtype, res)          # branch dtype
-    ops.linear_fwd(x_in, W, b, tmp)
+    ops.linear_fwd(x_in, Wb(W, x_in), b, tmp)
     y = torch.empty_like(res)                        # residual-stream dtype
     z = torch.empty_like(tmp)
     mean = empty((rows,), torch.float32, res)
     rstd = empty((rows,), torch.float32, res)
-    ops.ln_fwd(tmp, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, p, seed)
-    return y, (z, mean, rstd)
+    y16 = torch.empty_like(tmp) if (tmp.dtype == torch.bfloat16 and res.dtype == torch.float32) else None
+    ops.ln_fwd(tmp, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, p, seed, y16=y16)
+    return y, (y16 if y16 is not None else y), (z, mean, rstd)
 
 
 def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_ref=None, gate_scale=1.0):
@@ -129,17 +142,18 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
     ops.linear_dw(dxo, x_in, gW, rows=rows)
     ops.colsum(dxo, d, gb, 1, rows, d)
     dx_in = empty((rows, W.shape[1]), x_in.dtype, x_in)
-    ops.linear_dx(dxo, W, dx_in, rows=rows, gate_ref=gate_ref, gate_scale=gate_scale)
+    ops.linear_dx(dxo, Wb(W, dxo), dx_in, rows=rows, gate_ref=gate_ref, gate_scale=gate_scale)
     return dz, dx_in
 
 
 # ---- (d) FFN block -------------------------------------------------------------------------------
-def ffn_fwd(x, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None):
+def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None):
+    """x: residual stream; x16: the GEMM operand copy of it (== x in the pure modes)."""
     rows = x.shape[0]
     Hd = empty((rows, W1.shape[0]), act or x.dtype, x)
-    ops.linear_fwd(x, W1, b1, Hd, act=1, drop_p=p_h, seed=seed_h)
-    y, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o)
-    return y, (Hd, ln_saved)
+    ops.linear_fwd(x16, Wb(W1, x16), b1, Hd, act=1, drop_p=p_h, seed=seed_h)
+    y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o)
+    return y, y16, (Hd, ln_saved)
 
 
 def ffn_bwd(dy, x, W1, W2, gamma, saved, p_h, p_o, seed_o, gW1, gb1, gW2, gb2, ggamma, gbeta):
@@ -149,7 +163,7 @@ def ffn_bwd(dy, x, W1, W2, gamma, saved, p_h, p_o, seed_o, gW1, gb1, gW2, gb2, g
                          gate_ref=Hd, gate_scale=1.0 / (1.0 - p_h) if p_h > 0 else 1.0)
     ops.linear_dw(dh, x, gW1, rows=rows)
     ops.colsum(dh, f, gb1, 1, rows, f)
-    ops.linear_dx(dh, W1, dz, rows=rows, add_src=dz)
+    ops.linear_dx(dh, Wb(W1, dh), dz, rows=rows, add_src=dz)
     return dz
 
 
@@ -162,25 +176,26 @@ ENC_PARAMS = ("self_attn.sampling_offsets.weight", "self_attn.sampling_offsets.b
               "linear2.weight", "linear2.bias", "norm2.weight", "norm2.bias")
 
 
-def enc_layer_fwd(src, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None):
-    """src,pos (N*S,d) T.  P_: dict name->param.  Returns (out, saved)."""
+def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None):
+    """src (N*S,d): residual stream; src16: its GEMM-operand copy (== src in the pure modes); pos (N*S,d).
+    Returns (out, out16, saved)."""
     S, d = geom.S, src.shape[1]
     D = d // M
     pd = p if training else 0.0
     seeds = [next_seed() for _ in range(3)]
-    q = torch.empty_like(src)
+    q = empty(src.shape, src16.dtype, src)
     ops.add(src, pos, q)
-    V = value_proj_fwd(src, P_["self_attn.value_proj.weight"], P_["self_attn.value_proj.bias"], mask, N, S, M, D,
+    V = value_proj_fwd(src16, P_["self_attn.value_proj.weight"], P_["self_attn.value_proj.bias"], mask, N, S, M, D,
                        EXP.get("v", act))
     out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
                            P_["self_attn.attention_weights.weight"], P_["self_attn.attention_weights.bias"],
                            V, geom, ref, ref_bs, N, S, M, D, npts, EXP.get("oa", act))
-    x1, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
-                          P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0])
-    x2, ffn = ffn_fwd(x1, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                      P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], EXP.get("h", act))
-    saved = dict(src=src, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1, ffn=ffn, seeds=seeds, pd=pd)
-    return x2, saved
+    x1, x1_16, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
+                                 P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0])
+    x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
+                             P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], EXP.get("h", act))
+    saved = dict(src=src16, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1_16, ffn=ffn, seeds=seeds, pd=pd)
+    return x2, x2_16, saved
 
 
 def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_level):
@@ -238,17 +253,17 @@ def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training):
     ops.linear_fwd(tgt, Win[2 * d:], bin_[2 * d:], packed[:, 2 * d:], ldc=3 * d)
     att = empty((rows, d), torch.float32, tgt)
     ops.mha_fwd(packed, packed[:, d:], packed[:, 2 * d:], 3 * d, att, d, N, Q, M, D, pd, seeds[0])
-    t1, ln2 = proj_ln_fwd(att, P_["self_attn.out_proj.weight"], P_["self_attn.out_proj.bias"], tgt,
-                          P_["norm2.weight"], P_["norm2.bias"], pd, seeds[1])
+    t1, _, ln2 = proj_ln_fwd(att, P_["self_attn.out_proj.weight"], P_["self_attn.out_proj.bias"], tgt,
+                             P_["norm2.weight"], P_["norm2.bias"], pd, seeds[1])
     q2 = torch.empty_like(t1)
     ops.add(t1, qpos, q2)
     out_m, OA = sample_fwd(q2, P_["cross_attn.sampling_offsets.weight"], P_["cross_attn.sampling_offsets.bias"],
                            P_["cross_attn.attention_weights.weight"], P_["cross_attn.attention_weights.bias"],
                            V, geom, ref_in, Q * geom.L * 2, N, Q, M, D, npts)
-    t2, ln1 = proj_ln_fwd(out_m, P_["cross_attn.output_proj.weight"], P_["cross_attn.output_proj.bias"], t1,
-                          P_["norm1.weight"], P_["norm1.bias"], pd, seeds[2])
-    t3, ffn = ffn_fwd(t2, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                      P_["norm3.weight"], P_["norm3.bias"], pd, pd, seeds[3], seeds[4])
+    t2, _, ln1 = proj_ln_fwd(out_m, P_["cross_attn.output_proj.weight"], P_["cross_attn.output_proj.bias"], t1,
+                             P_["norm1.weight"], P_["norm1.bias"], pd, seeds[2])
+    t3, _, ffn = ffn_fwd(t2, t2, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
+                         P_["norm3.weight"], P_["norm3.bias"], pd, pd, seeds[3], seeds[4])
     saved = dict(tgt=tgt, qk=qk, packed=packed, att=att, ln2=ln2, t1=t1, q2=q2, OA=OA, out_m=out_m, ln1=ln1, t2=t2,
                  ffn=ffn, seeds=seeds, pd=pd, V=V)
     return t3, saved

@@ -3,22 +3,24 @@
 //
 // Shapes on this path are "tall and thin": M = N_img*S tokens (1e5), K in {256, 1024}, N in
 // {256..1280}; arithmetic intensity is fixed by K=256 (~128-200 flop/B), i.e. close to the
-// machine balance, so the kernel is built around (a) wide coalesced staging, (b) fp32->bf16
-// conversion and layout changes (NCHW, K-major operands for the backward contractions) done
-// while staging instead of in separate HBM passes, (c) an epilogue that applies everything the
-// consumer needs (bias, ReLU, gate, dropout, residual add, row mask, head-major value layout,
-// split-K atomics) so no elementwise kernel ever re-reads the output.
+// machine balance, so the kernel is built around (a) wide coalesced staging with enough bytes in
+// flight per CU to cover HBM latency, (b) fp32->bf16 conversion and layout changes (NCHW, K-major
+// operands of the backward contractions) done while staging instead of in separate HBM passes,
+// (c) an epilogue that applies everything the consumer needs (bias, ReLU, gate, dropout, residual
+// add, row mask, head-major value layout, split-K atomics) so no elementwise kernel re-reads C.
 //
 // Tile: BMxBN per 256-thread workgroup (4 waves as 2x2), each wave (BM/2)x(BN/2) in 16x16 MFMA
-// fragments.  One K stage = 64 bytes of K per row in the compute type (32 bf16 / 16 f32): an LDS
-// row is 64 B payload + 16 B pad (80 B pitch) for both operands, stored [row][k], so every
-// fragment is one ds_read_b128 per lane (row = lane&15, 16-B chunk = lane>>4).
-//   bf16: one v_mfma_f32_16x16x32_bf16 per fragment pair per stage.
+// fragments.  One K stage = BKB bytes of K per row in the compute type (128 B for 128x128 tiles,
+// 256 B for 64x64 tiles).  LDS image per stage: [row][k] with a 16-B pad per row, double buffered;
+// every fragment is one ds_read_b128 per lane (row = lane&15, 16-B chunk = lane>>4) per 64 B of K:
+//   bf16: one v_mfma_f32_16x16x32_bf16 per fragment pair per 64 B.
 //   f32 : four v_mfma_f32_16x16x4_f32 (element t of both 16-B chunks feeds MFMA t; A and B use the
 //         same k permutation, so the contraction is exact).
-// K-major operands (stored [K][rows], the dW = dY^T X and dX = dY W contractions, NCHW features)
-// are transposed in registers while staging: a thread loads 4 consecutive k-rows x 8 rows and
-// writes 8 x (4 k-values) so LDS keeps the same [row][k] image and the MFMA loop is unchanged.
+// Pipeline: global data is held RAW in registers as 16-B chunks from the load of stage t+2 until
+// its LDS write one iteration later (into the buffer that was read two stages ago), so a stage's
+// loads have a full compute stage plus the other resident workgroup to land, with ONE barrier per
+// stage.  K-major operands (stored [K][rows]: dW = dY^T X, dX = dY W, NCHW features) are transposed
+// at the LDS write: a thread holds 4 consecutive k-rows x 8 rows and writes 8 x (4 k-values).
 #include "common.cuh"
 
 namespace poet {
@@ -26,123 +28,148 @@ namespace poet {
 struct GemmK {
     PoetGemmDesc d;
     int kchunk;
-    int a_vec, b_vec;
+    int a_vec, b_vec, c_vec;
     uint32_t drop_thresh;
     float drop_scale;
 };
 
-template <typename CT> struct ct_traits;
-template <> struct ct_traits<bf16_t> { static constexpr int E = 8; };
-template <> struct ct_traits<float> { static constexpr int E = 4; };
+template <typename Src, typename CT, int N> struct cvt_pack;           // N source elements -> packed compute type
+template <> struct cvt_pack<bf16_t, bf16_t, 8> { static __device__ __forceinline__ uint4 run(uint4 v) { return v; } };
+template <> struct cvt_pack<float, float, 4> { static __device__ __forceinline__ uint4 run(uint4 v) { return v; } };
+template <> struct cvt_pack<float, bf16_t, 4> {
+    static __device__ __forceinline__ uint2 run(uint4 v) {
+        return make_uint2(pack_bf2(__uint_as_float(v.x), __uint_as_float(v.y)), pack_bf2(__uint_as_float(v.z), __uint_as_float(v.w)));
+    }
+};
 
-constexpr int LDS_PITCH16 = 5;   // uint4 per LDS row (64 B payload + 16 B pad)
+// 16 bytes of `base[row*ld + k ...]`, zero-filled outside [0,rtot) x [.,kend); scalar path when unaligned
+template <typename Src>
+__device__ __forceinline__ uint4 load_chunk(const Src* __restrict__ base, int64_t ld, int row, int rtot, int k, int kend, int vec_ok) {
+    constexpr int ES = 16 / sizeof(Src);
+    if (row < rtot && k + ES <= kend && vec_ok) return *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + k);
+    Src tmp[ES];
+#pragma unroll
+    for (int e = 0; e < ES; ++e) tmp[e] = (row < rtot && k + e < kend) ? base[(int64_t)row * ld + k + e] : Src(0);
+    uint4 r;
+    __builtin_memcpy(&r, tmp, 16);
+    return r;
+}
 
-// ---- K-contiguous operand: src[row*ld + k] ----------------------------------------------------
-template <typename Src, typename CT, int R>
+template <typename Src> __device__ __forceinline__ float elem_of(const uint4& v, int e);
+template <> __device__ __forceinline__ float elem_of<float>(const uint4& v, int e) {
+    return __uint_as_float(e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w);
+}
+template <> __device__ __forceinline__ float elem_of<bf16_t>(const uint4& v, int e) {
+    const uint32_t w = (e >> 1) == 0 ? v.x : (e >> 1) == 1 ? v.y : (e >> 1) == 2 ? v.z : v.w;
+    return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+
+// ---- K-contiguous operand: src[row*ld + k] --------------------------------------------------------
+template <typename Src, typename CT, int R, int BKB>
 struct LoaderKC {
-    static constexpr int E = ct_traits<CT>::E;
-    static constexpr int NI = (R * 4) / 256;
-    static_assert(NI >= 1, "tile too small");
-    float v[NI][E];
+    static constexpr int ES = 16 / sizeof(Src);                 // source elements per 16-B chunk
+    static constexpr int BK = BKB / sizeof(CT);                 // K elements per stage
+    static constexpr int CPR = BK / ES;                         // chunks per row
+    static constexpr int NCH = R * CPR;
+    static constexpr int NI = (NCH + 255) / 256;
+    static constexpr int PITCH = BKB + 16;
+    static_assert(sizeof(Src) >= sizeof(CT), "bf16 storage with f32 compute is not used");
+    uint4 v[NI];
 
-    __device__ __forceinline__ void load(const Src* __restrict__ src, int64_t ld, int r0, int rtot,
-                                         int k0, int kend, int vec_ok, int tid) {
+    __device__ __forceinline__ void load(const Src* __restrict__ src, int64_t ld, int r0, int rtot, int k0, int kend, int vec_ok, int tid) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int c = tid + i * 256;
-            const int row = c >> 2, kc = c & 3;
-            const int gr = r0 + row, gk = k0 + kc * E;
-            if (gr < rtot && gk + E <= kend && vec_ok) {
-                vec<Src, E>::ld(src + (int64_t)gr * ld + gk, v[i]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    v[i][e] = (gr < rtot && gk + e < kend) ? io<Src>::ld(src + (int64_t)gr * ld + gk + e) : 0.f;
+            if (NCH % 256 == 0 || c < NCH) {
+                const int row = c / CPR, kc = c % CPR;
+                v[i] = load_chunk<Src>(src, ld, r0 + row, rtot, k0 + kc * ES, kend, vec_ok);
             }
         }
     }
-    __device__ __forceinline__ void store(uint4* __restrict__ lds, int tid) const {
+    __device__ __forceinline__ void store(char* __restrict__ lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int c = tid + i * 256;
-            const int row = c >> 2, kc = c & 3;
-            uint4 w;
-            if constexpr (E == 8) {
-                w = make_uint4(pack_bf2(v[i][0], v[i][1]), pack_bf2(v[i][2], v[i][3]),
-                               pack_bf2(v[i][4], v[i][5]), pack_bf2(v[i][6], v[i][7]));
-            } else {
-                w = make_uint4(__float_as_uint(v[i][0]), __float_as_uint(v[i][1]),
-                               __float_as_uint(v[i][2]), __float_as_uint(v[i][3]));
+            if (NCH % 256 == 0 || c < NCH) {
+                const int row = c / CPR, kc = c % CPR;
+                auto w = cvt_pack<Src, CT, ES>::run(v[i]);
+                *reinterpret_cast<decltype(w)*>(lds + row * PITCH + kc * (int)sizeof(w)) = w;
             }
-            lds[row * LDS_PITCH16 + kc] = w;
         }
     }
 };
 
-// ---- K-major operand: src[k*ld + row] (register transpose while staging) -----------------------
-template <typename Src, typename CT, int R, int TOFF>
+// ---- K-major operand: src[k*ld + row]; an item = 4 consecutive k-rows x 8 rows, transposed at the LDS write ----
+template <typename Src, typename CT, int R, int BKB>
 struct LoaderKM {
-    static constexpr int E = ct_traits<CT>::E;
-    static constexpr int NKQ = E;                 // k-quads per stage (BK = 4E)
+    static constexpr int ES = 16 / sizeof(Src);
+    static constexpr int BK = BKB / sizeof(CT);
+    static constexpr int NKQ = BK / 4;
     static constexpr int ITEMS = NKQ * (R / 8);
-    static_assert(ITEMS <= 256, "one item per thread");
-    float v[4][8];
+    static constexpr int NI = (ITEMS + 255) / 256;
+    static constexpr int CPI = 8 / ES;                          // 16-B chunks per k-row of an item (1 bf16, 2 f32)
+    static constexpr int PITCH = BKB + 16;
+    uint4 v[NI][4][CPI];
 
-    __device__ __forceinline__ void load(const Src* __restrict__ src, int64_t ld, int r0, int rtot,
-                                         int k0, int kend, int vec_ok, int tid) {
-        const int item = tid - TOFF;
-        if (item < 0 || item >= ITEMS) return;
-        const int kq = item % NKQ, rg = item / NKQ;
-        const int gr = r0 + rg * 8;
+    __device__ __forceinline__ void load(const Src* __restrict__ src, int64_t ld, int r0, int rtot, int k0, int kend, int vec_ok, int tid) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gk = k0 + kq * 4 + i;
-            if (gk < kend && gr + 8 <= rtot && vec_ok) {
-                vec<Src, 8>::ld(src + (int64_t)gk * ld + gr, v[i]);
-            } else {
+        for (int i = 0; i < NI; ++i) {
+            const int item = tid + i * 256;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
+                const int kq = item % NKQ, rg = item / NKQ;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[i][j] = (gk < kend && gr + j < rtot) ? io<Src>::ld(src + (int64_t)gk * ld + gr + j) : 0.f;
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int cc = 0; cc < CPI; ++cc)      // the memory row of a K-major source is k; its columns are tile rows
+                        v[i][kk][cc] = load_chunk<Src>(src, ld, k0 + kq * 4 + kk, kend, r0 + rg * 8 + cc * ES, rtot, vec_ok);
             }
         }
     }
-    __device__ __forceinline__ void store(uint4* __restrict__ lds, int tid) const {
-        const int item = tid - TOFF;
-        if (item < 0 || item >= ITEMS) return;
-        const int kq = item % NKQ, rg = item / NKQ;
-        char* base = reinterpret_cast<char*>(lds);
+    __device__ __forceinline__ void store(char* __restrict__ lds, int tid) const {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = rg * 8 + j;
-            if constexpr (E == 8) {
-                *reinterpret_cast<uint2*>(base + row * (LDS_PITCH16 * 16) + kq * 8) =
-                    make_uint2(pack_bf2(v[0][j], v[1][j]), pack_bf2(v[2][j], v[3][j]));
-            } else {
-                *reinterpret_cast<float4*>(base + row * (LDS_PITCH16 * 16) + kq * 16) =
-                    make_float4(v[0][j], v[1][j], v[2][j], v[3][j]);
+        for (int i = 0; i < NI; ++i) {
+            const int item = tid + i * 256;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
+                const int kq = item % NKQ, rg = item / NKQ;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f0 = elem_of<Src>(v[i][0][j / ES], j % ES), f1 = elem_of<Src>(v[i][1][j / ES], j % ES);
+                    const float f2 = elem_of<Src>(v[i][2][j / ES], j % ES), f3 = elem_of<Src>(v[i][3][j / ES], j % ES);
+                    char* dst = lds + (rg * 8 + j) * PITCH;
+                    if constexpr (sizeof(CT) == 2) *reinterpret_cast<uint2*>(dst + kq * 8) = make_uint2(pack_bf2(f0, f1), pack_bf2(f2, f3));
+                    else *reinterpret_cast<float4*>(dst + kq * 16) = make_float4(f0, f1, f2, f3);
+                }
             }
         }
     }
 };
 
-template <typename Src, typename CT, int R, bool KM, int TOFF> struct LoaderSel;
-template <typename Src, typename CT, int R, int TOFF> struct LoaderSel<Src, CT, R, false, TOFF> { using type = LoaderKC<Src, CT, R>; };
-template <typename Src, typename CT, int R, int TOFF> struct LoaderSel<Src, CT, R, true, TOFF> { using type = LoaderKM<Src, CT, R, TOFF>; };
+template <typename Src, typename CT, int R, int BKB, bool KM> struct LoaderSel;
+template <typename Src, typename CT, int R, int BKB> struct LoaderSel<Src, CT, R, BKB, false> { using type = LoaderKC<Src, CT, R, BKB>; };
+template <typename Src, typename CT, int R, int BKB> struct LoaderSel<Src, CT, R, BKB, true> { using type = LoaderKM<Src, CT, R, BKB>; };
 
-template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, bool AKM, bool BKM>
+template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
-    constexpr int E = ct_traits<CT>::E;
-    constexpr int BK = 4 * E;
+    constexpr int BK = BKB / sizeof(CT);
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int BTOFF = (BKM && (E * (BN / 8) <= 128)) ? 128 : 0;
-    __shared__ uint4 lds[(BM + BN) * LDS_PITCH16];
-    uint4* As = lds;
-    uint4* Bs = lds + BM * LDS_PITCH16;
+    constexpr int PITCH = BKB + 16;
+    constexpr int KSTEPS = BKB / 64;
+    constexpr int STAGE = (BM + BN) * PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const PoetGemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // XCD-aware tile order: workgroup L runs on XCD L%8 (observed dispatch), so give each XCD a CONTIGUOUS range of
+    // tiles in (m-panel major, n minor) order -- the N tiles of one A panel then share one L2 instead of 8.  Pure
+    // speed heuristic: any placement computes the same result.
+    const int gx = gridDim.x, ntile = gx * gridDim.y;
+    int L = blockIdx.y * gx + blockIdx.x;
+    {
+        const int q = ntile >> 3, r = ntile & 7, xcd = L & 7, idx = L >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n0 = (L % gx) * BN, m0 = (L / gx) * BM;
     const int zb = blockIdx.z / d.splitk, sk = blockIdx.z % d.splitk;
     const int kbeg = sk * p.kchunk;
     const int kend = min(d.K, kbeg + p.kchunk);
@@ -151,8 +178,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
     const TA* A = reinterpret_cast<const TA*>(d.A) + (int64_t)zb * d.strideA;
     const TB* B = reinterpret_cast<const TB*>(d.B) + (int64_t)zb * d.strideB;
 
-    typename LoaderSel<TA, CT, BM, AKM, 0>::type la;
-    typename LoaderSel<TB, CT, BN, BKM, BTOFF>::type lb;
+    typename LoaderSel<TA, CT, BM, BKB, AKM>::type la;
+    typename LoaderSel<TB, CT, BN, BKB, BKM>::type lb;
 
     f32x4_t acc[FM][FN];
 #pragma unroll
@@ -160,112 +187,192 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // prologue: stage 0 -> LDS buffer 0, stage 1 -> registers
     la.load(A, d.lda, m0, d.M, kbeg, kend, p.a_vec, tid);
     lb.load(B, d.ldb, n0, d.N, kbeg, kend, p.b_vec, tid);
-    la.store(As, tid);
-    lb.store(Bs, tid);
+    la.store(smem, tid);
+    lb.store(smem + BM * PITCH, tid);
+    if (kbeg + BK < kend) {
+        la.load(A, d.lda, m0, d.M, kbeg + BK, kend, p.a_vec, tid);
+        lb.load(B, d.ldb, n0, d.N, kbeg + BK, kend, p.b_vec, tid);
+    }
     __syncthreads();
 
     const int frow = lane & 15, fchunk = lane >> 4;
+    int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = (k0 + BK) < kend;
-        if (more) {
-            la.load(A, d.lda, m0, d.M, k0 + BK, kend, p.a_vec, tid);
-            lb.load(B, d.ldb, n0, d.N, k0 + BK, kend, p.b_vec, tid);
+        // registers hold stage k0+BK (issued one iteration ago): park it in the other LDS buffer (its last readers
+        // passed the barrier that ended the previous iteration), then put stage k0+2BK in flight.
+        if (k0 + BK < kend) {
+            char* nxt = smem + (buf ^ 1) * STAGE;
+            la.store(nxt, tid);
+            lb.store(nxt + BM * PITCH, tid);
+            if (k0 + 2 * BK < kend) {
+                la.load(A, d.lda, m0, d.M, k0 + 2 * BK, kend, p.a_vec, tid);
+                lb.load(B, d.ldb, n0, d.N, k0 + 2 * BK, kend, p.b_vec, tid);
+            }
         }
-        uint4 af[FM], bfr[FN];
+        const char* As = smem + buf * STAGE;
+        const char* Bs = As + BM * PITCH;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = As[(wm * WM + i * 16 + frow) * LDS_PITCH16 + fchunk];
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            uint4 af[FM], bfr[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = Bs[(wn * WN + j * 16 + frow) * LDS_PITCH16 + fchunk];
+            for (int i = 0; i < FM; ++i)
+                af[i] = *reinterpret_cast<const uint4*>(As + (wm * WM + i * 16 + frow) * PITCH + ks * 64 + fchunk * 16);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
+            for (int j = 0; j < FN; ++j)
+                bfr[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WN + j * 16 + frow) * PITCH + ks * 64 + fchunk * 16);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if constexpr (E == 8) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
-                } else {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].z), __uint_as_float(bfr[j].z), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
+            for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (sizeof(CT) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].z), __uint_as_float(bfr[j].z), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
         __syncthreads();
-        if (more) {
-            la.store(As, tid);
-            lb.store(Bs, tid);
-            __syncthreads();
-        }
+        buf ^= 1;
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
+    // ---- epilogue: accumulators -> LDS [row][col] (f32) -> 8 consecutive columns per lane --------------------------
+    // so bias / gate / residual are 16-32 B vector loads and C leaves as 16-B (bf16x8) or 2x16-B (f32x8) stores that
+    // are contiguous along the row across lanes (the MFMA layout itself would give 2-byte stores 4 rows apart).
+    constexpr int CP = BN + 4;                               // fp32 pitch of the staged C tile
+    static_assert(BM * CP * 4 <= 2 * STAGE, "C tile must fit in the staging buffers");
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                Cs[(wm * WM + i * 16 + fchunk * 4 + t) * CP + wn * WN + j * 16 + frow] = acc[i][j][t] * d.alpha;
+    __syncthreads();
+
     TC* C = reinterpret_cast<TC*>(d.C) + (int64_t)zb * d.strideC;
+    const bool use_atomic = (d.atomic != 0) || (d.splitk > 1);
+    if (use_atomic) {
+        if constexpr (sizeof(TC) == 4) {
+            float* Cf = reinterpret_cast<float*>(C);
+            for (int idx = tid; idx < BM * BN; idx += 256) {
+                const int row = idx / BN, col = idx - row * BN;
+                if (m0 + row < d.M && n0 + col < d.N) atomicAdd(Cf + (int64_t)(m0 + row) * d.ldc + n0 + col, Cs[row * CP + col]);
+            }
+        }
+        return;
+    }
     const float* bias = d.bias ? d.bias + (int64_t)zb * d.stride_bias : nullptr;
     const TC* addp = reinterpret_cast<const TC*>(d.add_src);
     const TC* gate = reinterpret_cast<const TC*>(d.gate_ref);
-    const bool use_atomic = (d.atomic != 0) || (d.splitk > 1);
+    constexpr int C8 = BN / 8;
+    for (int idx = tid; idx < BM * C8; idx += 256) {
+        const int row = idx / C8, c8 = idx - row * C8;
+        const int grow = m0 + row, gcol = n0 + c8 * 8;
+        if (grow >= d.M || gcol >= d.N) continue;
+        float v[8];
+        vec<float, 8>::ld(Cs + row * CP + c8 * 8, v);
+        const bool full = (gcol + 8 <= d.N) && p.c_vec;
+        int64_t off;
+        if (d.out_mode == 1) {
+            const int hn = grow / d.hm_S, hs = grow - hn * d.hm_S, hm = gcol / d.hm_D, hd = gcol - hm * d.hm_D;
+            off = (((int64_t)hn * d.hm_M + hm) * d.hm_S + hs) * d.hm_D + hd;
+        } else {
+            off = (int64_t)grow * d.ldc + gcol;
+        }
+        if (bias) {
+            if (full) { float b[8]; vec<float, 8>::ld(bias + gcol, b);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+                for (int e = 0; e < 8; ++e) v[e] += b[e]; }
+            else { for (int e = 0; e < 8; ++e) if (gcol + e < d.N) v[e] += bias[gcol + e]; }
+        }
+        if (d.act == 1) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int row = m0 + wm * WM + i * 16 + fchunk * 4 + t;
-            if (row >= d.M) continue;
-            const bool masked = d.row_mask && d.row_mask[row];
-            int hm_n = 0, hm_s = 0;
-            if (d.out_mode == 1) { hm_n = row / d.hm_S; hm_s = row - hm_n * d.hm_S; }
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (gate) {
+            float g[8];
+            if (full) vec<TC, 8>::ld(gate + (int64_t)grow * d.ldc + gcol, g);
+            else for (int e = 0; e < 8; ++e) g[e] = (gcol + e < d.N) ? io<TC>::ld(gate + (int64_t)grow * d.ldc + gcol + e) : 0.f;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int col = n0 + wn * WN + j * 16 + frow;
-                if (col >= d.N) continue;
-                float val = acc[i][j][t] * d.alpha;
-                int64_t off;
-                if (d.out_mode == 1) {
-                    const int hm_m = col / d.hm_D, hm_d = col - hm_m * d.hm_D;
-                    off = (((int64_t)hm_n * d.hm_M + hm_m) * d.hm_S + hm_s) * d.hm_D + hm_d;
-                } else {
-                    off = (int64_t)row * d.ldc + col;
-                }
-                if (use_atomic) {
-                    if constexpr (sizeof(TC) == 4) atomicAdd(reinterpret_cast<float*>(C) + off, val);
-                    continue;
-                }
-                if (bias) val += bias[col];
-                if (d.act == 1) val = fmaxf(val, 0.f);
-                if (gate) val = (io<TC>::ld(gate + (int64_t)row * d.ldc + col) > 0.f) ? val * d.gate_scale : 0.f;
-                if (p.drop_thresh) {
-                    val = drop_keep(d.seed, (uint32_t)row * (uint32_t)d.N + (uint32_t)col, p.drop_thresh) ? val * p.drop_scale : 0.f;
-                }
-                if (addp) val += io<TC>::ld(addp + (int64_t)row * d.ld_add + col);
-                if (masked) val = 0.f;
-                io<TC>::st(C + off, val);
+            for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] * d.gate_scale : 0.f;
+        }
+        if (p.drop_thresh) {
+            const uint32_t base = (uint32_t)grow * (uint32_t)d.N + (uint32_t)gcol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = drop_keep(d.seed, base + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+        }
+        if (addp) {
+            float a8[8];
+            if (full) vec<TC, 8>::ld(addp + (int64_t)grow * d.ld_add + gcol, a8);
+            else for (int e = 0; e < 8; ++e) a8[e] = (gcol + e < d.N) ? io<TC>::ld(addp + (int64_t)grow * d.ld_add + gcol + e) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a8[e];
+        }
+        if (d.row_mask && d.row_mask[grow]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        if (full) {
+            vec<TC, 8>::st(C + off, v);
+        } else if (d.out_mode == 1) {
+            for (int e = 0; e < 8; ++e) if (gcol + e < d.N) {
+                const int cc = gcol + e, hn = grow / d.hm_S, hs = grow - hn * d.hm_S, hm = cc / d.hm_D, hd = cc - hm * d.hm_D;
+                io<TC>::st(C + (((int64_t)hn * d.hm_M + hm) * d.hm_S + hs) * d.hm_D + hd, v[e]);
             }
+        } else {
+            for (int e = 0; e < 8; ++e) if (gcol + e < d.N) io<TC>::st(C + off + e, v[e]);
         }
     }
 }
 
-template <typename TA, typename TB, typename TC, typename CT, int BM, int BN>
-static int launch_layout(const GemmK& p, dim3 grid, hipStream_t st) {
+template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB, bool AKM, bool BKM>
+static void launch_one(const GemmK& p, hipStream_t st) {
+    constexpr int LDS = 2 * (BM + BN) * (BKB + 16);
+    auto kern = gemm_kernel<TA, TB, TC, CT, BM, BN, BKB, AKM, BKM>;
+    static bool attr_set = false;          // per instantiation; idempotent, so a race between host threads is benign
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const PoetGemmDesc& d = p.d;
+    dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, p);
+}
+
+template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB>
+static void launch_layout(const GemmK& p, hipStream_t st) {
     const int key = p.d.a_kmajor * 2 + p.d.b_kmajor;
     switch (key) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<TA, TB, TC, CT, BM, BN, false, false>), grid, dim3(256), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<TA, TB, TC, CT, BM, BN, false, true>), grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<TA, TB, TC, CT, BM, BN, true, false>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<TA, TB, TC, CT, BM, BN, true, true>), grid, dim3(256), 0, st, p); break;
+        case 0: launch_one<TA, TB, TC, CT, BM, BN, BKB, false, false>(p, st); break;
+        case 1: launch_one<TA, TB, TC, CT, BM, BN, BKB, false, true>(p, st); break;
+        case 2: launch_one<TA, TB, TC, CT, BM, BN, BKB, true, false>(p, st); break;
+        default: launch_one<TA, TB, TC, CT, BM, BN, BKB, true, true>(p, st); break;
     }
-    return 0;
+}
+
+// tile choice: 0 = 128x128 (BKB 128), 1 = 64x64 (BKB 256), 2 = 32x32 (BKB 256; fp32-MFMA problems with few rows, so the
+// 1/16-rate f32 matrix pipe of more than a handful of CUs is used)
+static int tile_choice(const PoetGemmDesc& d) {
+    if (d.M >= 256 && d.N >= 128 && !(d.compute == POET_F32 && d.M < 1024)) return 0;
+    if (d.compute == POET_F32 && (int64_t)cdiv(d.M, 64) * cdiv(d.N, 64) * d.batch * d.splitk < 256) return 2;
+    return 1;
 }
 
 template <typename TA, typename TB, typename TC, typename CT>
-static int launch_tile(const GemmK& p, hipStream_t st) {
-    const PoetGemmDesc& d = p.d;
-    const bool big = (d.M >= 512 && d.N >= 128);
-    const int BM = big ? 128 : 64, BN = big ? 128 : 64;
-    dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.splitk);
-    if (big) return launch_layout<TA, TB, TC, CT, 128, 128>(p, grid, st);
-    return launch_layout<TA, TB, TC, CT, 64, 64>(p, grid, st);
+static void launch_tile(const GemmK& p, hipStream_t st) {
+    const int tc = tile_choice(p.d);
+    if (tc == 0) launch_layout<TA, TB, TC, CT, 128, 128, 128>(p, st);
+    else if (tc == 1) launch_layout<TA, TB, TC, CT, 64, 64, 256>(p, st);
+    else if constexpr (sizeof(CT) == 4) launch_layout<TA, TB, TC, CT, 32, 32, 256>(p, st);
 }
 
 static bool vec_ok(const void* ptr, int64_t ld, int64_t stride) {
@@ -293,11 +400,13 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.out_mode == 1) POET_CHECK(d.hm_M > 0 && d.hm_S > 0 && d.hm_D > 0 && d.hm_M * d.hm_D == d.N, POET_ERR_ARG, "poet_gemm: head-major dims");
-    const int E = d.compute == POET_BF16 ? 8 : 4;
-    const int BK = 4 * E;
+    const int BKB = tile_choice(d) == 0 ? 128 : 256;
+    const int BK = BKB / (d.compute == POET_BF16 ? 2 : 4);
     p.kchunk = cdiv(cdiv(d.K, d.splitk), BK) * BK;
     p.a_vec = vec_ok(d.A, d.lda, d.strideA);
     p.b_vec = vec_ok(d.B, d.ldb, d.strideB);
+    p.c_vec = vec_ok(d.C, d.ldc, d.strideC) && (!d.add_src || vec_ok(d.add_src, d.ld_add, 0)) && (!d.gate_ref || vec_ok(d.gate_ref, d.ldc, 0)) &&
+              (!d.bias || vec_ok(d.bias, 8, d.stride_bias)) && (d.out_mode != 1 || d.hm_D % 8 == 0);
     p.drop_thresh = d.drop_p > 0.f ? drop_thresh(d.drop_p) : 0u;
     p.drop_scale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;

@@ -5,18 +5,18 @@
 namespace poet {
 
 // ---- add / cast ---------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t n) {
+template <typename TA, typename TB, typename TO>
+__global__ __launch_bounds__(256) void add_kernel(const TA* __restrict__ a, const TB* __restrict__ b, TO* __restrict__ o, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i + 8 <= n) {
         float x[8], y[8];
-        vec<T, 8>::ld(a + i, x);
-        vec<T, 8>::ld(b + i, y);
+        vec<TA, 8>::ld(a + i, x);
+        vec<TB, 8>::ld(b + i, y);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] += y[e];
-        vec<T, 8>::st(o + i, x);
+        vec<TO, 8>::st(o + i, x);
     } else {
-        for (int64_t j = i; j < n; ++j) io<T>::st(o + j, io<T>::ld(a + j) + io<T>::ld(b + j));
+        for (int64_t j = i; j < n; ++j) io<TO>::st(o + j, io<TA>::ld(a + j) + io<TB>::ld(b + j));
     }
 }
 
@@ -48,35 +48,50 @@ struct ColsumP {
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const ColsumP p) {
+    // block = rows_per_block rows x 256 columns; each wave streams its share of the rows with 8 independent 4-column
+    // loads in flight per lane, the 4 waves are combined through LDS, then ONE atomic per column per block (and segment).
+    __shared__ float red[4][256];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c0 = (blockIdx.x * 64 + lane) * 4;
     const int64_t r0 = (int64_t)blockIdx.y * p.rows_per_block;
     const int64_t r1 = min(p.rows_per_batch, r0 + p.rows_per_block);
     const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)blockIdx.z * p.rows_per_batch * p.ld;
-    if (c0 >= p.cols) return;
+    const bool incol = c0 < p.cols;
     const bool full = (c0 + 4 <= p.cols) && p.aligned;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int seg = 0;
-    auto flush = [&](int s) {
-        for (int e = 0; e < 4; ++e)
-            if (c0 + e < p.cols && acc[e] != 0.f) atomicAdd(p.out + (int64_t)s * p.cols + c0 + e, acc[e]);
-        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
-    };
-    for (int64_t r = r0 + wid; r < r1; r += 4) {
-        int s = seg;
-        while (s + 1 < p.nseg && r >= p.seg[s + 1]) ++s;
-        if (s != seg) { flush(seg); seg = s; }
-        if (full) {
-            float v[4];
-            vec<T, 4>::ld(xb + r * p.ld + c0, v);
+    // segments covered by this block's row range
+    int s_lo = 0;
+    while (s_lo + 1 < p.nseg && r0 >= p.seg[s_lo + 1]) ++s_lo;
+    int s_hi = s_lo;
+    while (s_hi + 1 < p.nseg && r1 - 1 >= p.seg[s_hi + 1]) ++s_hi;
+    for (int sg = s_lo; sg <= s_hi; ++sg) {
+        const int64_t a = max(r0, p.seg[sg]), b = (sg + 1 < p.nseg || p.nseg > 1) ? min(r1, p.seg[sg + 1]) : r1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        constexpr int U = 8;
+        int64_t r = a + wid;
+        if (incol) {
+            for (; full && r + 4 * (U - 1) < b; r += 4 * U) {
+                float v[U][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += v[e];
-        } else {
-            for (int e = 0; e < 4; ++e)
-                if (c0 + e < p.cols) acc[e] += io<T>::ld(xb + r * p.ld + c0 + e);
+                for (int u = 0; u < U; ++u) vec<T, 4>::ld(xb + (r + 4 * u) * p.ld + c0, v[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
+            }
+            for (; r < b; r += 4)
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < p.cols) acc[e] += io<T>::ld(xb + r * p.ld + c0 + e);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wid][lane * 4 + e] = acc[e];
+        __syncthreads();
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c < p.cols) {
+            const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            if (t != 0.f) atomicAdd(p.out + (int64_t)sg * p.cols + c, t);
         }
     }
-    flush(seg);
 }
 
 // ---- fp32 value-gradient maps -> row-major activations -------------------------------------------
@@ -383,11 +398,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 using namespace poet;
 #define ST ((hipStream_t)stream)
 
-extern "C" int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+extern "C" int poet_add(const void* a, const void* b, void* out, int64_t n, int da, int db, int dout, void* stream) {
     POET_CHECK(a && b && out && n > 0, POET_ERR_ARG, "add: bad args");
     dim3 grid(cdiv(n, 2048)), block(256);
-    if (dtype == POET_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, grid, block, 0, ST, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
-    else hipLaunchKernelGGL(add_kernel<float>, grid, block, 0, ST, (const float*)a, (const float*)b, (float*)out, n);
+    const int key = da * 4 + db * 2 + dout;
+    if (key == 7) hipLaunchKernelGGL((add_kernel<bf16_t, bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else if (key == 0) hipLaunchKernelGGL((add_kernel<float, float, float>), grid, block, 0, ST, (const float*)a, (const float*)b, (float*)out, n);
+    else if (key == 3) hipLaunchKernelGGL((add_kernel<float, bf16_t, bf16_t>), grid, block, 0, ST, (const float*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else if (key == 1) hipLaunchKernelGGL((add_kernel<float, float, bf16_t>), grid, block, 0, ST, (const float*)a, (const float*)b, (bf16_t*)out, n);
+    else { set_error("add: unsupported dtype triple %d %d %d", da, db, dout); return POET_ERR_UNSUPPORTED; }
     POET_LAUNCH_CHECK();
     return POET_OK;
 }
@@ -411,7 +430,7 @@ extern "C" int poet_colsum(const void* x, int64_t ld, float* out, int batch, int
     p.x = x; p.ld = ld; p.out = out; p.rows_per_batch = rows_per_batch; p.cols = cols; p.nseg = nseg;
     if (seg_start_host) for (int i = 0; i <= nseg; ++i) p.seg[i] = seg_start_host[i];
     else { p.seg[0] = 0; p.seg[1] = rows_per_batch; }
-    p.rows_per_block = 512;
+    p.rows_per_block = rows_per_batch >= 4096 ? 128 : (rows_per_batch >= 512 ? 32 : 8);
     p.aligned = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     dim3 grid(cdiv(cols, 256), cdiv(rows_per_batch, p.rows_per_block), batch), block(256);
     if (dtype == POET_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, ST, p);

@@ -188,7 +188,6 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
     load_weights<TQ, L, P, FUSED>(p, row, m, a);
     const int64_t voff = (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8;
     const TV* vbase = reinterpret_cast<const TV*>(p.value) + voff;
-    float* gvbase = p.grad_value + voff;
 
     float g[8];
     vec<TQ, 8>::ld(reinterpret_cast<const TQ*>(p.grad_out) + row * ((int64_t)p.M * p.D) + m * p.D + dsub * 8, g);
@@ -221,24 +220,6 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
             da[l * P + i] = group_sum(s_da, p.tpg);
             dxy[2 * i] = group_sum(s_dx, p.tpg);
             dxy[2 * i + 1] = group_sum(s_dy, p.tpg);
-            // scatter into the value gradient (fp32 atomics)
-            const float w00 = aw * c.w00, w01 = aw * c.w01, w10 = aw * c.w10, w11 = aw * c.w11;
-            if (w00 != 0.f) {
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) atomicAdd(gvbase + c.o00 + ch, w00 * g[ch]);
-            }
-            if (w01 != 0.f) {
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) atomicAdd(gvbase + c.o01 + ch, w01 * g[ch]);
-            }
-            if (w10 != 0.f) {
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) atomicAdd(gvbase + c.o10 + ch, w10 * g[ch]);
-            }
-            if (w11 != 0.f) {
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) atomicAdd(gvbase + c.o11 + ch, w11 * g[ch]);
-            }
         }
         if (dsub == 0) {
             if constexpr (FUSED) {
@@ -271,9 +252,47 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
     }
 }
 
+// d(value): pure scatter, no value loads.  One lane per channel: the D lanes of a (query, head) add D consecutive
+// floats, so every atomic wave-instruction covers whole contiguous 4*D-byte segments (coalesced into a few L2 atomic
+// requests) instead of 64 scattered dwords.  The softmax / corner arithmetic is recomputed per lane (it is tiny).
+template <typename TQ, int L, int P, bool FUSED>
+__global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total * 8) return;
+    const int64_t rm = t / p.D;
+    const int c = (int)(t - rm * p.D);
+    const int64_t row = rm / p.M;
+    const int m = (int)(rm - row * p.M);
+    const int n = (int)(row / p.Lq), q = (int)(row - (int64_t)n * p.Lq);
+    float a[L * P];
+    load_weights<TQ, L, P, FUSED>(p, row, m, a);
+    const float g = io<TQ>::ld(reinterpret_cast<const TQ*>(p.grad_out) + row * ((int64_t)p.M * p.D) + m * p.D + c);
+    float* gv = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float xy[2 * P];
+        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, xy);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const Corner cn = make_corner(xy[2 * i], xy[2 * i + 1], p.H[l], p.W[l], p.start[l], p.vs_s);
+            const float ag = a[l * P + i] * g;
+            if (cn.w00 != 0.f) atomicAdd(gv + cn.o00, ag * cn.w00);
+            if (cn.w01 != 0.f) atomicAdd(gv + cn.o01, ag * cn.w01);
+            if (cn.w10 != 0.f) atomicAdd(gv + cn.o10, ag * cn.w10);
+            if (cn.w11 != 0.f) atomicAdd(gv + cn.o11, ag * cn.w11);
+        }
+    }
+}
+
 template <typename TV, typename TQ, int L, bool FUSED, bool BWD>
 static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     dim3 grid(cdiv(p.total, 256)), block(256);
+    dim3 gridv(cdiv(p.total * 8, 256));
+    if (BWD) {
+        if (P == 4) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 4, FUSED>), gridv, block, 0, st, p);
+        else if (P == 2) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 2, FUSED>), gridv, block, 0, st, p);
+        else hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 1, FUSED>), gridv, block, 0, st, p);
+    }
     if (P == 4) {
         if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 4, FUSED>), grid, block, 0, st, p);

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      TR* __restrict__ y, TX* __restrict__ z, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t rows, int d, float eps,
-                                                     uint32_t thresh, float dscale, uint32_t seed) {
+                                                     uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wid;
     if (row >= rows) return;
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * g[e] + b[e];
             vec<TR, 4>::st(y + row * d + c, o);
+            if (y16) vec<bf16_t, 4>::st(y16 + row * d + c, o);
             if (z) vec<TX, 4>::st(z + row * d + c, v[it]);
         }
     }
@@ -240,7 +241,7 @@ using namespace poet;
 
 extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
                            float* mean, float* rstd, int64_t rows, int d, float eps, float drop_p, uint32_t seed,
-                           int dtype_x, int dtype_r, void* stream) {
+                           int dtype_x, int dtype_r, void* y_bf16, void* stream) {
     POET_CHECK(x && gamma && beta && y, POET_ERR_ARG, "ln_fwd: null pointer");
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_fwd: d=%d unsupported", d);
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "ln_fwd: drop_p");
@@ -248,7 +249,7 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
     const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed)
+#define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16)
     POET_DT2(dtype_x, dtype_r, LN_FWD);
 #undef LN_FWD
     POET_LAUNCH_CHECK();

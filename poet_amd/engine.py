@@ -73,16 +73,27 @@ class ParamArena:
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # bf16 shadow of every weight: the second MFMA operand of the bf16 GEMMs; rewritten by the AdamW kernel
+        self.flat_bf16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
         for n, p, o in self.entries:
             k = p.numel()
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view(p.shape)
             p._grad_view = self.grad[o:o + k].view(p.shape)
             p.grad = p._grad_view
+            p._bf16 = self.flat_bf16[o:o + k].view(p.shape)
+        self.refresh_shadow()
         self.groups = [(0, self.n_main, lr), (self.n_main, self.total, lr * lr_proj_mult)]
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.step_count = 0
         self.world = 1
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 shadow from the fp32 masters (after construction / load_state_dict)."""
+        if self.flat.is_cuda:
+            ops.cast(self.flat, self.flat_bf16)
+        else:
+            self.flat_bf16.copy_(self.flat)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -99,7 +110,8 @@ class ParamArena:
         for a, b, lr in self.groups:
             if b > a:
                 ops.adamw(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b], b - a, lr, self.betas[0], self.betas[1],
-                          self.eps, self.weight_decay, self.step_count, sqnorm_buf=sq, max_norm=max_norm, grad_scale=gs)
+                          self.eps, self.weight_decay, self.step_count, sqnorm_buf=sq, max_norm=max_norm, grad_scale=gs,
+                          p_bf16=self.flat_bf16[a:b])
 
     def grad_norm(self) -> torch.Tensor:
         return torch.sqrt(self.sq[0]) / self.world
@@ -187,7 +199,8 @@ class PoseMatcher(nn.Module):
         if self._cache[0] is pb:            # same boxes for every decoder layer: identical assignment
             return self._cache[1]
         bs, nq = pb.shape[:2]
-        out_bbox = pb.flatten(0, 1).detach().cpu()
+        host = outputs.get("_pred_boxes_host")          # same values, already on the host: no device sync
+        out_bbox = torch.from_numpy(host).flatten(0, 1) if host is not None else pb.flatten(0, 1).detach().cpu()
         tgt_bbox = torch.cat([t["boxes"].detach().cpu() for t in targets])
         cost = (self.cost_bbox * torch.cdist(out_bbox, tgt_bbox, p=1)).view(bs, nq, -1)
         sizes = [len(t["boxes"]) for t in targets]
@@ -210,9 +223,11 @@ class SetCriterion(nn.Module):
     def _gather_targets(targets, indices, device):
         b = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
         s = torch.cat([src for (src, _) in indices])
-        tt = torch.cat([t["relative_position"][j.to(t["relative_position"].device)] for t, (_, j) in zip(targets, indices)], 0)
-        tr = torch.cat([t["relative_rotation"][j.to(t["relative_rotation"].device)] for t, (_, j) in zip(targets, indices)], 0)
-        return b.to(device), s.to(device), tt.to(device), tr.to(device)
+        mvi = lambda j, ref: j if not ref.is_cuda else j.pin_memory().to(ref.device, non_blocking=True)
+        tt = torch.cat([t["relative_position"][mvi(j, t["relative_position"])] for t, (_, j) in zip(targets, indices)], 0)
+        tr = torch.cat([t["relative_rotation"][mvi(j, t["relative_rotation"])] for t, (_, j) in zip(targets, indices)], 0)
+        mv = lambda t: t.to(device) if t.is_cuda or device.type != "cuda" else t.pin_memory().to(device, non_blocking=True)
+        return mv(b), mv(s), mv(tt), mv(tr)
 
     def _losses(self, outputs, gathered):
         b, s, tt, tr = gathered
@@ -227,6 +242,9 @@ class SetCriterion(nn.Module):
 
     def forward(self, outputs, targets, n_boxes):
         main = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
+        for aux in outputs.get("aux_outputs", []):
+            if "_pred_boxes_host" in outputs:
+                aux["_pred_boxes_host"] = outputs["_pred_boxes_host"]
         dev = outputs["pred_translation"].device
         indices = self.matcher(main, targets, n_boxes)
         gathered, last = self._gather_targets(targets, indices, dev), indices

@@ -38,23 +38,35 @@ class CastFn(torch.autograd.Function):
 class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, pos, level_embed, ref, mask, geom, cfg, names, *params):
-        """src,pos (N,S,d) T; ref (N,S,L,2) fp32; mask (N*S) uint8 or None; cfg dict(M,P,p,training,n_layers)."""
+        """src (N,S,d) residual-stream dtype; pos (N,S,d); ref (N,S,L,2) fp32; mask (N*S) uint8 or None;
+        cfg dict(M,P,p,training,n_layers,act).  Returns (memory, memory16): the stream and its bf16 GEMM-operand copy
+        (the same tensor in the pure modes); memory16 is non-differentiable, gradients flow through `memory`."""
         N, S, d = src.shape
         x = src.reshape(N * S, d)
+        act = cfg.get("act") or src.dtype
+        if act != x.dtype:
+            x16 = torch.empty((N * S, d), dtype=act, device=src.device)
+            ops.cast(x, x16)
+        else:
+            x16 = x
         pos2 = pos.reshape(N * S, d)
         saved = []
         for i in range(cfg["n_layers"]):
             P_ = _pdict(names, params, f"layers.{i}.")
-            x, sv = B.enc_layer_fwd(x, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"], cfg["training"],
-                                       cfg.get("act"))
+            x, x16, sv = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
+                                         cfg["training"], cfg.get("act"))
             saved.append(sv)
         ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
         ctx.ref, ctx.mask, ctx.level_embed, ctx.shape = ref, mask, level_embed, (N, S, d)
         ctx.need_src = src.requires_grad
-        return x.view(N, S, d)
+        mem, mem16 = x.view(N, S, d), x16.view(N, S, d)
+        if mem16 is mem or mem16.data_ptr() == mem.data_ptr():
+            mem16 = mem.detach()
+        ctx.mark_non_differentiable(mem16)
+        return mem, mem16
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _unused=None):
         N, S, d = ctx.shape
         cfg, geom, names, params = ctx.cfg, ctx.geom, ctx.names, ctx.params
         G = B.GradSink(list(names) + ["level_embed"], list(params) + [ctx.level_embed])
@@ -75,12 +87,14 @@ class EncoderFn(torch.autograd.Function):
 # ====================================================================================================
 class DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, memory, tgt, qpos, ref_in, mask, geom, cfg, names, *params):
-        """memory (N,S,d) T; tgt,qpos (N,Q,d) fp32; ref_in (N,Q,L,2) fp32.  Returns hs (n_layers,N,Q,d) fp32."""
+    def forward(ctx, memory, memory16, tgt, qpos, ref_in, mask, geom, cfg, names, *params):
+        """memory (N,S,d): differentiable handle in the residual-stream dtype; memory16: the copy the value projections
+        actually read (bf16 in the bf16 policy); tgt,qpos (N,Q,d) fp32; ref_in (N,Q,L,2) fp32.
+        Returns hs (n_layers,N,Q,d) fp32."""
         N, S, d = memory.shape
         Q, M = tgt.shape[1], cfg["M"]
         D = d // M
-        mem2 = memory.reshape(N * S, d)
+        mem2 = memory16.reshape(N * S, d)
         x = tgt.reshape(N * Q, d).contiguous()
         qp = qpos.reshape(N * Q, d).contiguous()
         hs = torch.empty((cfg["n_layers"], N, Q, d), dtype=torch.float32, device=memory.device)
@@ -94,6 +108,7 @@ class DecoderFn(torch.autograd.Function):
             saved.append(sv)
         ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
         ctx.mem2, ctx.ref_in, ctx.mask, ctx.dims = mem2, ref_in, mask, (N, S, d, Q)
+        ctx.mem_dtype = memory.dtype
         ctx.need_mem, ctx.need_tgt = memory.requires_grad, tgt.requires_grad
         return hs
 
@@ -105,7 +120,7 @@ class DecoderFn(torch.autograd.Function):
         D = d // M
         G = B.GradSink(names, params)
         dhs = dhs.contiguous()
-        dmem = torch.empty((N * S, d), dtype=ctx.mem2.dtype, device=dhs.device) if ctx.need_mem else None
+        dmem = torch.empty((N * S, d), dtype=ctx.mem_dtype, device=dhs.device) if ctx.need_mem else None
         dx = None
         first = True
         for i in reversed(range(cfg["n_layers"])):
@@ -126,7 +141,7 @@ class DecoderFn(torch.autograd.Function):
         announce("1_decoder")
         dmemory = dmem.view(N, S, d) if ctx.need_mem else None
         dtgt = dx.view(N, Q, d) if ctx.need_tgt else None
-        return (dmemory, dtgt, None, None, None, None, None, None, *G.ret)
+        return (dmemory, None, dtgt, None, None, None, None, None, None, *G.ret)
 
 
 # ====================================================================================================

@@ -193,12 +193,12 @@ class DeformableTransformerDecoder(nn.Module):
         self.bbox_embed = None
         self.class_embed = None
 
-    def run(self, memory, tgt, qpos, ref_in, mask_u8, geom: LevelGeom, act=None):
+    def run(self, memory, memory16, tgt, qpos, ref_in, mask_u8, geom: LevelGeom, act=None):
         l0 = self.layers[0]
         cfg = dict(M=l0.cross_attn.n_heads, P=l0.cross_attn.n_points, p=l0.dropout1.p, training=self.training,
                    n_layers=self.num_layers, act=act)
         names, params = _named(self.layers, "layers.")
-        return Fn.DecoderFn.apply(memory, tgt, qpos, ref_in, mask_u8, geom, cfg, names, *params)
+        return Fn.DecoderFn.apply(memory, memory16, tgt, qpos, ref_in, mask_u8, geom, cfg, names, *params)
 
 
 class DeformableTransformer(nn.Module):
@@ -260,11 +260,11 @@ class DeformableTransformer(nn.Module):
         mask_flat = torch.cat([m.reshape(N, -1) for m in masks_u8], 1).contiguous().view(-1)
         ref = torch.empty((N, S, geom.L, 2), dtype=torch.float32, device=dev)
         ops.enc_ref_points(vr, geom, ref, N)
-        memory = self.encoder.run(src, pos, self.level_embed, ref, mask_flat, geom, self.act_dtype)
+        memory, memory16 = self.encoder.run(src, pos, self.level_embed, ref, mask_flat, geom, self.act_dtype)
         Q = tgt.shape[1]
         ref_in = torch.empty((N, Q, geom.L, 2), dtype=torch.float32, device=dev)
         ops.dec_ref_points(reference_points.contiguous(), vr, ref_in, N, Q, geom.L)
-        hs = self.decoder.run(memory, tgt, qpos, ref_in, mask_flat, geom, self.act_dtype)
+        hs = self.decoder.run(memory, memory16, tgt, qpos, ref_in, mask_flat, geom, self.act_dtype)
         self._last_memory = memory
         return hs
 
@@ -276,7 +276,7 @@ class DeformableTransformer(nn.Module):
         geom = LevelGeom([s.shape[-2:] for s in srcs])
         N, d = srcs[0].shape[0], srcs[0].shape[1]
         src = Fn_flatten(srcs, geom, self.stream_dtype)
-        pos = torch.empty((N, geom.S, d), dtype=self.stream_dtype, device=src.device)
+        pos = torch.empty((N, geom.S, d), dtype=self.act_dtype, device=src.device)
         for l, p in enumerate(pos_embeds):
             h, w = geom.shapes[l]
             ops.nchw_to_tokens(p.contiguous(), pos, N, d, h * w, geom.starts[l], geom.S)
@@ -397,6 +397,7 @@ class PoET(nn.Module):
         val = torch.from_numpy(valid).to(device, non_blocking=True)
         emb = torch.empty((N * Q, self.hidden_dim), dtype=torch.float32, device=device)
         ops.bbox_sine(pack.view(N * Q, 4), emb, N * Q, self.hidden_dim // 8, valid=val.view(-1), fill=-10.0)
+        self._boxes_host = boxes
         return emb.view(N, Q, -1), pack, cls, n_boxes
 
     def forward(self, samples, targets=None):
@@ -424,7 +425,7 @@ class PoET(nn.Module):
 
         names, params = _named(self.input_proj)
         src = Fn.InputProjFn.apply(feats, geom, 32, (act, stream), names, *params)
-        pos = torch.empty((N, geom.S, self.hidden_dim), dtype=stream, device=dev)
+        pos = torch.empty((N, geom.S, self.hidden_dim), dtype=act, device=dev)
         lvl_embed = tr.level_embed.detach().contiguous()
         for l, (h, w) in enumerate(geom.shapes):
             ops.pos_sine(masks[l], pos, lvl_embed[l], N, h, w, self.hidden_dim // 2, geom.starts[l], geom.S)
@@ -441,5 +442,6 @@ class PoET(nn.Module):
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_translation": t, "pred_rotation": r, "pred_boxes": pred_boxes,
                                    "pred_classes": pred_classes} for t, r in zip(trans[:-1], rot[:-1])]
+        out["_pred_boxes_host"] = self._boxes_host     # lets the matcher run without a device->host sync
         self._last_hs = hs
         return out, n_boxes

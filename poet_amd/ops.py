@@ -38,6 +38,66 @@ def _i64arr(vals: Sequence[int]):
     return (C.c_int64 * len(vals))(*[int(v) for v in vals])
 
 
+class _Profile:
+    """Optional per-launch timing with HIP events on the launch stream (torch.cuda.Event records on torch's current
+    stream, which is the stream every kernel here is enqueued on).  Off by default; bench.py switches it on for a few
+    extra steps to measure the roofline numbers.  Each record carries the launch's ALGORITHMIC flops and bytes."""
+
+    def __init__(self):
+        self.on = False
+        self.rec = []
+
+    def start(self):
+        self.on, self.rec = True, []
+
+    def stop(self):
+        self.on = False
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, e0, e1, fl, by in self.rec:
+            a = agg.setdefault(tag, dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            a["total_ms"] += e0.elapsed_time(e1)
+            a["launches"] += 1
+            a["flops"] += fl
+            a["bytes"] += by
+        self.rec = []
+        return agg
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, tag, e0, flops, nbytes):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append((tag, e0, e1, float(flops), float(nbytes)))
+
+    @staticmethod
+    def roofline(agg, steps, hbm_peak_gbs, mfma_peak_tfs):
+        """Roofline line for the kernel family that takes the most time."""
+        tag = max(agg, key=lambda k: agg[k]["total_ms"])
+        a = agg[tag]
+        sec = a["total_ms"] / 1e3
+        mfma = tag.startswith("gemm")
+        if mfma:
+            ach, peak, unit = a["flops"] / sec / 1e12, mfma_peak_tfs, "TFLOP/s"
+        else:
+            ach, peak, unit = a["bytes"] / sec / 1e9, hbm_peak_gbs, "GB/s"
+        return {"kernel": tag, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": a["launches"] / steps,
+                "avg_launch_us": round(1e3 * a["total_ms"] / a["launches"], 2),
+                "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]), "algorithmic_flops_per_launch": round(a["flops"] / a["launches"]),
+                "achieved_GBs_algorithmic": round(a["bytes"] / sec / 1e9, 1)}
+
+
+PROFILE = _Profile()
+
+
+def _esz(t):
+    return t.element_size()
+
+
 class LevelGeom:
     """Host-side multi-scale geometry: spatial shapes (H,W) per level and start offsets."""
 
@@ -82,6 +142,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         d.out_mode, d.hm_M, d.hm_S, d.hm_D = 1, *head_major
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
+    if PROFILE.on:
+        e0 = PROFILE.begin()
+        _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
+        kind = "gemm_dW" if (a_kmajor and atomic) else ("gemm_dX" if b_kmajor else "gemm_fwd")
+        nb = batch * (M * K * _esz(A) + M * N * _esz(Cout)) + N * K * _esz(B) * (batch if strideB else 1)
+        PROFILE.end(kind if M * N * K * batch > (1 << 28) else "gemm_small", e0, 2.0 * M * N * K * batch, nb)
+        return Cout
     _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
     return Cout
 
@@ -104,10 +171,10 @@ def linear_dx(dy: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, rows: int
 
 
 def _splitk_for(M, N, K):
-    big = M >= 512 and N >= 128
+    big = M >= 256 and N >= 128
     t = 128 if big else 64
     tiles = -(-M // t) * -(-N // t)
-    return max(1, min(-(-1024 // tiles), -(-K // 256)))
+    return max(1, min(-(-1024 // tiles), -(-K // 512)))
 
 
 def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None):
@@ -157,10 +224,10 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 
 
 # ---- norms -----------------------------------------------------------------------------------------
-def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0):
+def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None):
     lib = _lib.load()
     _lib.check(lib.poet_ln_fwd(_req(x, "x").data_ptr(), _ptr(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(z),
-                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y), _stream()), "poet_ln_fwd")
+                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y), _ptr(y16), _stream()), "poet_ln_fwd")
     return y
 
 
@@ -258,7 +325,8 @@ def enc_ref_points(valid_ratios, geom: LevelGeom, ref, N):
 # ---- elementwise / layout --------------------------------------------------------------------------
 def add(a, b, out):
     lib = _lib.load()
-    _lib.check(lib.poet_add(_req(a, "a").data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), dcode(a), _stream()), "poet_add")
+    _lib.check(lib.poet_add(_req(a, "a").data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), dcode(a), dcode(b), dcode(out), _stream()),
+               "poet_add")
     return out
 
 
@@ -319,3 +387,27 @@ def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, sqnorm_buf=None, max_n
     lib = _lib.load()
     _lib.check(lib.poet_adamw(_req(p, "p").data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), n, lr, beta1, beta2,
                               eps, wd, step, _ptr(sqnorm_buf), max_norm, grad_scale, _stream()), "poet_adamw")
+
+
+# ---- optional timing of the non-GEMM kernels (algorithmic bytes = every tensor argument touched once) -------------
+def _instrument(name, tag):
+    fn = globals()[name]
+
+    def wrapped(*a, **k):
+        if not PROFILE.on:
+            return fn(*a, **k)
+        e0 = PROFILE.begin()
+        r = fn(*a, **k)
+        nb = sum(t.numel() * t.element_size() for t in list(a) + list(k.values()) if torch.is_tensor(t))
+        PROFILE.end(tag, e0, 0.0, nb)
+        return r
+
+    wrapped.__name__ = name
+    globals()[name] = wrapped
+
+
+for _n, _t in [("msda_fused_fwd", "msda_fused_fwd"), ("msda_fused_bwd", "msda_fused_bwd"), ("ln_fwd", "ln_fwd"), ("ln_bwd", "ln_bwd"),
+               ("colsum", "colsum"), ("vgrad_to_rows", "vgrad_to_rows"), ("add", "add"), ("cast", "cast"),
+               ("groupnorm_fwd", "groupnorm"), ("groupnorm_bwd", "groupnorm"), ("mha_fwd", "mha"), ("mha_bwd", "mha"),
+               ("pos_sine", "pos_sine"), ("adamw", "adamw"), ("sqnorm", "sqnorm")]:
+    _instrument(_n, _t)
