@@ -189,6 +189,7 @@ def main():
     for _ in range(args.steps):
         total, loss_dict = trainer.step(samples, targets)
         poet_amd.reduce_dict(loss_dict)                          # engine.py:61 (logging all-reduce), no .item()
+    t_enq = time.perf_counter() - t0                              # host time to ENQUEUE the K steps (no device sync inside)
     sync()
     elapsed = time.perf_counter() - t0
     prof, prof_steps = None, 3
@@ -222,7 +223,8 @@ def main():
                        "global_batch": world * batch, "tokens_per_image": sum(h * w for h, w in cfg["level_hw"]),
                        "parallelism": f"dp{world}", "precision_policy": args.precision,
                        "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
-                       "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4)},
+                       "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4),
+                       "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 3)},
         }
         if prof is not None:
             out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)

@@ -132,7 +132,10 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
                         const float* ref, int64_t ref_batch_stride, const void* grad_out,
                         float* grad_value, void* grad_offattn,
                         int N, int S, int M, int D, int L, int P, int Lq,
-                        int v_dtype, int q_dtype, void* stream);
+                        int v_dtype, int q_dtype,
+                        int grid_queries /* 1: query q is pixel q of the flattened levels (encoder self-attention):
+                                            enables the LDS-privatised value-gradient scatter */,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * y = LayerNorm(res + dropout(x)) over the last dim d (d % 4 == 0, d <= 1024), one wave per row.

@@ -97,11 +97,12 @@ def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P
 
 
 def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P, dV, g_so_w, g_so_b, g_aw_w, g_aw_b,
-               dq, dq_accumulate, seg_sums=None):
+               dq, dq_accumulate, seg_sums=None, grid_queries=False):
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
     dOA = torch.empty_like(OA)
-    ops.msda_fused_bwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq)
+    ops.msda_fused_bwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
+                       grid_queries=grid_queries)
     ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldq)
     ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldq)
     if seg_sums is not None:      # per-level column sums (encoder): feeds both the biases and level_embed
@@ -217,7 +218,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
                sv["V"], geom, ref, ref_bs, N, S, M, D, npts, dV,
                g("self_attn.sampling_offsets.weight"), g("self_attn.sampling_offsets.bias"),
                g("self_attn.attention_weights.weight"), g("self_attn.attention_weights.bias"),
-               dsrc, True, seg_sums=seg)
+               dsrc, True, seg_sums=seg, grid_queries=True)
     # d(level_embed)[l] += colsum_l(dOA) @ [W_so ; W_aw]   (pos = sine + level_embed, q = src + pos)
     if g_level is not None:
         so_w, aw_w = P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"]

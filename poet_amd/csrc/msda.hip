@@ -13,6 +13,8 @@
 // FUSED variants take the raw sampling_offsets / attention_weights Linear outputs and fold in the
 // softmax over L*P, loc = ref + off/(W,H) and (backward) the softmax Jacobian, so neither the fp32
 // locations nor the weights are ever materialised in HBM.
+#include <stdlib.h>
+
 #include "common.cuh"
 
 namespace poet {
@@ -37,6 +39,7 @@ struct MsdaP {
     int H[MAXL], W[MAXL], start[MAXL];
     int64_t total;       // N*Lq*M*(D/8) threads
     int groups, tpg;     // channel groups per row, per head
+    int grid_queries;    // queries are the pixels of the flattened levels, in order (encoder self-attention)
 };
 
 template <typename TQ, int P>
@@ -284,11 +287,195 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
     }
 }
 
+// d(value) for GRID queries (encoder self-attention: query q IS pixel q of the flattened levels): LDS-privatised
+// scatter.  One workgroup = (spatial tile, head, image).  It owns every query whose pixel centre falls in the tile (at
+// all levels), accumulates their contributions into fp32 LDS windows (tile + halo of each level) with ds_add_f32, and
+// flushes each window once with coalesced global atomics; a sample whose corner falls outside the window (large
+// learned offset, padded image) goes straight to a global atomic, so the result never depends on the halo.
+// Global atomics drop from (16 points x 4 corners x D) per (query, head) to ~(window pixels x D) per workgroup (~20x).
+struct TileP { int TX, TY, HALO; };
+
+__device__ __forceinline__ int cdiv_i(int a, int b) { return (a >= 0) ? (a + b - 1) / b : -((-a) / b); }
+
+template <typename TQ, int L, int P>
+__global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, const TileP tp) {
+    // LDS windows are INT32 FIXED POINT: ds_add_u32 sustains ~6.8 T lane-ops/s on MI355X, ds_add_f32 only ~0.2 T/s
+    // (measured), i.e. float LDS atomics are no faster than L2 atomics.  Scale = 2^k per workgroup with
+    // max|grad_out| * 2^k ~ 2^18: resolution 4e-6 of the tile's largest gradient, 2^13 contributions of headroom.
+    // Used for bf16 storage only (the fp32 parity path keeps the exact float scatter).
+    extern __shared__ __attribute__((aligned(16))) int win[];
+    __shared__ float s_red[4];
+    constexpr int LP = L * P;
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m = blockIdx.y, n = blockIdx.z;
+    const int D = p.D;
+    int wx0[L], wy0[L], ww[L], wh[L], loff[L + 1];           // loff in pixels
+    loff[0] = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int W = p.W[l], H = p.H[l];
+        const int ax = max((tx * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((tx + 1) * W, tp.TX) + tp.HALO, W);
+        const int ay = max((ty * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((ty + 1) * H, tp.TY) + tp.HALO, H);
+        wx0[l] = ax; wy0[l] = ay; ww[l] = bx - ax; wh[l] = by - ay;
+        loff[l + 1] = loff[l] + ww[l] * wh[l];
+    }
+    for (int i = tid; i < loff[L] * D; i += 256) win[i] = 0;
+
+    const int c = tid % D, slot = tid / D, nslots = 256 / D;
+    const TQ* gob = reinterpret_cast<const TQ*>(p.grad_out) + (int64_t)m * D + c;
+    const int64_t gstride = (int64_t)p.M * D;
+
+    // pass 1: max |grad_out| over this tile's queries -> power-of-two scale
+    float gm = 0.f;
+#pragma unroll 1
+    for (int lq = 0; lq < L; ++lq) {
+        const int W = p.W[lq], H = p.H[lq];
+        const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
+        const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
+        const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
+        for (int i = slot; i < nq; i += nslots) {
+            const int64_t row = (int64_t)n * p.Lq + p.start[lq] + (qy0 + i / qw) * W + qx0 + i % qw;
+            gm = fmaxf(gm, fabsf(io<TQ>::ld(gob + row * gstride)));
+        }
+    }
+    gm = wave_max(gm);
+    if ((tid & 63) == 0) s_red[tid >> 6] = gm;
+    __syncthreads();                                         // also orders the window zero-fill
+    gm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    if (!(gm > 0.f) || !(gm < 3.0e38f)) return;               // nothing to scatter (uniform across the workgroup)
+    int ex;
+    (void)frexpf(gm, &ex);                                    // gm in [2^(ex-1), 2^ex)
+    const float scale = ldexpf(1.f, 18 - ex), inv = ldexpf(1.f, ex - 18);
+
+    float* gvb = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;
+#pragma unroll 1
+    for (int lq = 0; lq < L; ++lq) {
+        const int W = p.W[lq], H = p.H[lq];
+        const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
+        const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
+        const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
+        for (int i = slot; i < nq; i += nslots) {
+            const int q = p.start[lq] + (qy0 + i / qw) * W + qx0 + i % qw;
+            const int64_t row = (int64_t)n * p.Lq + q;
+            const float gs = io<TQ>::ld(gob + row * gstride) * scale;
+            // ---- lane j (< L*P) of the slot prepares sample point j ----
+            const int j = c;
+            const bool has = j < LP;
+            const int l = has ? j / P : 0;
+            const TQ* qrow = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq;
+            float lg = has ? io<TQ>::ld(qrow + p.logit_col + m * LP + j) : -3.0e38f;
+            float mx = lg;
+            for (int o = 1; o < 16 && o < D; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float e = has ? __expf(lg - mx) : 0.f, sum = e;
+            for (int o = 1; o < 16 && o < D; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float aj = e / sum;
+            int cidx[4];
+            float cw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cidx[k] = -1; cw[k] = 0.f; }
+            if (has) {
+                const int Wl = p.W[l], Hl = p.H[l];
+                const float* rp = p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * L + l) * 2;
+                float px = io<TQ>::ld(qrow + (m * LP + j) * 2) + rp[0] * (float)Wl - 0.5f;
+                float py = io<TQ>::ld(qrow + (m * LP + j) * 2 + 1) + rp[1] * (float)Hl - 0.5f;
+                px = fminf(fmaxf(px, -2.f), (float)Wl + 1.f);
+                py = fminf(fmaxf(py, -2.f), (float)Hl + 1.f);
+                const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
+                const int x0 = (int)x0f, y0 = (int)y0f;
+                // window geometry of level l (runtime l: select from the unrolled per-level registers)
+                int lwx0 = wx0[0], lwy0 = wy0[0], lww = ww[0], lwh = wh[0], lo = loff[0];
+#pragma unroll
+                for (int t = 1; t < L; ++t)
+                    if (l == t) { lwx0 = wx0[t]; lwy0 = wy0[t]; lww = ww[t]; lwh = wh[t]; lo = loff[t]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+                    const float wgt = ((k & 1) ? fx : 1.f - fx) * ((k >> 1) ? fy : 1.f - fy) * aj;
+                    if (xx >= 0 && xx < Wl && yy >= 0 && yy < Hl && wgt != 0.f) {
+                        const int lx = xx - lwx0, ly = yy - lwy0;
+                        cw[k] = wgt;
+                        cidx[k] = (lx >= 0 && lx < lww && ly >= 0 && ly < lwh) ? lo + ly * lww + lx
+                                                                                 : -2 - (p.start[l] + yy * Wl + xx);
+                    }
+                }
+            }
+            // ---- broadcast point by point to the channel lanes; int32 LDS accumulate ----
+#pragma unroll 4
+            for (int pt = 0; pt < LP; ++pt) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ii = __shfl(cidx[k], pt, D <= 64 ? D : 64);
+                    const float wv = __shfl(cw[k], pt, D <= 64 ? D : 64);
+                    if (ii >= 0) atomicAdd(&win[ii * D + c], __float2int_rn(wv * gs));
+                    else if (ii <= -2) atomicAdd(gvb + (int64_t)(-2 - ii) * p.vs_s, wv * gs * inv);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int cnt = ww[l] * wh[l] * D;
+        for (int i = tid; i < cnt; i += 256) {
+            const int v = win[loff[l] * D + i];
+            if (v != 0) {
+                const int cc = i % D, pix = i / D;
+                const int xx = wx0[l] + pix % ww[l], yy = wy0[l] + pix / ww[l];
+                atomicAdd(p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)(p.start[l] + yy * p.W[l] + xx) * p.vs_s + cc,
+                          (float)v * inv);
+            }
+        }
+    }
+}
+
+// host: pick the tile grid / halo so the windows fit the LDS budget; returns bytes (0 = do not use the tiled kernel)
+static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
+    if (p.D < 16 || p.D > 64 || 256 % p.D != 0) return 0;
+    const int budget = 72 * 1024;                          // two workgroups per CU
+    for (int halo = 4; halo >= 2; halo -= 2) {
+        for (int t = 1; t <= 16; t *= 2) {
+            const int TX = min(t, max(p.W[0] / 4, 1)), TY = min(t, max(p.H[0] / 4, 1));
+            size_t worst = 0;
+            for (int ty = 0; ty < TY; ++ty)
+                for (int tx = 0; tx < TX; ++tx) {
+                    size_t fl = 0;
+                    for (int l = 0; l < L; ++l) {
+                        const int W = p.W[l], H = p.H[l];
+                        const int ax = max((tx * W) / TX - halo, 0), bx = min(cdiv((int64_t)(tx + 1) * W, TX) + halo, W);
+                        const int ay = max((ty * H) / TY - halo, 0), by = min(cdiv((int64_t)(ty + 1) * H, TY) + halo, H);
+                        fl += (size_t)(bx - ax) * (by - ay) * p.D;
+                    }
+                    worst = max(worst, fl);
+                }
+            if (worst * 4 <= (size_t)budget) { tp.TX = TX; tp.TY = TY; tp.HALO = halo; return worst * 4; }
+        }
+    }
+    return 0;
+}
+
+template <typename TQ, int L>
+static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
+    if (P != 4 || L * P > 16 || sizeof(TQ) != 2) return false;
+    TileP tp{};
+    const size_t lds = plan_tiles(p, L, tp);
+    { const char* e = getenv("POET_NO_TILED_SCATTER"); if (e && atoi(e)) return false; }
+    if (!lds) return false;
+    auto kern = msda_bwd_dv_tiled_kernel<TQ, L, 4>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(256), lds, st, p, tp);
+    return true;
+}
+
 template <typename TV, typename TQ, int L, bool FUSED, bool BWD>
 static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     dim3 grid(cdiv(p.total, 256)), block(256);
     dim3 gridv(cdiv(p.total * 8, 256));
-    if (BWD) {
+    bool dv_done = false;
+    if constexpr (BWD && FUSED) {
+        if (p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
+    }
+    if (BWD && !dv_done) {
         if (P == 4) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 4, FUSED>), gridv, block, 0, st, p);
         else if (P == 2) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 2, FUSED>), gridv, block, 0, st, p);
         else hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 1, FUSED>), gridv, block, 0, st, p);
@@ -415,7 +602,7 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
                                    const int64_t* starts, const void* offattn, int64_t ldq, int logit_col,
                                    const float* ref, int64_t ref_bs, const void* grad_out, float* grad_value,
                                    void* grad_offattn, int N, int S, int M, int D, int L, int P, int Lq,
-                                   int v_dtype, int q_dtype, void* stream) {
+                                   int v_dtype, int q_dtype, int grid_queries, void* stream) {
     MsdaP p{};
     int rc = fill_common(p, shapes, starts, N, S, M, D, L, P, Lq);
     if (rc) return rc;
@@ -423,6 +610,7 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
     if (rc) return rc;
     POET_CHECK(grad_out && grad_value && grad_offattn, POET_ERR_ARG, "msda_fused_bwd: null pointer");
     p.grad_out = grad_out; p.grad_value = grad_value; p.g1 = grad_offattn;
+    p.grid_queries = grid_queries;
     rc = dispatch<true, true>(p, L, P, v_dtype, q_dtype, (hipStream_t)stream);
     if (rc) return rc;
     POET_LAUNCH_CHECK();

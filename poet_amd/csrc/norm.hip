@@ -160,6 +160,19 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// channel-group row access: cpg == 8 (d_model 256 / 32 groups) is one 16-B (bf16) or 32-B (f32) vector per token
+template <typename T>
+__device__ __forceinline__ void gn_ld(const T* p, float* v, int cpg, bool vec8) {
+    if (vec8) vec<T, 8>::ld(p, v);
+    else for (int c = 0; c < cpg; ++c) v[c] = io<T>::ld(p + c);
+}
+template <typename T>
+__device__ __forceinline__ void gn_st(T* p, const float* v, int cpg, bool vec8) {
+    if (vec8) vec<T, 8>::st(p, v);
+    else for (int c = 0; c < cpg; ++c) io<T>::st(p + c, v[c]);
+}
+constexpr int GN_MAXCPG = 8;
+
 template <typename T, typename TY>
 __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TY* __restrict__ y,
@@ -169,23 +182,28 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* __restrict__ x, co
     __shared__ float sm[4];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G;
+    const bool vec8 = (cpg == 8);
     const T* xb = x + ((int64_t)n * x_stride + x_off) * C + g * cpg;
     TY* yb = y + ((int64_t)n * y_stride + y_off) * C + g * cpg;
-    float s = 0.f;
-    for (int hw = threadIdx.x; hw < HW; hw += 256)
-        for (int c = 0; c < cpg; ++c) s += io<T>::ld(xb + (int64_t)hw * C + c);
+    float s = 0.f, q = 0.f;
+    for (int hw = threadIdx.x; hw < HW; hw += 256) {
+        float v[GN_MAXCPG];
+        gn_ld<T>(xb + (int64_t)hw * C, v, cpg, vec8);
+        for (int c = 0; c < cpg; ++c) { s += v[c]; q += v[c] * v[c]; }
+    }
     const float cnt = (float)HW * (float)cpg;
     const float mu = block_sum(s, sm) / cnt;
-    float q = 0.f;
-    for (int hw = threadIdx.x; hw < HW; hw += 256)
-        for (int c = 0; c < cpg; ++c) { const float t = io<T>::ld(xb + (int64_t)hw * C + c) - mu; q += t * t; }
-    const float rs = rsqrtf(block_sum(q, sm) / cnt + eps);
+    const float var = fmaxf(block_sum(q, sm) / cnt - mu * mu, 0.f);
+    const float rs = rsqrtf(var + eps);
     if (threadIdx.x == 0) { stats[(n * G + g) * 2] = mu; stats[(n * G + g) * 2 + 1] = rs; }
-    for (int hw = threadIdx.x; hw < HW; hw += 256)
-        for (int c = 0; c < cpg; ++c) {
-            const float v = (io<T>::ld(xb + (int64_t)hw * C + c) - mu) * rs * gamma[g * cpg + c] + beta[g * cpg + c];
-            io<TY>::st(yb + (int64_t)hw * C + c, v);
-        }
+    float gm[GN_MAXCPG], bt[GN_MAXCPG];
+    for (int c = 0; c < cpg; ++c) { gm[c] = gamma[g * cpg + c]; bt[c] = beta[g * cpg + c]; }
+    for (int hw = threadIdx.x; hw < HW; hw += 256) {
+        float v[GN_MAXCPG];
+        gn_ld<T>(xb + (int64_t)hw * C, v, cpg, vec8);
+        for (int c = 0; c < cpg; ++c) v[c] = (v[c] - mu) * rs * gm[c] + bt[c];
+        gn_st<TY>(yb + (int64_t)hw * C, v, cpg, vec8);
+    }
 }
 
 template <typename T, typename TY>
@@ -197,33 +215,34 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const TY* __restrict__ dy, 
     __shared__ float sm[4];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G;
+    const bool vec8 = (cpg == 8);
     const int64_t base = ((int64_t)n * x_stride + x_off) * C + g * cpg;
     const int64_t ybase = ((int64_t)n * y_stride + y_off) * C + g * cpg;
     const float mu = stats[(n * G + g) * 2], rs = stats[(n * G + g) * 2 + 1];
+    float pg[GN_MAXCPG], pb[GN_MAXCPG], gm[GN_MAXCPG];
+    for (int c = 0; c < cpg; ++c) { pg[c] = 0.f; pb[c] = 0.f; gm[c] = gamma[g * cpg + c]; }
+    for (int hw = threadIdx.x; hw < HW; hw += 256) {
+        float d[GN_MAXCPG], v[GN_MAXCPG];
+        gn_ld<TY>(dy + ybase + (int64_t)hw * C, d, cpg, vec8);
+        gn_ld<T>(x + base + (int64_t)hw * C, v, cpg, vec8);
+        for (int c = 0; c < cpg; ++c) { pg[c] += d[c] * (v[c] - mu) * rs; pb[c] += d[c]; }
+    }
     float s1 = 0.f, s2 = 0.f;
     for (int c = 0; c < cpg; ++c) {
-        float pg = 0.f, pb = 0.f;
-        const float gmc = gamma[g * cpg + c];
-        for (int hw = threadIdx.x; hw < HW; hw += 256) {
-            const float d = io<TY>::ld(dy + ybase + (int64_t)hw * C + c);
-            const float xh = (io<T>::ld(x + base + (int64_t)hw * C + c) - mu) * rs;
-            pg += d * xh;
-            pb += d;
-        }
-        pg = block_sum(pg, sm);
-        pb = block_sum(pb, sm);
-        if (threadIdx.x == 0) { atomicAdd(dgamma + g * cpg + c, pg); atomicAdd(dbeta + g * cpg + c, pb); }
-        s1 += gmc * pb;
-        s2 += gmc * pg;
+        const float tg = block_sum(pg[c], sm), tb = block_sum(pb[c], sm);
+        if (threadIdx.x == 0) { atomicAdd(dgamma + g * cpg + c, tg); atomicAdd(dbeta + g * cpg + c, tb); }
+        s1 += gm[c] * tb;
+        s2 += gm[c] * tg;
     }
     const float cnt = (float)HW * (float)cpg;
     const float m1 = s1 / cnt, m2 = s2 / cnt;
-    for (int hw = threadIdx.x; hw < HW; hw += 256)
-        for (int c = 0; c < cpg; ++c) {
-            const float d = io<TY>::ld(dy + ybase + (int64_t)hw * C + c) * gamma[g * cpg + c];
-            const float xh = (io<T>::ld(x + base + (int64_t)hw * C + c) - mu) * rs;
-            io<T>::st(dx + base + (int64_t)hw * C + c, rs * (d - m1 - xh * m2));
-        }
+    for (int hw = threadIdx.x; hw < HW; hw += 256) {
+        float d[GN_MAXCPG], v[GN_MAXCPG];
+        gn_ld<TY>(dy + ybase + (int64_t)hw * C, d, cpg, vec8);
+        gn_ld<T>(x + base + (int64_t)hw * C, v, cpg, vec8);
+        for (int c = 0; c < cpg; ++c) v[c] = rs * (d[c] * gm[c] - m1 - (v[c] - mu) * rs * m2);
+        gn_st<T>(dx + base + (int64_t)hw * C, v, cpg, vec8);
+    }
 }
 
 }  // namespace poet
@@ -280,7 +299,7 @@ extern "C" int poet_groupnorm_fwd(const void* x, const float* gamma, const float
                                   int HW, int C, int G, int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride,
                                   float eps, int dtype_x, int dtype_y, void* stream) {
     POET_CHECK(x && gamma && beta && y && stats, POET_ERR_ARG, "groupnorm_fwd: null pointer");
-    POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0, POET_ERR_ARG, "groupnorm_fwd: bad dims");
+    POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= GN_MAXCPG, POET_ERR_ARG, "groupnorm_fwd: bad dims (C/G must be <= 8)");
     dim3 grid(N * G), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define GN_FWD(TX, TR) gn_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, HW, C, G, x_off, x_stride, y_off, y_stride, eps)
@@ -294,7 +313,7 @@ extern "C" int poet_groupnorm_bwd(const void* dy, const void* x, const float* st
                                   float* dgamma, float* dbeta, int N, int HW, int C, int G, int64_t x_off,
                                   int64_t x_stride, int64_t y_off, int64_t y_stride, int dtype_x, int dtype_y, void* stream) {
     POET_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta, POET_ERR_ARG, "groupnorm_bwd: null pointer");
-    POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0, POET_ERR_ARG, "groupnorm_bwd: bad dims");
+    POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= GN_MAXCPG, POET_ERR_ARG, "groupnorm_bwd: bad dims (C/G must be <= 8)");
     dim3 grid(N * G), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define GN_BWD(TX, TR) gn_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)x, stats, gamma, (TX*)dx, dgamma, dbeta, HW, C, G, x_off, x_stride, y_off, y_stride)

@@ -10,7 +10,14 @@ import torch
 from . import _lib
 from ._lib import BF16, F32, GemmDesc
 
+import struct as _struct
+
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
+# PoetGemmDesc as one packed record (natural C layout of include/poet_hip.h; checked against ctypes below)
+_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i")       # native alignment inserts the same padding as the C compiler
+assert _GEMM_PACK.size <= C.sizeof(GemmDesc) and GemmDesc.hm_D.offset + 4 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
+_GEMM_DESC = GemmDesc()
+_GEMM_BUF = (C.c_char * C.sizeof(GemmDesc)).from_buffer(_GEMM_DESC)
 
 
 def dcode(t: torch.Tensor) -> int:
@@ -20,8 +27,25 @@ def dcode(t: torch.Tensor) -> int:
         raise TypeError(f"poet_amd: unsupported dtype {t.dtype}") from None
 
 
+_STREAM_OVERRIDE = [None]
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream.  `with ops.pinned_stream():` resolves it once for a whole
+    forward/backward program (torch.cuda.current_stream() costs ~9 us per call, x ~700 launches per step)."""
+    s = _STREAM_OVERRIDE[0]
+    return s if s is not None else torch.cuda.current_stream().cuda_stream
+
+
+class pinned_stream:
+    def __enter__(self):
+        self.prev = _STREAM_OVERRIDE[0]
+        _STREAM_OVERRIDE[0] = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _STREAM_OVERRIDE[0] = self.prev
+        return False
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -124,24 +148,21 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
          row_mask=None, drop_p=0.0, seed=0, compute=None, batch=1, strideA=0, strideB=0, strideC=0, stride_bias=0,
          splitk=1, atomic=False, alpha=1.0, head_major=None):
     lib = _lib.load()
-    _req(A, "A"); _req(B, "B"); _req(Cout, "C")
-    d = GemmDesc()
-    d.A, d.A2, d.B, d.C = A.data_ptr(), None, B.data_ptr(), Cout.data_ptr()
-    d.bias, d.add_src, d.gate_ref, d.row_mask = _ptr(bias), _ptr(add_src), _ptr(gate_ref), _ptr(row_mask)
-    d.M, d.N, d.K = M, N, K
-    d.lda, d.ldb, d.ldc, d.ld_add = lda, ldb, ldc, ld_add
-    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
-    d.a_dtype, d.b_dtype, d.c_dtype = dcode(A), dcode(B), dcode(Cout)
+    if not (A.is_cuda and B.is_cuda and Cout.is_cuda):
+        raise _lib.PoetHipError("poet_amd: GEMM operands must live on the GPU (no CPU path exists)")
+    ad, bd, cd = _DT[A.dtype], _DT[B.dtype], _DT[Cout.dtype]
     if compute is None:     # bf16 MFMA as soon as any operand is stored in bf16; pure-fp32 calls use the f32 MFMA
-        compute = BF16 if torch.bfloat16 in (A.dtype, B.dtype, Cout.dtype) else F32
-    d.compute = compute
-    d.batch, d.strideA, d.strideB, d.strideC, d.stride_bias = batch, strideA, strideB, strideC, stride_bias
-    d.splitk, d.atomic, d.act = splitk, int(atomic), act
-    d.alpha, d.gate_scale, d.drop_p, d.seed = alpha, gate_scale, drop_p, seed & 0xFFFFFFFF
-    if head_major is not None:
-        d.out_mode, d.hm_M, d.hm_S, d.hm_D = 1, *head_major
+        compute = BF16 if (ad | bd | cd) else F32
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
+    hm = head_major or (0, 0, 0)
+    d = _GEMM_DESC
+    _GEMM_PACK.pack_into(_GEMM_BUF, 0, A.data_ptr(), 0, B.data_ptr(), Cout.data_ptr(),
+                         0 if bias is None else bias.data_ptr(), 0 if add_src is None else add_src.data_ptr(),
+                         0 if gate_ref is None else gate_ref.data_ptr(), 0 if row_mask is None else row_mask.data_ptr(),
+                         M, N, K, lda, ldb, ldc, ld_add, int(a_kmajor), int(b_kmajor), ad, bd, cd, compute, batch,
+                         strideA, strideB, strideC, stride_bias, splitk, int(atomic), act, alpha, gate_scale, drop_p,
+                         seed & 0xFFFFFFFF, 1 if head_major is not None else 0, hm[0], hm[1], hm[2])
     if PROFILE.on:
         e0 = PROFILE.begin()
         _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
@@ -215,12 +236,12 @@ def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 
 
 def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value,
-                   grad_offattn, N, M, D, P, Lq):
+                   grad_offattn, N, M, D, P, Lq, grid_queries=False):
     lib = _lib.load()
     _lib.check(lib.poet_msda_fused_bwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
                                        offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, grad_out.data_ptr(),
                                        grad_value.data_ptr(), grad_offattn.data_ptr(), N, geom.S, M, D, geom.L, P, Lq,
-                                       dcode(value), dcode(offattn), _stream()), "poet_msda_fused_bwd")
+                                       dcode(value), dcode(offattn), int(grid_queries), _stream()), "poet_msda_fused_bwd")
 
 
 # ---- norms -----------------------------------------------------------------------------------------

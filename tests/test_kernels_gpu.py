@@ -457,3 +457,38 @@ def test_layernorm_mixed(ops):
     ops.ln_bwd(dev(dy), z, mean, rstd, dev(gamma), dz, dx, dg, db, rows, d)
     _close(dz, zr.grad, torch.bfloat16, msg="mixed ln dz")
     _close(dx, zr.grad, torch.bfloat16, msg="mixed ln dx")
+
+
+@pytest.mark.parametrize("shapes,m,dt", [([(12, 16), (6, 8), (3, 4)], 4, torch.float32), ([(30, 40), (15, 20), (8, 10), (4, 5)], 2, torch.bfloat16),
+                                         ([(60, 80), (30, 40), (15, 20), (8, 10)], 1, torch.bfloat16)])
+def test_msda_fused_grid_queries_tiled_scatter(ops, shapes, m, dt):
+    """Encoder self-attention case (query q == pixel q): the LDS-privatised value-gradient scatter must equal the
+    plain scatter, including samples thrown far outside their tile's halo (global-atomic fallback)."""
+    n, d, p = 2, 16, 4
+    L = len(shapes)
+    geom = ops.LevelGeom(shapes)
+    S = geom.S
+    rng = np.random.default_rng(17)
+    value = torch.from_numpy(rng.standard_normal((n, m, S, d)).astype(np.float32)).to(dt)       # head-major
+    mlp = m * L * p
+    off = rng.standard_normal((n, S, 2 * mlp)) * 2.0
+    off[:, ::7] *= 12.0                                                                           # some far-away samples
+    oa = torch.from_numpy(np.concatenate([off, rng.standard_normal((n, S, mlp))], -1).astype(np.float32)).to(dt)
+    vr = torch.ones(n, L, 2)
+    ref = torch.empty(n, S, L, 2, device="cuda")
+    ops.enc_ref_points(dev(vr), geom, ref, n)
+    gout = torch.from_numpy(rng.standard_normal((n, S, m * d)).astype(np.float32)).to(dt)
+    vstr = (m * S * d, d, S * d)
+    outs = []
+    for grid in (False, True):
+        gv = torch.zeros(n, m, S, d, device="cuda")
+        goa = torch.empty_like(dev(oa))
+        ops.msda_fused_bwd(dev(value), vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv, goa, n, m, d, p, S,
+                           grid_queries=grid)
+        outs.append((gv.cpu(), goa.float().cpu()))
+    scale = outs[0][0].abs().max().item()
+    # fp32 storage keeps the exact float scatter; bf16 storage uses the int32 fixed-point LDS windows (resolution
+    # 2^-18 of the tile's largest |grad_out| per contribution)
+    tol = 2e-4 if dt == torch.float32 else 2e-3
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < tol * max(1.0, scale)
+    assert torch.equal(outs[0][1], outs[1][1])
