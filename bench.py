@@ -88,6 +88,27 @@ def gemm_flops_per_image(cfg):
     return enc + dec + heads + proj
 
 
+# HBM traffic per launch of a kernel family from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
+# WRITE_SIZE passes of this same command, profiles/collect_round1.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the
+# gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when the family is not in the summary.
+_PMC_NAMES = {"msda_bwd_dvalue_scatter": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_kernel<", "msda_fused_fwd": "msda_fwd_kernel",
+              "gemm_dW": "128, 128, 128, true, true>", "gemm_dX": "float, bf16, 128, 128, 128, false, true>",
+              "gemm_fwd": "bf16, bf16, 128, 128, 128, false, false>", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel"}
+
+
+def pmc_traffic_bytes(tag):
+    path = os.path.join(ROOT, "profiles", "round1_pmc_hbm.csv")
+    key = _PMC_NAMES.get(tag)
+    if key is None or not os.path.exists(path):
+        return None
+    import csv
+    rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))][1:]
+    for r in rows:
+        if key in r[0]:
+            return int((2 * float(r[2]) + float(r[4])) * 1024)
+    return None
+
+
 def build_model(cfg, feats, precision, device):
     import poet_amd
     from poet_amd.synthetic import SyntheticBackbone
@@ -228,6 +249,7 @@ def main():
         }
         if prof is not None:
             out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)
+            out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"])
             out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
                                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         if world == 1 and not args.no_cpu_baseline:

@@ -135,6 +135,8 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
                         int v_dtype, int q_dtype,
                         int grid_queries /* 1: query q is pixel q of the flattened levels (encoder self-attention):
                                             enables the LDS-privatised value-gradient scatter */,
+                        int parts /* 3 (or 0) = everything; 1 = only d(offsets|logits); 2 = only the d(value) scatter
+                                     -- lets a profiler time the two kernels of this call separately */,
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------

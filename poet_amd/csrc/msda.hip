@@ -40,6 +40,7 @@ struct MsdaP {
     int64_t total;       // N*Lq*M*(D/8) threads
     int groups, tpg;     // channel groups per row, per head
     int grid_queries;    // queries are the pixels of the flattened levels, in order (encoder self-attention)
+    int parts;           // backward: bit0 = d(offsets|logits)/d(loc,attn) kernel, bit1 = d(value) scatter kernel
 };
 
 template <typename TQ, int P>
@@ -471,15 +472,16 @@ template <typename TV, typename TQ, int L, bool FUSED, bool BWD>
 static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     dim3 grid(cdiv(p.total, 256)), block(256);
     dim3 gridv(cdiv(p.total * 8, 256));
-    bool dv_done = false;
+    bool dv_done = !(p.parts & 2);
     if constexpr (BWD && FUSED) {
-        if (p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
+        if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
     }
     if (BWD && !dv_done) {
         if (P == 4) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 4, FUSED>), gridv, block, 0, st, p);
         else if (P == 2) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 2, FUSED>), gridv, block, 0, st, p);
         else hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 1, FUSED>), gridv, block, 0, st, p);
     }
+    if (BWD && !(p.parts & 1)) return;
     if (P == 4) {
         if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 4, FUSED>), grid, block, 0, st, p);
@@ -562,6 +564,7 @@ extern "C" int poet_msda_bwd(const void* value, const int64_t* shapes, const int
     POET_CHECK(value && loc && attn && grad_out && grad_value && grad_loc && grad_attn, POET_ERR_ARG, "msda_bwd: null pointer");
     p.value = value; p.vs_n = (int64_t)S * M * D; p.vs_s = (int64_t)M * D; p.vs_m = D;
     p.q1 = loc; p.q2 = attn; p.grad_out = grad_out; p.grad_value = grad_value; p.g1 = grad_loc; p.g2 = grad_attn;
+    p.parts = 3;
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, (hipStream_t)stream);
     POET_CHECK(e == hipSuccess, POET_ERR_LAUNCH, "msda_bwd: memset failed: %s", hipGetErrorString(e));
     rc = dispatch<false, true>(p, L, P, dtype, dtype, (hipStream_t)stream);
@@ -602,7 +605,7 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
                                    const int64_t* starts, const void* offattn, int64_t ldq, int logit_col,
                                    const float* ref, int64_t ref_bs, const void* grad_out, float* grad_value,
                                    void* grad_offattn, int N, int S, int M, int D, int L, int P, int Lq,
-                                   int v_dtype, int q_dtype, int grid_queries, void* stream) {
+                                   int v_dtype, int q_dtype, int grid_queries, int parts, void* stream) {
     MsdaP p{};
     int rc = fill_common(p, shapes, starts, N, S, M, D, L, P, Lq);
     if (rc) return rc;
@@ -611,6 +614,7 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
     POET_CHECK(grad_out && grad_value && grad_offattn, POET_ERR_ARG, "msda_fused_bwd: null pointer");
     p.grad_out = grad_out; p.grad_value = grad_value; p.g1 = grad_offattn;
     p.grid_queries = grid_queries;
+    p.parts = (parts & 3) ? (parts & 3) : 3;
     rc = dispatch<true, true>(p, L, P, v_dtype, q_dtype, (hipStream_t)stream);
     if (rc) return rc;
     POET_LAUNCH_CHECK();

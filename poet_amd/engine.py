@@ -297,6 +297,20 @@ def reduce_dict(loss_dict: Dict[str, torch.Tensor], average=True):
         return dict(zip(names, vals))
 
 
+def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True):
+    """Batch sharding of the reference's DistributedSampler (data_utils/samplers.py:48-66): epoch-seeded permutation,
+    padded by wrap-around to a multiple of `world`, rank r takes the contiguous slice [r*n, (r+1)*n)."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(epoch)
+        idx = torch.randperm(n_items, generator=g).tolist()
+    else:
+        idx = list(range(n_items))
+    per = int(math.ceil(n_items / world))
+    idx += idx[: per * world - len(idx)]
+    return idx[per * rank: per * (rank + 1)]
+
+
 class Trainer:
     """One training step == engine.py:55-81 (forward, loss, zero_grad, backward, clip, AdamW)."""
 

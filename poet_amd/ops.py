@@ -236,12 +236,20 @@ def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 
 
 def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value,
-                   grad_offattn, N, M, D, P, Lq, grid_queries=False):
+                   grad_offattn, N, M, D, P, Lq, grid_queries=False, parts=3):
     lib = _lib.load()
+    if PROFILE.on and parts == 3:       # time the two kernels of the backward separately
+        a = (value, vstrides, geom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value, grad_offattn, N, M, D, P, Lq)
+        nb_q = offattn.numel() * offattn.element_size() * 2 + grad_out.numel() * grad_out.element_size() + value.numel() * value.element_size()
+        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2)
+        PROFILE.end("msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * 4)
+        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1)
+        PROFILE.end("msda_bwd_dq", e0, 0.0, nb_q)
+        return
     _lib.check(lib.poet_msda_fused_bwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
                                        offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, grad_out.data_ptr(),
                                        grad_value.data_ptr(), grad_offattn.data_ptr(), N, geom.S, M, D, geom.L, P, Lq,
-                                       dcode(value), dcode(offattn), int(grid_queries), _stream()), "poet_msda_fused_bwd")
+                                       dcode(value), dcode(offattn), int(grid_queries), parts, _stream()), "poet_msda_fused_bwd")
 
 
 # ---- norms -----------------------------------------------------------------------------------------
@@ -427,7 +435,7 @@ def _instrument(name, tag):
     globals()[name] = wrapped
 
 
-for _n, _t in [("msda_fused_fwd", "msda_fused_fwd"), ("msda_fused_bwd", "msda_fused_bwd"), ("ln_fwd", "ln_fwd"), ("ln_bwd", "ln_bwd"),
+for _n, _t in [("msda_fused_fwd", "msda_fused_fwd"), ("ln_fwd", "ln_fwd"), ("ln_bwd", "ln_bwd"),
                ("colsum", "colsum"), ("vgrad_to_rows", "vgrad_to_rows"), ("add", "add"), ("cast", "cast"),
                ("groupnorm_fwd", "groupnorm"), ("groupnorm_bwd", "groupnorm"), ("mha_fwd", "mha"), ("mha_bwd", "mha"),
                ("pos_sine", "pos_sine"), ("adamw", "adamw"), ("sqnorm", "sqnorm")]:

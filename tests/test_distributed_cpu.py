@@ -1,0 +1,116 @@
+"""Data-parallel plumbing on CPU: two `gloo` processes (world_size 2).  The HIP kernels cannot run here, so the
+gradient arena is filled with known per-rank values; what is checked is what the N>1 path adds on top of the
+single-GPU step: bucket layout, bucketed sum all-reduce in backward-completion order, the 1/world average folded
+into the optimiser scale, the logging all-reduce (util/misc.py:168-195) and the sampler sharding
+(data_utils/samplers.py:48-66)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Toy(nn.Module):
+    """Parameter names chosen to land in every arena bucket and LR group."""
+
+    def __init__(self):
+        super().__init__()
+        self.translation_head = nn.Linear(8, 3)
+        self.rotation_head = nn.Linear(8, 6)
+        self.transformer = nn.Module()
+        self.transformer.decoder = nn.Linear(8, 8)
+        self.transformer.encoder = nn.Module()
+        self.transformer.encoder.sampling_offsets = nn.Linear(8, 4)
+        self.transformer.encoder.linear1 = nn.Linear(8, 16)
+        self.transformer.level_embed = nn.Parameter(torch.zeros(2, 8))
+        self.transformer.reference_points = nn.Linear(8, 2)      # never gets a gradient: stays out of the arena
+        self.input_proj = nn.Linear(5, 8)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from poet_amd.engine import BucketReducer, ParamArena, reduce_dict, set_reducer, announce, shard_indices
+        torch.manual_seed(0)
+        model = _Toy()
+        arena = ParamArena(model)
+        names = [n for n, _, _ in arena.entries]
+        assert not any("reference_points" in n for n in names)
+        # buckets are contiguous, ordered by backward completion, and cover the arena exactly
+        tags = [b[0] for b in arena.buckets]
+        assert tags == ["0_heads", "1_decoder", "2_encoder", "3_input_proj", "4_proj"], tags
+        assert arena.buckets[0][1] == 0 and arena.buckets[-1][2] == arena.total
+        for (_, _, e), (_, s, _) in zip(arena.buckets[:-1], arena.buckets[1:]):
+            assert e == s
+        # the 0.1x LR group is exactly the sampling_offsets tail
+        assert arena.groups[1][0] == arena.n_main and arena.groups[1][2] == pytest.approx(arena.groups[0][2] * 0.1)
+        proj = [n for n, _, o in arena.entries if o >= arena.n_main]
+        assert proj and all("sampling_offsets" in n for n in proj)
+        # parameters are views of the flat buffer
+        p0 = model.input_proj.weight
+        assert p0.data_ptr() >= arena.flat.data_ptr() and p0._grad_view.data_ptr() >= arena.grad.data_ptr()
+
+        red = BucketReducer(arena)
+        assert red.world == world and arena.world == world
+        set_reducer(red)
+        arena.zero_grad()
+        for n, p, _ in arena.entries:                      # "kernels" write rank-dependent gradients in place
+            p._grad_view.fill_(float(rank + 1))
+        for tag in ["0_heads", "1_decoder", "2_encoder", "3_input_proj"]:   # order of the autograd nodes' announce()
+            announce(tag)
+        red.finish()                                       # reduces the un-announced 0.1x-LR tail too
+        set_reducer(None)
+        expect = float(sum(r + 1 for r in range(world)))
+        for n, p, _ in arena.entries:
+            assert torch.all(p._grad_view == expect), n
+        # a second step must reduce again (done-set is cleared)
+        for n, p, _ in arena.entries:
+            p._grad_view.fill_(1.0)
+        set_reducer(red); announce("0_heads"); red.finish(); set_reducer(None)
+        assert torch.all(arena.grad[arena.buckets[0][1]: arena.buckets[0][2]][:3] == float(world))
+
+        # logging all-reduce keeps the reference's semantics (sorted keys, averaged)
+        out = reduce_dict({"loss_b": torch.tensor(float(rank)), "loss_a": torch.tensor(2.0 * rank)})
+        assert float(out["loss_b"]) == pytest.approx(sum(range(world)) / world)
+        assert float(out["loss_a"]) == pytest.approx(2.0 * sum(range(world)) / world)
+
+        # sampler sharding == the reference's DistributedSampler (contiguous slice of the epoch-seeded permutation;
+        # note: torch's own sampler strides instead -- the reference's is the contract here)
+        g = torch.Generator(); g.manual_seed(3)
+        perm = torch.randperm(37, generator=g).tolist()
+        per = 19
+        perm += perm[: per * world - 37]
+        mine = shard_indices(37, rank, world, epoch=3)
+        assert mine == perm[per * rank: per * (rank + 1)] and len(mine) == per
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        assert sorted(set(sum(gathered, []))) == list(range(37))          # every sample is covered
+        q.put((rank, "ok"))
+    except Exception as e:                                  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_reducer_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res

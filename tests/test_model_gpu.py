@@ -205,3 +205,45 @@ def test_cpu_tensors_fail_loudly(gpu):
     from poet_amd import ops
     with pytest.raises(poet_amd.PoetHipError):
         ops.add(torch.zeros(8), torch.zeros(8), torch.zeros(8))
+
+
+def test_transformer_nchw_dropin_matches_oracle(gpu):
+    """`DeformableTransformer.forward(srcs, masks, pos_embeds, query_embed, reference_points)` with the reference's
+    NCHW signature (models/deformable_transformer.py:120-166): outputs, d(srcs) and parameter gradients vs the oracle."""
+    import poet_amd
+    from oracle import poet_ref
+    from oracle.formula import formula_fill
+    torch.manual_seed(3)
+    d, M, L, Q, N = 64, 4, 3, 5, 2
+    shapes = [(10, 12), (5, 6), (3, 3)]
+    ref_t = poet_ref.DeformableTransformer(d, M, 2, 2, 128, 0.0, True, L, 4, 4)
+    formula_fill(ref_t)
+    mine = poet_amd.DeformableTransformer(d, M, 2, 2, 128, 0.0, "relu", True, L, 4, 4)
+    mine.load_state_dict(ref_t.state_dict(), strict=True)
+    mine = mine.cuda().set_precision("fp32")
+    srcs = [torch.randn(N, d, h, w) for h, w in shapes]
+    masks = [torch.zeros(N, h, w, dtype=torch.bool) for h, w in shapes]
+    for m, (h, w) in zip(masks, shapes):
+        m[1, :, w - 2:] = True
+    pe = poet_ref.PositionEmbeddingSine(d // 2, normalize=True)
+    pos = [pe(poet_ref.NestedTensor(s, m)) for s, m in zip(srcs, masks)]
+    qe = torch.randn(N, Q, 2 * d)
+    rp = torch.rand(N, Q, 2)
+    s1 = [s.clone().requires_grad_() for s in srcs]
+    hs_ref, init_ref, inter_ref, _, _ = ref_t(s1, masks, pos, qe, rp)
+    g = torch.randn_like(hs_ref)
+    hs_ref.backward(g)
+    s2 = [s.cuda().requires_grad_() for s in srcs]
+    hs, init, inter, a, b = mine(s2, [m.cuda() for m in masks], [p.cuda() for p in pos], qe.cuda(), rp.cuda())
+    assert a is None and b is None and hs.shape == hs_ref.shape and inter.shape == inter_ref.shape
+    hs.backward(g.cuda())
+    assert (hs.cpu() - hs_ref).abs().max().item() < 1e-4
+    assert torch.equal(init.cpu(), init_ref)
+    for x, y in zip(s2, s1):
+        assert (x.grad.cpu() - y.grad).abs().max().item() < 1e-3 * max(1.0, y.grad.abs().max().item())
+    pr = dict(ref_t.named_parameters())
+    for n, p in mine.named_parameters():
+        if pr[n].grad is None:
+            assert p.grad is None, n
+            continue
+        assert (p.grad.cpu() - pr[n].grad).abs().max().item() < 2e-3 * max(1.0, pr[n].grad.abs().max().item()), n
