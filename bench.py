@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel from Python instead of replaying HIP graphs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,7 +195,11 @@ def main():
     feats, targets = synth_batch(cfg, batch, 1234 + rank, device)
     model, crit = build_model(cfg, feats, args.precision, device)
     model.train()
-    trainer = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+    if args.no_graphs:
+        trainer = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+    else:
+        trainer = poet_amd.GraphedTrainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=2)
+        args.warmup = max(args.warmup, 4)                       # 2 eager steps + capture + 1 replay before timing
     ih, iw = cfg["image_hw"]
     samples = poet_amd.NestedTensor(None, torch.zeros((batch, ih, iw), dtype=torch.bool, device=device))
 
@@ -217,9 +222,11 @@ def main():
     if not args.no_roofline and rank == 0 and world == 1:
         # per-kernel HIP-event timing on the launch stream, over 3 EXTRA steps of the same workload right after the
         # timed region (kept out of it so the events do not perturb `value`)
+        eager = trainer if args.no_graphs else super(poet_amd.GraphedTrainer, trainer)     # per-launch events need eager launches
+        ops.SEED_DEV[0] = None
         ops.PROFILE.start()
         for _ in range(prof_steps):
-            trainer.step(samples, targets)
+            eager.step(samples, targets)
         prof = ops.PROFILE.stop()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -243,6 +250,7 @@ def main():
                                    f"bs={batch} per GPU, dropout {cfg['dropout']}, AdamW + clip 0.1, random init",
                        "global_batch": world * batch, "tokens_per_image": sum(h * w for h, w in cfg["level_hw"]),
                        "parallelism": f"dp{world}", "precision_policy": args.precision,
+                       "launch": "eager" if args.no_graphs else "hipGraph replay (fwd graph, bwd+opt graph)",
                        "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
                        "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4),
                        "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 3)},

@@ -95,6 +95,8 @@ typedef struct PoetGemmDesc {
     float drop_p;
     uint32_t seed;
     int32_t out_mode, hm_M, hm_S, hm_D;
+    const uint32_t* seed_dev; /* optional device word XOR-mixed into `seed` at run time: lets a captured hipGraph draw a
+                                 fresh dropout mask on every replay (the host bumps the word between replays) */
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
 
@@ -150,10 +152,12 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
 int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                 void* y, void* z_out, float* mean, float* rstd,
                 int64_t rows, int d, float eps, float drop_p, uint32_t seed, int dtype_x, int dtype_r,
-                void* y_bf16 /* optional: bf16 copy of y, the MFMA operand of the next GEMM */, void* stream);
+                void* y_bf16 /* optional: bf16 copy of y, the MFMA operand of the next GEMM */,
+                const uint32_t* seed_dev /* optional, see PoetGemmDesc.seed_dev */, void* stream);
 int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                 void* dz_out, void* dx_out, float* dgamma, float* dbeta,
-                int64_t rows, int d, float drop_p, uint32_t seed, int dtype_x, int dtype_r, void* stream);
+                int64_t rows, int d, float drop_p, uint32_t seed, int dtype_x, int dtype_r,
+                const uint32_t* seed_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small multi-head self-attention core (nn.MultiheadAttention without the projections):
@@ -162,10 +166,10 @@ int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* r
  * probabilities, no key-padding mask (the reference passes none).
  * ---------------------------------------------------------------------------------------------- */
 int poet_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, float* out, int64_t ld_out,
-                 int N, int Q, int M, int hd, float drop_p, uint32_t seed, void* stream);
+                 int N, int Q, int M, int hd, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 int poet_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dout, int64_t ld_out,
                  float* dq, float* dk, float* dv, int64_t ld_d,
-                 int N, int Q, int M, int hd, float drop_p, uint32_t seed, void* stream);
+                 int N, int Q, int M, int hd, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Position encodings (fp32 math, full-range sinf/cosf).
@@ -254,7 +258,11 @@ int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* 
 int poet_sqnorm(const float* g, int64_t n, float* out, void* stream);
 int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
                float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-               const float* sqnorm, float max_norm, float grad_scale, void* stream);
+               const float* sqnorm, float max_norm, float grad_scale,
+               const uint32_t* step_dev /* optional: the step count is read from this device word instead of `step` */,
+               void* stream);
+/* *word += delta (single-thread kernel): advances the device-side dropout seed / Adam step between graph replays. */
+int poet_counter_add(uint32_t* word, uint32_t delta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,8 @@ from .modules import (BoundingBoxEmbeddingSine, DeformableTransformer, Deformabl
                       DeformableTransformerDecoderLayer, DeformableTransformerEncoder,
                       DeformableTransformerEncoderLayer, MLP, MSDeformAttn, NestedTensor, PoET,
                       PositionEmbeddingSine)
-from .engine import (BucketReducer, ParamArena, PoseMatcher, SetCriterion, Trainer, build_weight_dict,  # noqa: F401
-                     reduce_dict)
+from .engine import (BucketReducer, GraphedTrainer, ParamArena, PoseMatcher, SetCriterion, Trainer,  # noqa: F401
+                     build_weight_dict, reduce_dict)
 from .blocks import manual_seed  # noqa: F401
 
 __version__ = "0.1.0"

@@ -25,6 +25,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int32), ("atomic", C.c_int32), ("act", C.c_int32),
         ("alpha", f32), ("gate_scale", f32), ("drop_p", f32), ("seed", u32),
         ("out_mode", C.c_int32), ("hm_M", C.c_int32), ("hm_S", C.c_int32), ("hm_D", C.c_int32),
+        ("seed_dev", vp),
     ]
 
 
@@ -38,10 +39,10 @@ _PROTOS = {
                              i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_msda_fused_bwd": ([vp, i64, i64, i64, pi64, pi64, vp, i64, i32, vp, i64, vp, vp, vp,
                              i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
-    "poet_ln_fwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u32, i32, i32, vp, vp], i32),
-    "poet_ln_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u32, i32, i32, vp], i32),
-    "poet_mha_fwd": ([vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, u32, vp], i32),
-    "poet_mha_bwd": ([vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, u32, vp], i32),
+    "poet_ln_fwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u32, i32, i32, vp, vp, vp], i32),
+    "poet_ln_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u32, i32, i32, vp, vp], i32),
+    "poet_mha_fwd": ([vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, u32, vp, vp], i32),
+    "poet_mha_bwd": ([vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, u32, vp, vp], i32),
     "poet_pos_sine": ([vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp], i32),
     "poet_bbox_sine": ([vp, vp, vp, i32, i32, f32, vp], i32),
     "poet_dec_ref_points": ([vp, vp, vp, i32, i32, i32, vp], i32),
@@ -61,7 +62,8 @@ _PROTOS = {
     "poet_pose_finish_fwd": ([vp, vp, vp, vp, vp, i32, i32, vp], i32),
     "poet_pose_finish_bwd": ([vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
     "poet_sqnorm": ([vp, i64, vp, vp], i32),
-    "poet_adamw": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp], i32),
+    "poet_adamw": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp], i32),
+    "poet_counter_add": ([vp, u32, vp], i32),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -16,6 +16,7 @@ struct MhaP {
     float scale;
     uint32_t thresh, seed;
     float dscale;
+    const uint32_t* seed_dev;
 };
 
 template <int HD>
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
     const uint32_t ibase = ((uint32_t)blockIdx.x * Q + lane) * Q;
     for (int j = 0; j < Q; ++j) {
         float pj = sp[lane * (Q + 1) + j] * inv;
-        if (p.thresh) pj = drop_keep(p.seed, ibase + j, p.thresh) ? pj * p.dscale : 0.f;
+        if (p.thresh) pj = drop_keep(p.seed ^ (p.seed_dev ? *p.seed_dev * 0x9E3779B1u : 0u), ibase + j, p.thresh) ? pj * p.dscale : 0.f;
 #pragma unroll
         for (int c = 0; c < HD; ++c) acc[c] += pj * sv[j * PH + c];
     }
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         for (int j = 0; j < Q; ++j) {
             const float pj = spd[lane * PQ + j] * inv;
             float keep = 1.f;
-            if (p.thresh) keep = drop_keep(p.seed, ibase + j, p.thresh) ? p.dscale : 0.f;
+            if (p.thresh) keep = drop_keep(p.seed ^ (p.seed_dev ? *p.seed_dev * 0x9E3779B1u : 0u), ibase + j, p.thresh) ? p.dscale : 0.f;
             float dpd = 0.f;
 #pragma unroll
             for (int c = 0; c < HD; ++c) dpd += dor[c] * sv[j * PH + c];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
     }
 }
 
-static int mha_common(MhaP& p, int N, int Q, int M, int hd, float drop_p, uint32_t seed) {
+static int mha_common(MhaP& p, int N, int Q, int M, int hd, float drop_p, uint32_t seed, const uint32_t* seed_dev) {
     POET_CHECK(N > 0 && M > 0 && Q > 0 && Q <= 64, POET_ERR_UNSUPPORTED, "mha: Q=%d must be in 1..64", Q);
     POET_CHECK(hd == 16 || hd == 32 || hd == 64, POET_ERR_UNSUPPORTED, "mha: head dim %d not in {16,32,64}", hd);
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "mha: drop_p");
@@ -168,6 +169,7 @@ static int mha_common(MhaP& p, int N, int Q, int M, int hd, float drop_p, uint32
     p.thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     p.dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     p.seed = seed;
+    p.seed_dev = seed_dev;
     return POET_OK;
 }
 
@@ -176,9 +178,9 @@ static int mha_common(MhaP& p, int N, int Q, int M, int hd, float drop_p, uint32
 using namespace poet;
 
 extern "C" int poet_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, float* out, int64_t ld_out,
-                            int N, int Q, int M, int hd, float drop_p, uint32_t seed, void* stream) {
+                            int N, int Q, int M, int hd, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
     MhaP p{};
-    int rc = mha_common(p, N, Q, M, hd, drop_p, seed);
+    int rc = mha_common(p, N, Q, M, hd, drop_p, seed, seed_dev);
     if (rc) return rc;
     POET_CHECK(q && k && v && out, POET_ERR_ARG, "mha_fwd: null pointer");
     p.q = q; p.k = k; p.v = v; p.out = out; p.ld = ld; p.ld_out = ld_out;
@@ -195,9 +197,9 @@ extern "C" int poet_mha_fwd(const float* q, const float* k, const float* v, int6
 
 extern "C" int poet_mha_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dout, int64_t ld_out,
                             float* dq, float* dk, float* dv, int64_t ld_d, int N, int Q, int M, int hd, float drop_p,
-                            uint32_t seed, void* stream) {
+                            uint32_t seed, const uint32_t* seed_dev, void* stream) {
     MhaP p{};
-    int rc = mha_common(p, N, Q, M, hd, drop_p, seed);
+    int rc = mha_common(p, N, Q, M, hd, drop_p, seed, seed_dev);
     if (rc) return rc;
     POET_CHECK(q && k && v && dout && dq && dk && dv, POET_ERR_ARG, "mha_bwd: null pointer");
     p.q = q; p.k = k; p.v = v; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv; p.ld = ld; p.ld_out = ld_out; p.ld_d = ld_d;

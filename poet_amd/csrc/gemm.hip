@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
         }
         if (p.drop_thresh) {
             const uint32_t base = (uint32_t)grow * (uint32_t)d.N + (uint32_t)gcol;
+            const uint32_t sd = d.seed ^ (d.seed_dev ? *d.seed_dev * 0x9E3779B1u : 0u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = drop_keep(d.seed, base + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = drop_keep(sd, base + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
         }
         if (addp) {
             float a8[8];

@@ -14,7 +14,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      TR* __restrict__ y, TX* __restrict__ z, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t rows, int d, float eps,
-                                                     uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16) {
+                                                     uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16,
+                                                     const uint32_t* __restrict__ seed_dev) {
+    if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wid;
     if (row >= rows) return;
@@ -78,8 +80,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, 
                                                      const float* __restrict__ gamma, TR* __restrict__ dz,
                                                      TX* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int d,
-                                                     uint32_t thresh, float dscale, uint32_t seed) {
+                                                     uint32_t thresh, float dscale, uint32_t seed,
+                                                     const uint32_t* __restrict__ seed_dev) {
     __shared__ float red[2][4][LN_MAXIT * 256];
+    if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float ag[LN_MAXIT][4], ab[LN_MAXIT][4], gm[LN_MAXIT][4];
 #pragma unroll
@@ -260,7 +264,7 @@ using namespace poet;
 
 extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
                            float* mean, float* rstd, int64_t rows, int d, float eps, float drop_p, uint32_t seed,
-                           int dtype_x, int dtype_r, void* y_bf16, void* stream) {
+                           int dtype_x, int dtype_r, void* y_bf16, const uint32_t* seed_dev, void* stream) {
     POET_CHECK(x && gamma && beta && y, POET_ERR_ARG, "ln_fwd: null pointer");
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_fwd: d=%d unsupported", d);
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "ln_fwd: drop_p");
@@ -268,7 +272,7 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
     const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16)
+#define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev)
     POET_DT2(dtype_x, dtype_r, LN_FWD);
 #undef LN_FWD
     POET_LAUNCH_CHECK();
@@ -277,7 +281,7 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
 
 extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                            void* dz_out, void* dx_out, float* dgamma, float* dbeta, int64_t rows, int d, float drop_p,
-                           uint32_t seed, int dtype_x, int dtype_r, void* stream) {
+                           uint32_t seed, int dtype_x, int dtype_r, const uint32_t* seed_dev, void* stream) {
     POET_CHECK(dy && z && mean && rstd && gamma && dz_out && dgamma && dbeta, POET_ERR_ARG, "ln_bwd: null pointer");
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_bwd: d=%d unsupported", d);
     POET_CHECK(!(drop_p > 0.f && dx_out == dz_out), POET_ERR_ARG, "ln_bwd: dx_out must not alias dz_out when drop_p>0");
@@ -288,7 +292,7 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     if (nb > 512) nb = 512;
     dim3 grid(nb), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed)
+#define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev)
     POET_DT2(dtype_x, dtype_r, LN_BWD);
 #undef LN_BWD
     POET_LAUNCH_CHECK();

@@ -98,8 +98,9 @@ class ParamArena:
     def zero_grad(self):
         self.grad.zero_()
 
-    def step(self, max_norm: float = 0.1):
-        """clip_grad_norm_(max_norm) + AdamW (engine.py:77-81) on the flat arenas."""
+    def step(self, max_norm: float = 0.1, step_dev=None):
+        """clip_grad_norm_(max_norm) + AdamW (engine.py:77-81) on the flat arenas.  With `step_dev` (a device word) the
+        step count / bias corrections are read on the device, so the launch sequence can be replayed from a hipGraph."""
         self.step_count += 1
         gs = 1.0 / self.world
         sq = None
@@ -111,7 +112,7 @@ class ParamArena:
             if b > a:
                 ops.adamw(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b], b - a, lr, self.betas[0], self.betas[1],
                           self.eps, self.weight_decay, self.step_count, sqnorm_buf=sq, max_norm=max_norm, grad_scale=gs,
-                          p_bf16=self.flat_bf16[a:b])
+                          p_bf16=self.flat_bf16[a:b], step_dev=step_dev)
 
     def grad_norm(self) -> torch.Tensor:
         return torch.sqrt(self.sq[0]) / self.world
@@ -242,6 +243,8 @@ class SetCriterion(nn.Module):
 
     def forward(self, outputs, targets, n_boxes):
         main = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
+        if hasattr(self.matcher, "_cache"):
+            self.matcher._cache = (None, None)      # the per-call cache must not outlive the call (static buffers are reused)
         aux_list = outputs.get("aux_outputs", [])
         for aux in aux_list:
             if "_pred_boxes_host" in outputs:
@@ -340,4 +343,127 @@ class Trainer:
             self.reducer.finish()
         self.arena.step(self.max_norm)
         set_reducer(None)
+        return total.detach(), loss_dict
+
+
+class _Replay(torch.autograd.Function):
+    """Autograd shim around the two captured graphs: forward replays the model-forward graph and hands out its static
+    outputs; backward copies the loss gradients into the static grad buffers and replays backward (+ optimiser)."""
+
+    @staticmethod
+    def forward(ctx, trainer, handle):
+        ctx.trainer = trainer
+        trainer.g_fwd.replay()
+        return trainer.s_rot.detach(), trainer.s_trans.detach()
+
+    @staticmethod
+    def backward(ctx, drot, dtrans):
+        t = ctx.trainer
+        t.s_drot.copy_(drot)
+        t.s_dtrans.copy_(dtrans)
+        t.g_bwd.replay()
+        if t.world > 1:                      # one large collective on the whole flat gradient arena, then the optimiser graph
+            dist.all_reduce(t.arena.grad, op=dist.ReduceOp.SUM)
+            t.g_opt.replay()
+        return None, None
+
+
+class GraphedTrainer(Trainer):
+    """Trainer whose device work is replayed from HIP graphs (the step has ~700 kernel launches; enqueuing them from
+    Python costs about as much as executing them).  Three graphs, captured after `warm` eager steps:
+        g_fwd : bump the device-side dropout word; PoET.forward_core (input_proj .. heads)
+        g_bwd : zero the gradient arena; the four backward programs (+ clip + AdamW when world == 1)
+        g_opt : clip + AdamW (world > 1 only; the RCCL all-reduce of the whole arena runs eagerly between g_bwd and g_opt)
+    Host work per step: pad/pack the boxes, three small H2D copies, the matcher, the loss and its backward (eager).
+    Requirements: fixed batch size / image geometry, model in train() mode for the whole run."""
+
+    def __init__(self, model, criterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=3):
+        super().__init__(model, criterion, lr=lr, weight_decay=weight_decay, max_norm=max_norm, distributed=False)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.arena.world = self.world
+        if self.world > 1:
+            dist.broadcast(self.arena.flat, src=0)
+            self.arena.refresh_shadow()
+        self.warm, self.calls, self.ready = warm, 0, False
+
+    def _static_inputs(self, samples, targets):
+        m = self.model
+        features, _, _ = m.backbone(samples)
+        boxes, classes, valid, n_boxes = m.host_queries(targets)
+        return features, boxes, classes, valid, n_boxes
+
+    def _capture(self, samples, targets):
+        m, dev = self.model, self.arena.flat.device
+        features, boxes, classes, valid, _ = self._static_inputs(samples, targets)
+        self.s_feats = [f.tensors for f in features]
+        self.s_fmasks = [(f.mask.contiguous().view(torch.uint8) if f.mask.dtype == torch.bool else f.mask.contiguous()).clone()
+                         for f in features]
+        im = samples.mask
+        self.s_imask = (im.contiguous().view(torch.uint8) if im.dtype == torch.bool else im.contiguous()).clone()
+        # pinned staging ring: the host may run several steps ahead of the GPU, so a slot is only rewritten after the
+        # H2D copies that read it have completed (event per slot)
+        self.ring = [dict(boxes=torch.from_numpy(boxes.copy()).pin_memory(), cls=torch.from_numpy(classes.copy()).pin_memory(),
+                          valid=torch.from_numpy(valid.copy()).pin_memory(), ev=None) for _ in range(4)]
+        self.ring_pos = 0
+        self.s_boxes = self.ring[0]["boxes"].to(dev)
+        self.s_cls = self.ring[0]["cls"].to(dev)
+        self.s_valid = self.ring[0]["valid"].to(dev)
+        self.seed_word = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_word = torch.full((1,), self.arena.step_count, dtype=torch.int32, device=dev)
+        self.handle = torch.zeros(1, device=dev, requires_grad=True)
+        ops.SEED_DEV[0] = self.seed_word
+        set_reducer(None)
+        torch.cuda.synchronize()
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd):
+            with ops.pinned_stream():
+                ops.counter_add(self.seed_word, 1)
+                rot, trans, _ = m.forward_core(self.s_feats, self.s_fmasks, self.s_imask, self.s_boxes, self.s_valid, self.s_cls)
+        self.s_rot, self.s_trans = rot, trans
+        self.s_drot, self.s_dtrans = torch.zeros_like(rot), torch.zeros_like(trans)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+            with ops.pinned_stream():
+                self.arena.zero_grad()
+                torch.autograd.backward([rot, trans], [self.s_drot, self.s_dtrans])
+                if self.world == 1:
+                    ops.counter_add(self.step_word, 1)
+                    self.arena.step(self.max_norm, step_dev=self.step_word)
+        if self.world > 1:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
+                with ops.pinned_stream():
+                    ops.counter_add(self.step_word, 1)
+                    self.arena.step(self.max_norm, step_dev=self.step_word)
+        torch.cuda.synchronize()
+        self.ready = True
+
+    def step(self, samples, targets):
+        self.calls += 1
+        if not self.ready:
+            if self.calls <= self.warm:
+                return super().step(samples, targets)        # eager warm-up (also fills every lazy cache)
+            self._capture(samples, targets)
+        m = self.model
+        features, boxes, classes, valid, n_boxes = self._static_inputs(samples, targets)
+        for f, sf, sm in zip(features, self.s_feats, self.s_fmasks):
+            if f.tensors.data_ptr() != sf.data_ptr():
+                sf.copy_(f.tensors, non_blocking=True)
+            sm.copy_(f.mask.view(torch.uint8) if f.mask.dtype == torch.bool else f.mask, non_blocking=True)
+        slot = self.ring[self.ring_pos]
+        self.ring_pos = (self.ring_pos + 1) % len(self.ring)
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        slot["boxes"].copy_(torch.from_numpy(boxes)); slot["cls"].copy_(torch.from_numpy(classes)); slot["valid"].copy_(torch.from_numpy(valid))
+        self.s_boxes.copy_(slot["boxes"], non_blocking=True)
+        self.s_cls.copy_(slot["cls"], non_blocking=True)
+        self.s_valid.copy_(slot["valid"], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record()
+        rot, trans = _Replay.apply(self, self.handle)
+        out = m.make_outputs(rot, trans, self.s_boxes, self.s_cls, boxes)
+        loss_dict = self.criterion(out, targets, n_boxes)
+        wd = self.criterion.weight_dict
+        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        total.backward()
         return total.detach(), loss_dict

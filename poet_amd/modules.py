@@ -377,7 +377,9 @@ class PoET(nn.Module):
         self.bbox_embedding = BoundingBoxEmbeddingSine(num_pos_feats=d / 8)
 
     # ---- query assembly (pose_estimation_transformer.py:203-239,309-311,337-338), batched on the host ----
-    def assemble_queries(self, targets, device):
+    def host_queries(self, targets):
+        """Pure host work: pad every image's boxes/labels to n_queries (dummy box -1, dummy class -1).
+        Returns numpy (boxes (N,Q,4) f32, classes (N,Q) i64, valid (N,Q) u8) and n_boxes."""
         N, Q = len(targets), self.n_queries
         boxes = np.full((N, Q, 4), -1.0, np.float32)
         classes = np.full((N, Q), -1, np.int64)
@@ -392,56 +394,64 @@ class PoET(nn.Module):
                 raise ValueError(f"image {i} has {nb} boxes > num_queries={Q} (the reference assumes n <= Q in gt mode)")
             n_boxes.append(nb)
             boxes[i, :nb], classes[i, :nb], valid[i, :nb] = b, c, 1
-        pack = torch.from_numpy(boxes).to(device, non_blocking=True)
-        cls = torch.from_numpy(classes).to(device, non_blocking=True)
-        val = torch.from_numpy(valid).to(device, non_blocking=True)
-        emb = torch.empty((N * Q, self.hidden_dim), dtype=torch.float32, device=device)
-        ops.bbox_sine(pack.view(N * Q, 4), emb, N * Q, self.hidden_dim // 8, valid=val.view(-1), fill=-10.0)
-        self._boxes_host = boxes
-        return emb.view(N, Q, -1), pack, cls, n_boxes
+        return boxes, classes, valid, n_boxes
 
-    def forward(self, samples, targets=None):
-        if targets is None:
-            raise NotImplementedError("bbox_mode gt/jitter needs targets")
-        features, _pos, _pred = self.backbone(samples)
-        dev = features[0].tensors.device
+    def forward_core(self, feats, feat_masks, image_mask, boxes, valid, classes):
+        """Device-only part of forward (capturable in a hipGraph: no host sync, no host-dependent shapes).
+        feats: list of NCHW maps; feat_masks: list of (N,h,w) uint8; image_mask (N,H,W) uint8;
+        boxes (N,Q,4) f32; valid (N,Q) uint8; classes (N,Q) int64.  Returns (rot, trans, hs)."""
         tr = self.transformer
         act, stream = tr.act_dtype, tr.stream_dtype
-        emb, pred_boxes, pred_classes, n_boxes = self.assemble_queries(targets, dev)
-        N, Q = pred_classes.shape
-
+        dev = feats[0].device
+        N, Q = classes.shape
+        emb = torch.empty((N * Q, self.hidden_dim), dtype=torch.float32, device=dev)
+        ops.bbox_sine(boxes.view(N * Q, 4), emb, N * Q, self.hidden_dim // 8, valid=valid.view(-1), fill=-10.0)
+        emb = emb.view(N, Q, -1)
         # per-level geometry and masks (extra levels: nearest resize of the image mask, :328-329)
-        feats = [f.tensors for f in features]
-        masks = [_u8(f.mask) for f in features]
+        masks = list(feat_masks)
         shapes = [tuple(f.shape[-2:]) for f in feats]
         for lvl in range(len(feats), self.num_feature_levels):
             h, w = shapes[-1]
             shapes.append(((h - 1) // 2 + 1, (w - 1) // 2 + 1))
-            im = _u8(samples.mask)
             m = torch.empty((N, *shapes[-1]), dtype=torch.uint8, device=dev)
-            ops.mask_nearest(im, m, N, im.shape[1], im.shape[2], *shapes[-1])
+            ops.mask_nearest(image_mask, m, N, image_mask.shape[1], image_mask.shape[2], *shapes[-1])
             masks.append(m)
         geom = LevelGeom(shapes)
-
         names, params = _named(self.input_proj)
         src = Fn.InputProjFn.apply(feats, geom, 32, (act, stream), names, *params)
         pos = torch.empty((N, geom.S, self.hidden_dim), dtype=act, device=dev)
         lvl_embed = tr.level_embed.detach().contiguous()
         for l, (h, w) in enumerate(geom.shapes):
             ops.pos_sine(masks[l], pos, lvl_embed[l], N, h, w, self.hidden_dim // 2, geom.starts[l], geom.S)
-
-        hs = tr.forward_flat(src, pos, masks, geom, emb, emb, pred_boxes[:, :, :2].contiguous())
-
-        cls32 = pred_classes.to(torch.int32).view(-1) if self.class_mode == "specific" else torch.zeros(
-            N * Q, dtype=torch.int32, device=dev)
+        hs = tr.forward_flat(src, pos, masks, geom, emb, emb, boxes[:, :, :2].contiguous())
+        if self.class_mode == "specific":
+            cls32 = classes.to(torch.int32).view(-1)
+            ncls = self.n_classes
+        else:
+            cls32, ncls = torch.zeros(N * Q, dtype=torch.int32, device=dev), 1
         names, params = _named(self.translation_head, "translation_head.")
         n2, p2 = _named(self.rotation_head, "rotation_head.")
-        rot, trans = Fn.HeadsFn.apply(hs, cls32, self.n_classes if self.class_mode == "specific" else 1,
-                                      names + n2, *(params + p2))
+        rot, trans = Fn.HeadsFn.apply(hs, cls32, ncls, names + n2, *(params + p2))
+        return rot, trans, hs
+
+    def make_outputs(self, rot, trans, pred_boxes, pred_classes, boxes_host):
         out = {"pred_translation": trans[-1], "pred_rotation": rot[-1], "pred_boxes": pred_boxes, "pred_classes": pred_classes}
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_translation": t, "pred_rotation": r, "pred_boxes": pred_boxes,
                                    "pred_classes": pred_classes} for t, r in zip(trans[:-1], rot[:-1])]
-        out["_pred_boxes_host"] = self._boxes_host     # lets the matcher run without a device->host sync
+        out["_pred_boxes_host"] = boxes_host          # lets the matcher run without a device->host sync
+        return out
+
+    def forward(self, samples, targets=None):
+        if targets is None:
+            raise NotImplementedError("bbox_mode gt/jitter needs targets")
+        features, _pos, _pred = self.backbone(samples)
+        dev = features[0].tensors.device
+        boxes, classes, valid, n_boxes = self.host_queries(targets)
+        pred_boxes = torch.from_numpy(boxes).to(dev, non_blocking=True)
+        pred_classes = torch.from_numpy(classes).to(dev, non_blocking=True)
+        val = torch.from_numpy(valid).to(dev, non_blocking=True)
+        rot, trans, hs = self.forward_core([f.tensors for f in features], [_u8(f.mask) for f in features], _u8(samples.mask),
+                                           pred_boxes, val, pred_classes)
         self._last_hs = hs
-        return out, n_boxes
+        return self.make_outputs(rot, trans, pred_boxes, pred_classes, boxes), n_boxes

@@ -14,8 +14,17 @@ import struct as _struct
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 # PoetGemmDesc as one packed record (natural C layout of include/poet_hip.h; checked against ctypes below)
-_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i")       # native alignment inserts the same padding as the C compiler
-assert _GEMM_PACK.size <= C.sizeof(GemmDesc) and GemmDesc.hm_D.offset + 4 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
+_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q")     # native alignment inserts the same padding as the C compiler
+assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 8 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
+
+# Device word mixed into every dropout seed (and the Adam step) at run time.  None in eager mode; engine.GraphedTrainer
+# sets it so captured hipGraphs draw fresh masks on each replay.
+SEED_DEV = [None]
+
+
+def _seed_dev():
+    t = SEED_DEV[0]
+    return None if t is None else t.data_ptr()
 _GEMM_DESC = GemmDesc()
 _GEMM_BUF = (C.c_char * C.sizeof(GemmDesc)).from_buffer(_GEMM_DESC)
 
@@ -162,7 +171,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                          0 if gate_ref is None else gate_ref.data_ptr(), 0 if row_mask is None else row_mask.data_ptr(),
                          M, N, K, lda, ldb, ldc, ld_add, int(a_kmajor), int(b_kmajor), ad, bd, cd, compute, batch,
                          strideA, strideB, strideC, stride_bias, splitk, int(atomic), act, alpha, gate_scale, drop_p,
-                         seed & 0xFFFFFFFF, 1 if head_major is not None else 0, hm[0], hm[1], hm[2])
+                         seed & 0xFFFFFFFF, 1 if head_major is not None else 0, hm[0], hm[1], hm[2],
+                         (_seed_dev() or 0) if drop_p > 0 else 0)
     if PROFILE.on:
         e0 = PROFILE.begin()
         _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
@@ -256,7 +266,8 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None):
     lib = _lib.load()
     _lib.check(lib.poet_ln_fwd(_req(x, "x").data_ptr(), _ptr(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(z),
-                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y), _ptr(y16), _stream()), "poet_ln_fwd")
+                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y), _ptr(y16),
+                               _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_fwd")
     return y
 
 
@@ -264,7 +275,7 @@ def ln_bwd(dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, rows, d, drop_p=0.0,
     lib = _lib.load()
     _lib.check(lib.poet_ln_bwd(_req(dy, "dy").data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                dz.data_ptr(), _ptr(dx), dgamma.data_ptr(), dbeta.data_ptr(), rows, d, drop_p,
-                               seed & 0xFFFFFFFF, dcode(z), dcode(dy), _stream()), "poet_ln_bwd")
+                               seed & 0xFFFFFFFF, dcode(z), dcode(dy), _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_bwd")
 
 
 def groupnorm_fwd(x, gamma, beta, y, stats, N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps=1e-5):
@@ -285,14 +296,14 @@ def groupnorm_bwd(dy, x, stats, gamma, dx, dgamma, dbeta, N, HW, Cc, G, x_off, x
 def mha_fwd(q, k, v, ld, out, ld_out, N, Q, M, hd, drop_p=0.0, seed=0):
     lib = _lib.load()
     _lib.check(lib.poet_mha_fwd(_req(q, "q").data_ptr(), k.data_ptr(), v.data_ptr(), ld, out.data_ptr(), ld_out, N, Q, M, hd,
-                                drop_p, seed & 0xFFFFFFFF, _stream()), "poet_mha_fwd")
+                                drop_p, seed & 0xFFFFFFFF, _seed_dev() if drop_p > 0 else None, _stream()), "poet_mha_fwd")
 
 
 def mha_bwd(q, k, v, ld, dout, ld_out, dq, dk, dv, ld_d, N, Q, M, hd, drop_p=0.0, seed=0):
     lib = _lib.load()
     _lib.check(lib.poet_mha_bwd(_req(q, "q").data_ptr(), k.data_ptr(), v.data_ptr(), ld, dout.data_ptr(), ld_out, dq.data_ptr(),
-                                dk.data_ptr(), dv.data_ptr(), ld_d, N, Q, M, hd, drop_p, seed & 0xFFFFFFFF, _stream()),
-               "poet_mha_bwd")
+                                dk.data_ptr(), dv.data_ptr(), ld_d, N, Q, M, hd, drop_p, seed & 0xFFFFFFFF,
+                                _seed_dev() if drop_p > 0 else None, _stream()), "poet_mha_bwd")
 
 
 # ---- encodings / geometry --------------------------------------------------------------------------
@@ -412,10 +423,15 @@ def sqnorm(g, out):
     _lib.check(lib.poet_sqnorm(_req(g, "g").data_ptr(), g.numel(), out.data_ptr(), _stream()), "poet_sqnorm")
 
 
-def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, sqnorm_buf=None, max_norm=0.0, grad_scale=1.0, p_bf16=None):
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, sqnorm_buf=None, max_norm=0.0, grad_scale=1.0, p_bf16=None, step_dev=None):
     lib = _lib.load()
     _lib.check(lib.poet_adamw(_req(p, "p").data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), n, lr, beta1, beta2,
-                              eps, wd, step, _ptr(sqnorm_buf), max_norm, grad_scale, _stream()), "poet_adamw")
+                              eps, wd, step, _ptr(sqnorm_buf), max_norm, grad_scale, _ptr(step_dev), _stream()), "poet_adamw")
+
+
+def counter_add(word, delta=1):
+    lib = _lib.load()
+    _lib.check(lib.poet_counter_add(_req(word, "word").data_ptr(), delta, _stream()), "poet_counter_add")
 
 
 # ---- optional timing of the non-GEMM kernels (algorithmic bytes = every tensor argument touched once) -------------
