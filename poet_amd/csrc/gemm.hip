@@ -363,8 +363,10 @@ static void launch_layout(const GemmK& p, hipStream_t st) {
 // tile choice: 0 = 128x128 (BKB 128), 1 = 64x64 (BKB 256), 2 = 32x32 (BKB 256; fp32-MFMA problems with few rows, so the
 // 1/16-rate f32 matrix pipe of more than a handful of CUs is used)
 static int tile_choice(const PoetGemmDesc& d) {
-    if (d.M >= 256 && d.N >= 128 && !(d.compute == POET_F32 && d.M < 1024)) return 0;
-    if (d.compute == POET_F32 && (int64_t)cdiv(d.M, 64) * cdiv(d.N, 64) * d.batch * d.splitk < 256) return 2;
+    const int64_t big_blocks = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * d.batch * d.splitk;
+    if (d.M >= 256 && d.N >= 128 && !(d.compute == POET_F32 && big_blocks < 128)) return 0;
+    if (d.compute == POET_F32 && (int64_t)cdiv(d.M, 64) * cdiv(d.N, 64) * d.batch * d.splitk < 256)
+        return (d.splitk == 1) ? 3 : 2;       // 3: whole-K stages (K=256 fp32 in one), the latency-bound 320-row decoder GEMMs
     return 1;
 }
 
@@ -373,7 +375,10 @@ static void launch_tile(const GemmK& p, hipStream_t st) {
     const int tc = tile_choice(p.d);
     if (tc == 0) launch_layout<TA, TB, TC, CT, 128, 128, 128>(p, st);
     else if (tc == 1) launch_layout<TA, TB, TC, CT, 64, 64, 256>(p, st);
-    else if constexpr (sizeof(CT) == 4) launch_layout<TA, TB, TC, CT, 32, 32, 256>(p, st);
+    else if constexpr (sizeof(CT) == 4) {
+        if (tc == 3) launch_layout<TA, TB, TC, CT, 32, 32, 1024>(p, st);
+        else launch_layout<TA, TB, TC, CT, 32, 32, 256>(p, st);
+    }
 }
 
 static bool vec_ok(const void* ptr, int64_t ld, int64_t stride) {
@@ -401,7 +406,8 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.out_mode == 1) POET_CHECK(d.hm_M > 0 && d.hm_S > 0 && d.hm_D > 0 && d.hm_M * d.hm_D == d.N, POET_ERR_ARG, "poet_gemm: head-major dims");
-    const int BKB = tile_choice(d) == 0 ? 128 : 256;
+    const int tcs = tile_choice(d);
+    const int BKB = tcs == 0 ? 128 : (tcs == 3 ? 1024 : 256);
     const int BK = BKB / (d.compute == POET_BF16 ? 2 : 4);
     p.kchunk = cdiv(cdiv(d.K, d.splitk), BK) * BK;
     p.a_vec = vec_ok(d.A, d.lda, d.strideA);

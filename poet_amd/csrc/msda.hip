@@ -137,9 +137,19 @@ __device__ __forceinline__ void load_points(const MsdaP& p, int64_t row, int n, 
     }
 }
 
+// Workgroup b runs on XCD b%8 (observed dispatch order).  Hand each XCD a contiguous range of query rows so that its
+// private 4 MB L2 only ever holds the value maps of the image(s) it is working on (3.3 MB per image at 640x480) instead
+// of all N images interleaved (measured: 370 -> 284 us per encoder launch).  Speed heuristic only.
+__device__ __forceinline__ int64_t xcd_contiguous_block(int64_t b, int64_t nb) {
+    const int64_t q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// 256 VGPRs (2 waves/SIMD) on purpose: the compiler keeps all 64 corner loads of a thread in flight; capping the
+// registers for more occupancy measured 2.7x-3.8x slower, lifting the cap (1 wave/SIMD) 1.2x slower.
 template <typename TV, typename TQ, int L, int P, bool FUSED>
-__global__ __launch_bounds__(256) void msda_fwd_kernel(const MsdaP p) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256, 2) void msda_fwd_kernel(const MsdaP p) {
+    const int64_t t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= p.total) return;
     const int64_t row = t / p.groups;
     const int c8 = (int)(t - row * p.groups);
@@ -295,17 +305,32 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
 // learned offset, padded image) goes straight to a global atomic, so the result never depends on the halo.
 // Global atomics drop from (16 points x 4 corners x D) per (query, head) to ~(window pixels x D) per workgroup (~20x).
 struct TileP { int TX, TY, HALO; };
+// 512 threads: twice the waves on the same LDS windows (the accumulate loop is VALU/LDS-issue bound at 2 waves/SIMD)
+constexpr int TILED_NT = 1024;
 
 __device__ __forceinline__ int cdiv_i(int a, int b) { return (a >= 0) ? (a + b - 1) / b : -((-a) / b); }
 
+// value of lane J of the caller's 16-lane DPP row, for every lane of the row (gfx90a+ row_newbcast)
+template <int J>
+__device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false); }
+
+template <int LP, int J = 0, typename F>
+__device__ __forceinline__ void row_points(const int (&cidx)[4], const float (&cw)[4], F&& f) {
+    if constexpr (J < LP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f(row_bcast<J>(cidx[k]), __int_as_float(row_bcast<J>(__float_as_int(cw[k]))));
+        row_points<LP, J + 1>(cidx, cw, f);
+    }
+}
+
 template <typename TQ, int L, int P>
-__global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, const TileP tp) {
+__global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP p, const TileP tp) {
     // LDS windows are INT32 FIXED POINT: ds_add_u32 sustains ~6.8 T lane-ops/s on MI355X, ds_add_f32 only ~0.2 T/s
     // (measured), i.e. float LDS atomics are no faster than L2 atomics.  Scale = 2^k per workgroup with
     // max|grad_out| * 2^k ~ 2^18: resolution 4e-6 of the tile's largest gradient, 2^13 contributions of headroom.
     // Used for bf16 storage only (the fp32 parity path keeps the exact float scatter).
     extern __shared__ __attribute__((aligned(16))) int win[];
-    __shared__ float s_red[4];
+    __shared__ float s_red[TILED_NT / 64];
     constexpr int LP = L * P;
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m = blockIdx.y, n = blockIdx.z;
@@ -320,9 +345,9 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, c
         wx0[l] = ax; wy0[l] = ay; ww[l] = bx - ax; wh[l] = by - ay;
         loff[l + 1] = loff[l] + ww[l] * wh[l];
     }
-    for (int i = tid; i < loff[L] * D; i += 256) win[i] = 0;
+    for (int i = tid; i < loff[L] * D; i += TILED_NT) win[i] = 0;
 
-    const int c = tid % D, slot = tid / D, nslots = 256 / D;
+    const int c = tid % D, slot = tid / D, nslots = TILED_NT / D;
     const TQ* gob = reinterpret_cast<const TQ*>(p.grad_out) + (int64_t)m * D + c;
     const int64_t gstride = (int64_t)p.M * D;
 
@@ -342,7 +367,9 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, c
     gm = wave_max(gm);
     if ((tid & 63) == 0) s_red[tid >> 6] = gm;
     __syncthreads();                                         // also orders the window zero-fill
-    gm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    gm = s_red[0];
+#pragma unroll
+    for (int w = 1; w < TILED_NT / 64; ++w) gm = fmaxf(gm, s_red[w]);
     if (!(gm > 0.f) || !(gm < 3.0e38f)) return;               // nothing to scatter (uniform across the workgroup)
     int ex;
     (void)frexpf(gm, &ex);                                    // gm in [2^(ex-1), 2^ex)
@@ -355,16 +382,29 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, c
         const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
         const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
-        for (int i = slot; i < nq; i += nslots) {
+        // software prefetch: the operands of query i + nslots are in flight while query i is scattered
+        const int j = c;
+        const bool has = j < LP;
+        const int l = has ? j / P : 0;
+        float n_g = 0.f, n_lg = -3.0e38f, n_ox = 0.f, n_oy = 0.f, n_rx = 0.f, n_ry = 0.f;
+        auto fetch = [&](int i) {
             const int q = p.start[lq] + (qy0 + i / qw) * W + qx0 + i % qw;
             const int64_t row = (int64_t)n * p.Lq + q;
-            const float gs = io<TQ>::ld(gob + row * gstride) * scale;
+            n_g = io<TQ>::ld(gob + row * gstride);
+            if (has) {
+                const TQ* qrow = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq;
+                n_lg = io<TQ>::ld(qrow + p.logit_col + m * LP + j);
+                n_ox = io<TQ>::ld(qrow + (m * LP + j) * 2);
+                n_oy = io<TQ>::ld(qrow + (m * LP + j) * 2 + 1);
+                const float* rp = p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * L + l) * 2;
+                n_rx = rp[0]; n_ry = rp[1];
+            }
+        };
+        if (slot < nq) fetch(slot);
+        for (int i = slot; i < nq; i += nslots) {
+            const float gs = n_g * scale, lg = n_lg, ox = n_ox, oy = n_oy, rx = n_rx, ry = n_ry;
+            if (i + nslots < nq) fetch(i + nslots);
             // ---- lane j (< L*P) of the slot prepares sample point j ----
-            const int j = c;
-            const bool has = j < LP;
-            const int l = has ? j / P : 0;
-            const TQ* qrow = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq;
-            float lg = has ? io<TQ>::ld(qrow + p.logit_col + m * LP + j) : -3.0e38f;
             float mx = lg;
             for (int o = 1; o < 16 && o < D; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
             float e = has ? __expf(lg - mx) : 0.f, sum = e;
@@ -376,9 +416,8 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, c
             for (int k = 0; k < 4; ++k) { cidx[k] = -1; cw[k] = 0.f; }
             if (has) {
                 const int Wl = p.W[l], Hl = p.H[l];
-                const float* rp = p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * L + l) * 2;
-                float px = io<TQ>::ld(qrow + (m * LP + j) * 2) + rp[0] * (float)Wl - 0.5f;
-                float py = io<TQ>::ld(qrow + (m * LP + j) * 2 + 1) + rp[1] * (float)Hl - 0.5f;
+                float px = ox + rx * (float)Wl - 0.5f;
+                float py = oy + ry * (float)Hl - 0.5f;
                 px = fminf(fmaxf(px, -2.f), (float)Wl + 1.f);
                 py = fminf(fmaxf(py, -2.f), (float)Hl + 1.f);
                 const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
@@ -401,14 +440,31 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, c
                 }
             }
             // ---- broadcast point by point to the channel lanes; int32 LDS accumulate ----
+            // D == 16: a slot is exactly one DPP row, so lane pt's registers reach the 16 channel lanes with
+            // v_mov_b32 row_newbcast (VALU) instead of ds_bpermute, which shares the LDS pipe with the atomics
+            // (measured: broadcasts were ~1.0 ms of this kernel's 1.5 ms at 640x480).
+            if (D == 16) {
+                // wave vote: when all 4 x LP x 4 corners of the wave are inside their windows (the common case away
+                // from image borders) run the branch-free body: 2 DPP moves + mul + cvt + add + ds_add per corner
+                const bool inwin = !has || (cidx[0] >= 0 && cidx[1] >= 0 && cidx[2] >= 0 && cidx[3] >= 0);
+                if (__all(inwin)) {
+                    row_points<LP>(cidx, cw, [&](int ii, float wv) { atomicAdd(&win[ii * 16 + c], __float2int_rn(wv * gs)); });
+                } else {
+                    row_points<LP>(cidx, cw, [&](int ii, float wv) {
+                        if (ii >= 0) atomicAdd(&win[ii * 16 + c], __float2int_rn(wv * gs));
+                        else if (ii <= -2) atomicAdd(gvb + (int64_t)(-2 - ii) * p.vs_s, wv * gs * inv);
+                    });
+                }
+            } else {
 #pragma unroll 4
-            for (int pt = 0; pt < LP; ++pt) {
+                for (int pt = 0; pt < LP; ++pt) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ii = __shfl(cidx[k], pt, D <= 64 ? D : 64);
-                    const float wv = __shfl(cw[k], pt, D <= 64 ? D : 64);
-                    if (ii >= 0) atomicAdd(&win[ii * D + c], __float2int_rn(wv * gs));
-                    else if (ii <= -2) atomicAdd(gvb + (int64_t)(-2 - ii) * p.vs_s, wv * gs * inv);
+                    for (int k = 0; k < 4; ++k) {
+                        const int ii = __shfl(cidx[k], pt, D <= 64 ? D : 64);
+                        const float wv = __shfl(cw[k], pt, D <= 64 ? D : 64);
+                        if (ii >= 0) atomicAdd(&win[ii * D + c], __float2int_rn(wv * gs));
+                        else if (ii <= -2) atomicAdd(gvb + (int64_t)(-2 - ii) * p.vs_s, wv * gs * inv);
+                    }
                 }
             }
         }
@@ -417,7 +473,7 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, c
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const int cnt = ww[l] * wh[l] * D;
-        for (int i = tid; i < cnt; i += 256) {
+        for (int i = tid; i < cnt; i += TILED_NT) {
             const int v = win[loff[l] * D + i];
             if (v != 0) {
                 const int cc = i % D, pix = i / D;
@@ -432,7 +488,7 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_tiled_kernel(const MsdaP p, c
 // host: pick the tile grid / halo so the windows fit the LDS budget; returns bytes (0 = do not use the tiled kernel)
 static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
     if (p.D < 16 || p.D > 64 || 256 % p.D != 0) return 0;
-    const int budget = 72 * 1024;                          // two workgroups per CU
+    const int budget = 150 * 1024;                         // two workgroups per CU (160 KB LDS); 640x480 fits a 4x4 tiling
     for (int halo = 4; halo >= 2; halo -= 2) {
         for (int t = 1; t <= 16; t *= 2) {
             const int TX = min(t, max(p.W[0] / 4, 1)), TY = min(t, max(p.H[0] / 4, 1));
@@ -463,8 +519,8 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
     if (!lds) return false;
     auto kern = msda_bwd_dv_tiled_kernel<TQ, L, 4>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(256), lds, st, p, tp);
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
     return true;
 }
 

@@ -202,10 +202,10 @@ def linear_dx(dy: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, rows: int
 
 
 def _splitk_for(M, N, K):
-    big = M >= 256 and N >= 128
+    big = M >= 256 and N >= 128 and K >= 4096
     t = 128 if big else 64
     tiles = -(-M // t) * -(-N // t)
-    return max(1, min(-(-1024 // tiles), -(-K // 512)))
+    return max(1, min(-(-1024 // tiles), -(-K // (512 if big else 128))))
 
 
 def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None):
@@ -252,7 +252,7 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
         a = (value, vstrides, geom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value, grad_offattn, N, M, D, P, Lq)
         nb_q = offattn.numel() * offattn.element_size() * 2 + grad_out.numel() * grad_out.element_size() + value.numel() * value.element_size()
         e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2)
-        PROFILE.end("msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * 4)
+        PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype == torch.bfloat16) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * 4)
         e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1)
         PROFILE.end("msda_bwd_dq", e0, 0.0, nb_q)
         return
