@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpoet_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result"]
 
@@ -34,7 +34,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
-    hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(os.path.dirname(HERE), "include", "poet_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "gemm.cuh"), os.path.join(os.path.dirname(HERE), "include", "poet_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -31,15 +31,14 @@ void set_error(const char* fmt, ...);
 
 // ---- bf16 <-> f32 (round-to-nearest-even, same as torch) ---------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;           // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): one VALU op per PAIR instead of ~5 per value
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct io;
 template <> struct io<float> {
@@ -97,16 +96,18 @@ template <> struct vec<bf16_t, 8> {
 };
 
 // ---- counter-based dropout RNG -------------------------------------------------------------------
-// keep(seed, idx): lowbias32 hash of (idx ^ seed-mix) -> 24-bit uniform; regenerated in backward
-// from the same (seed, idx), so no mask is ever stored.
+// keep(seed, idx): one lowbias32 hash of (idx>>1 ^ seed-mix) serves the element PAIR (idx & ~1, idx | 1), 16 bits each
+// (p is quantised to 2^-16); regenerated in backward from the same (seed, idx), so no mask is ever stored.  Vectorised
+// epilogues call drop_pair() once per two consecutive elements.
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thresh24) {
-    return (hash32(idx ^ (seed * 0x9E3779B9u)) >> 8) >= thresh24;
+__device__ __forceinline__ uint32_t drop_pair(uint32_t seed, uint32_t pair) { return hash32(pair ^ (seed * 0x9E3779B9u)); }
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thresh16) {
+    return ((drop_pair(seed, idx >> 1) >> ((idx & 1u) * 16u)) & 0xffffu) >= thresh16;
 }
-__host__ __device__ __forceinline__ uint32_t drop_thresh(float p) { return (uint32_t)(p * 16777216.0f); }
+__host__ __device__ __forceinline__ uint32_t drop_thresh(float p) { return (uint32_t)(p * 65536.0f); }
 
 // ---- wave-level reductions (64 lanes) ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

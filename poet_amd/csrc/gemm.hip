@@ -23,15 +23,9 @@
 // at the LDS write: a thread holds 4 consecutive k-rows x 8 rows and writes 8 x (4 k-values).
 #include "common.cuh"
 
-namespace poet {
+#include "gemm.cuh"
 
-struct GemmK {
-    PoetGemmDesc d;
-    int kchunk;
-    int a_vec, b_vec, c_vec;
-    uint32_t drop_thresh;
-    float drop_scale;
-};
+namespace poet {
 
 template <typename Src, typename CT, int N> struct cvt_pack;           // N source elements -> packed compute type
 template <> struct cvt_pack<bf16_t, bf16_t, 8> { static __device__ __forceinline__ uint4 run(uint4 v) { return v; } };
@@ -419,6 +413,10 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+    if (gemm_ws_try(p, st)) {              // tall activations x small stationary weight: streaming kernel (gemm_ws.hip)
+        POET_LAUNCH_CHECK();
+        return POET_OK;
+    }
     const int key = (d.a_dtype << 3) | (d.b_dtype << 2) | (d.c_dtype << 1) | d.compute;
     switch (key) {
         case (POET_BF16 << 3) | (POET_F32 << 2) | (POET_BF16 << 1) | POET_BF16:

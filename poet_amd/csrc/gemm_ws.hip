@@ -1,0 +1,335 @@
+// Weight-stationary streaming GEMM for gfx950:  C[M,N] = epilogue(A[M,K] * W^T),  M ~ 1e5 token rows, K = 256,
+// W a (slice of a) 256-column weight.  Every nn.Linear of the encoder with a 256-wide input and its input-gradient
+// twin (reference call sites: models/deformable_transformer.py:215-240 encoder layer, MSDeformAttn's four
+// projections) has this shape at bs*S = 102080 rows.  They are HBM-bound (K = 256 gives ~128 flop/B against a machine
+// balance of ~400), so the kernel is organised around the byte stream, not the MFMA:
+//
+//  * persistent workgroups; a workgroup keeps ONE BN x K slice of W in LDS for its whole life (loaded once, 64 KB),
+//    so the only recurring traffic is A in and C out;
+//  * the activation operand never touches LDS: a wave owns 32 consecutive rows and loads its MFMA B-operand fragments
+//    straight from global memory (lane = row l&15, 16-byte k-chunk l>>4), 16 x 16 B per lane for the whole K = 256.
+//    The registers of chunk kk are refilled with the NEXT 32 rows' chunk kk as soon as chunk kk has been consumed
+//    (rolling prefetch), so every wave always has 16 KB in flight with no barrier anywhere in the loop;
+//  * the product is computed transposed, D = W_frag (16 n x 32 k) * A_frag^T (32 k x 16 m): a lane then holds 4
+//    consecutive n for ONE row m.  The rows of W are laid out in LDS in a permuted order so that across the 4 fragments
+//    of a 64-column group a lane owns two runs of 8 consecutive output columns of its row (32 apart): the whole epilogue (bias, ReLU, ReLU
+//    gate, dropout, residual add, row mask, head-major scatter) runs on registers with 16/32-byte vector accesses and
+//    every vector access of a 16-lane row group covers 64 B (bf16) / 128 B (f32) contiguous bytes per row -- no LDS staging, no barrier;
+//  * 16-row units are dealt to waves as contiguous balanced ranges (6 or 7 units per wave at 102080 rows), the
+//    N/BN column slices of the same rows run on the same XCD (workgroup b -> XCD b % 8) so A is fetched from HBM once
+//    and re-read through that XCD's L2.
+#include "gemm.cuh"
+
+#include <type_traits>
+
+namespace poet {
+
+namespace {
+
+__device__ __forceinline__ int ws_perm(int rho) {          // LDS row (fragment jn, MFMA row i) -> column inside the slice
+    // fragment jn = 4*jq + jf, MFMA row i = 4*g + t  ->  column 64*jq + 32*(jf>>1) + 8*g + 4*(jf&1) + t: lane group g
+    // owns columns [8g, 8g+8) and [32+8g, 32+8g+8) of every 64-column group
+    const int jn = rho >> 4, i = rho & 15;
+    return (jn >> 2) * 64 + ((jn >> 1) & 1) * 32 + (i >> 2) * 8 + (jn & 1) * 4 + (i & 3);
+}
+__device__ __forceinline__ int ws_inv_perm(int n) {
+    const int jq = n >> 6, h = (n >> 5) & 1, g = (n >> 3) & 3, lo = (n >> 2) & 1, t = n & 3;
+    return ((jq * 4 + h * 2 + lo) << 4) + g * 4 + t;
+}
+
+enum : int { WS_GATE = 1, WS_ADD = 2, WS_MASK = 4 };
+
+template <typename TC> struct run8;                        // 8 consecutive C-typed values <-> raw 16-byte registers
+template <> struct run8<bf16_t> {
+    static constexpr int NV = 1;
+    static __device__ __forceinline__ void ld(const bf16_t* p, uint4* r) { r[0] = *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ void dec(const uint4* r, float* o) {
+        o[0] = __uint_as_float(r[0].x << 16); o[1] = __uint_as_float(r[0].x & 0xffff0000u);
+        o[2] = __uint_as_float(r[0].y << 16); o[3] = __uint_as_float(r[0].y & 0xffff0000u);
+        o[4] = __uint_as_float(r[0].z << 16); o[5] = __uint_as_float(r[0].z & 0xffff0000u);
+        o[6] = __uint_as_float(r[0].w << 16); o[7] = __uint_as_float(r[0].w & 0xffff0000u);
+    }
+};
+template <> struct run8<float> {
+    static constexpr int NV = 2;
+    static __device__ __forceinline__ void ld(const float* p, uint4* r) {
+        r[0] = *reinterpret_cast<const uint4*>(p);
+        r[1] = *reinterpret_cast<const uint4*>(p + 4);
+    }
+    static __device__ __forceinline__ void dec(const uint4* r, float* o) {
+        o[0] = __uint_as_float(r[0].x); o[1] = __uint_as_float(r[0].y); o[2] = __uint_as_float(r[0].z); o[3] = __uint_as_float(r[0].w);
+        o[4] = __uint_as_float(r[1].x); o[5] = __uint_as_float(r[1].y); o[6] = __uint_as_float(r[1].z); o[7] = __uint_as_float(r[1].w);
+    }
+};
+
+template <typename TC, int KIND, bool WKM>
+__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmK p) {
+    constexpr int BN = 128, KS = 8;
+    constexpr int K = KS * 32, PITCH = K * 2 + 16, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
+    constexpr bool GATE = KIND & WS_GATE, ADD = KIND & WS_ADD, MASK = KIND & WS_MASK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [BN][PITCH] bf16 rows of W (permuted) | bias[BN] f32
+    float* sbias = reinterpret_cast<float*>(smem + BN * PITCH);
+    const PoetGemmDesc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int frow = lane & 15, g = lane >> 4;
+
+    // ---- work assignment ----
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int NT = d.N / BN, groups = per / NT;
+    if (j >= groups * NT) return;
+    const int nt = j % NT, G = (j / NT) * 8 + xcd, NW = groups * 8 * 4;
+    const int n0 = nt * BN;
+    const int U = (d.M + 15) >> 4, wv = G * 4 + wid;
+    const int u_lo = (int)((int64_t)wv * U / NW), u_hi = (int)((int64_t)(wv + 1) * U / NW);
+
+    // ---- A prefetch for the first 32 rows goes out before W is touched ----
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(d.A);
+    uint4 a[2][KS];
+    auto arow = [&](int u, int fm) {                                   // row of fragment fm of the unit pair starting at u, clamped
+        return max(min(min(u + fm, u_hi - 1) * 16 + frow, d.M - 1), 0);
+    };
+    if (u_lo < u_hi) {
+        const bf16_t* p0 = A + (int64_t)arow(u_lo, 0) * d.lda + g * 8;
+        const bf16_t* p1 = A + (int64_t)arow(u_lo, 1) * d.lda + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            a[0][kk] = *reinterpret_cast<const uint4*>(p0 + kk * 32);
+            a[1][kk] = *reinterpret_cast<const uint4*>(p1 + kk * 32);
+        }
+    }
+
+    // ---- stationary W slice -> LDS (once) ----
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B);
+    // (all of a thread's requests are in flight before its first LDS store: one exposed latency, not one per chunk)
+    if constexpr (!WKM) {                                               // W[n][k], k contiguous
+        constexpr int CPR = K / 8, NIT = BN * CPR / 256;
+        uint4 wv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * 256, rho = idx / CPR, kc = idx - rho * CPR;
+            wv[i] = *reinterpret_cast<const uint4*>(B + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * 256, rho = idx / CPR, kc = idx - rho * CPR;
+            *reinterpret_cast<uint4*>(smem + rho * PITCH + kc * 16) = wv[i];
+        }
+    } else {                                                            // W[k][n] (input-gradient GEMMs): transpose on the way in
+        constexpr int NG = BN / 8, NIT = (K / 4) * NG / 256;            // item: 4 consecutive k x 8 consecutive n
+        uint4 wv[NIT][4];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * 256, kq = idx / NG, nl = (idx - kq * NG) * 8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[i][r] = *reinterpret_cast<const uint4*>(B + (int64_t)(kq * 4 + r) * d.ldb + n0 + nl);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * 256, kq = idx / NG, nl = (idx - kq * NG) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                uint32_t h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t w = (e >> 1) == 0 ? wv[i][r].x : (e >> 1) == 1 ? wv[i][r].y : (e >> 1) == 2 ? wv[i][r].z : wv[i][r].w;
+                    h[r] = (e & 1) ? (w >> 16) : (w & 0xffffu);
+                }
+                *reinterpret_cast<uint2*>(smem + ws_inv_perm(nl + e) * PITCH + kq * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    }
+    if (tid < BN) sbias[tid] = d.bias ? d.bias[n0 + tid] : 0.f;
+    __syncthreads();
+
+    const TC* addp = reinterpret_cast<const TC*>(d.add_src);
+    const TC* gate = reinterpret_cast<const TC*>(d.gate_ref);
+    TC* C = reinterpret_cast<TC*>(d.C);
+    const uint32_t sd = d.seed ^ (d.seed_dev ? *d.seed_dev * 0x9E3779B1u : 0u);
+    int woff = frow * PITCH + g * 16;
+
+    // One iteration = 32 rows (two 16-row fragments) x BN columns.  TAIL = false: both fragments wholly valid, no
+    // predication, every VMEM op of the body is unconditional, so the compiler's s_waitcnt counts are exact and nothing
+    // ever drains the queue: operands of the epilogue (gate / residual / row mask) are requested FIRST, the A refills
+    // follow inside the k loop, the stores come last.  TAIL = true (at most once per wave, after the loop): rows past the
+    // wave's range are clamped on load and skipped on store.
+    auto iteration = [&](int u, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        int grow[2];
+        grow[0] = TAIL ? arow(u, 0) : u * 16 + frow;
+        grow[1] = TAIL ? arow(u, 1) : u * 16 + 16 + frow;
+        uint4 gq[GATE ? 2 : 1][NQ][2][NV], rq[ADD ? 2 : 1][NQ][2][NV];
+        uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm) {
+            if constexpr (MASK) mk[fm] = d.row_mask[grow[fm]];
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int gcol = n0 + jq * 64 + h * 32 + g * 8;
+                    if constexpr (GATE) run8<TC>::ld(gate + (int64_t)grow[fm] * d.ldc + gcol, gq[fm][jq][h]);
+                    if constexpr (ADD) run8<TC>::ld(addp + (int64_t)grow[fm] * d.ld_add + gcol, rq[fm][jq][h]);
+                }
+        }
+        f32x4_t acc[2][FNT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < FNT; ++jn) acc[i][jn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(woff));          // W fragments are loop-invariant: keep them in LDS, not hoisted into 256 VGPRs
+        const char* wl = smem + woff;
+        const int un = TAIL ? u : u + 2;        // the refill of the last iteration re-reads its own rows (cache hit, never used)
+        const bf16_t* q0 = A + (int64_t)arow(un, 0) * d.lda + g * 8;
+        const bf16_t* q1 = A + (int64_t)arow(un, 1) * d.lda + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, a[0][kk]), a1 = __builtin_bit_cast(bf16x8_t, a[1][kk]);
+#pragma unroll
+            for (int jn = 0; jn < FNT; ++jn) {
+                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl + jn * 16 * PITCH + kk * 64));
+                acc[0][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[0][jn], 0, 0, 0);
+                acc[1][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[1][jn], 0, 0, 0);
+            }
+            a[0][kk] = *reinterpret_cast<const uint4*>(q0 + kk * 32);
+            a[1][kk] = *reinterpret_cast<const uint4*>(q1 + kk * 32);
+            __builtin_amdgcn_sched_barrier(0);                          // keep the refill HERE (the scheduler sinks it otherwise)
+        }
+
+        // ---- epilogue on registers: lane = row frow of fragment fm, columns [8g, 8g+8) and [32+8g, 32+8g+8) of each 64 ----
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm) {
+            const bool live = !TAIL || ((u + fm) < u_hi && (u + fm) * 16 + frow < d.M);
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                           // one run of 8 consecutive columns at a time
+                    const int lcol = jq * 64 + h * 32 + g * 8;          // column inside the slice
+                    float v[8];
+#pragma unroll
+                    for (int lo = 0; lo < 2; ++lo)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[lo * 4 + t] = acc[fm][jq * 4 + h * 2 + lo][t] * d.alpha;
+                    {
+                        float b[8];
+                        vec<float, 8>::ld(sbias + lcol, b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += b[e];
+                    }
+                    if (d.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if constexpr (GATE) {
+                        float gt[8];
+                        run8<TC>::dec(gq[fm][jq][h], gt);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gt[e] > 0.f ? v[e] * d.gate_scale : 0.f;
+                    }
+                    if (p.drop_thresh) {
+                        const uint32_t base = (uint32_t)grow[fm] * (uint32_t)d.N + (uint32_t)(n0 + lcol);
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {              // base is even: (e, e+1) share one hash
+                            const uint32_t hsh = drop_pair(sd, (base + e) >> 1);
+                            v[e] = (hsh & 0xffffu) >= p.drop_thresh ? v[e] * p.drop_scale : 0.f;
+                            v[e + 1] = (hsh >> 16) >= p.drop_thresh ? v[e + 1] * p.drop_scale : 0.f;
+                        }
+                    }
+                    if constexpr (ADD) {
+                        float r[8];
+                        run8<TC>::dec(rq[fm][jq][h], r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    }
+                    if constexpr (MASK) {
+                        if (mk[fm] & 0xffu) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                        }
+                    }
+                    if (live) {
+                        const int gcol = n0 + lcol;
+                        if (d.out_mode == 1) {
+                            const int hn = grow[fm] / d.hm_S, hs = grow[fm] - hn * d.hm_S, hm = gcol / d.hm_D, hd = gcol - hm * d.hm_D;
+                            vec<TC, 8>::st(C + (((int64_t)hn * d.hm_M + hm) * d.hm_S + hs) * d.hm_D + hd, v);
+                        } else {
+                            vec<TC, 8>::st(C + (int64_t)grow[fm] * d.ldc + gcol, v);
+                        }
+                    }
+                }
+        }
+    };
+
+    int u = u_lo;
+    const int u_full = min(u_hi, d.M >> 4);                             // units below u_full are wholly inside [0, M)
+    for (; u + 2 <= u_full; u += 2) iteration(u, std::false_type{});
+    if (u < u_hi) iteration(u, std::true_type{});
+}
+
+template <typename TC, int KIND, bool WKM>
+void ws_launch(const GemmK& p, int nblocks, hipStream_t st) {
+    constexpr int LDS = 128 * (8 * 64 + 16) + 128 * 4;
+    auto kern = gemm_ws_kernel<TC, KIND, WKM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), LDS, st, p);
+}
+
+// the epilogue kinds that occur on the path: forward {plain, +residual, +row mask}, input gradient {plain, ReLU gate,
+// accumulate, both}; anything else goes to the generic kernel
+template <typename TC>
+bool ws_kind(const GemmK& p, int nblocks, hipStream_t st) {
+    const PoetGemmDesc& d = p.d;
+    const int kind = (d.gate_ref ? WS_GATE : 0) | (d.add_src ? WS_ADD : 0) | (d.row_mask ? WS_MASK : 0);
+    if (!d.b_kmajor) {
+        switch (kind) {
+            case 0: ws_launch<TC, 0, false>(p, nblocks, st); return true;
+            case WS_ADD: ws_launch<TC, WS_ADD, false>(p, nblocks, st); return true;
+            case WS_MASK: ws_launch<TC, WS_MASK, false>(p, nblocks, st); return true;
+            default: return false;
+        }
+    }
+    switch (kind) {
+        case 0: ws_launch<TC, 0, true>(p, nblocks, st); return true;
+        case WS_GATE: ws_launch<TC, WS_GATE, true>(p, nblocks, st); return true;
+        case WS_ADD: ws_launch<TC, WS_ADD, true>(p, nblocks, st); return true;
+        case WS_GATE | WS_ADD:
+            if constexpr (sizeof(TC) == 2) { ws_launch<TC, WS_GATE | WS_ADD, true>(p, nblocks, st); return true; }
+            return false;                                               // f32: 128 VGPRs of prefetched epilogue operands
+        default: return false;
+    }
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace
+
+bool gemm_ws_try(const GemmK& p, hipStream_t st) {
+    const PoetGemmDesc& d = p.d;
+    static const int disabled = [] { const char* e = getenv("POET_GEMM_NO_WS"); return e && atoi(e) ? 1 : 0; }();
+    if (disabled) return false;
+    if (d.compute != POET_BF16 || d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || d.a_kmajor || d.batch != 1 || d.splitk != 1 ||
+        d.atomic || d.A2)
+        return false;
+    if (d.K != 256 || d.N % 128 != 0 || d.M < 4096) return false;
+    if (!p.a_vec || !p.b_vec || !p.c_vec) return false;
+    if (d.out_mode == 1 && d.hm_D % 8 != 0) return false;
+    const int NT = d.N / 128;
+    int per = 2 * device_cus() / 8;                                     // two workgroups per CU, per XCD
+    if (per < NT) per = NT;
+    const int nblocks = per * 8;
+    return d.c_dtype == POET_BF16 ? ws_kind<bf16_t>(p, nblocks, st) : ws_kind<float>(p, nblocks, st);
+}
+
+}  // namespace poet

@@ -492,3 +492,54 @@ def test_msda_fused_grid_queries_tiled_scatter(ops, shapes, m, dt):
     tol = 2e-4 if dt == torch.float32 else 2e-3
     assert (outs[0][0] - outs[1][0]).abs().max().item() < tol * max(1.0, scale)
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------------- streaming (weight-stationary) GEMM
+@pytest.mark.parametrize("cdtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("wdtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N", [256, 768, 80])
+def test_gemm_streaming_fwd(ops, cdtype, wdtype, N):
+    """M >= 4096, K = 256, bf16 activations: poet_gemm routes to gemm_ws.hip.  Full epilogue against torch, and the
+    dropout pattern against the generic tiled kernel (same call on a < 4096-row prefix: masks are index-based)."""
+    M, K = 5000 + 7, 256
+    x = _rand(M, K, seed=90).to(torch.bfloat16)
+    w = _rand(N, K, seed=91, scale=1 / math.sqrt(K)).to(wdtype)
+    b = _rand(N, seed=92)
+    add = _rand(M, N, seed=93).to(cdtype)
+    mask = (torch.arange(M) % 11 == 3).to(torch.uint8)
+    out = torch.empty(M, N, dtype=cdtype, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), out, act=1, add_src=dev(add), row_mask=dev(mask))
+    ref = (torch.relu(x.float() @ w.to(torch.bfloat16).float().t() + b) + add.float()).masked_fill(mask.bool()[:, None], 0)
+    _close(out, ref, torch.bfloat16, msg="streaming fwd")
+    # dropout: same (seed, row*N+col) stream as the generic kernel
+    o_ws = torch.empty(M, N, dtype=cdtype, device="cuda")
+    o_gen = torch.empty(1000, N, dtype=cdtype, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), o_ws, drop_p=0.25, seed=77)
+    ops.linear_fwd(dev(x[:1000].contiguous()), dev(w), dev(b), o_gen, drop_p=0.25, seed=77)
+    a, g = o_ws[:1000].float().cpu(), o_gen.float().cpu()
+    assert torch.equal(a == 0, g == 0)
+    assert (a - g).abs().max().item() <= 2e-2 * g.abs().max().item()
+    frac = (o_ws.float() == 0).float().mean().item()
+    assert abs(frac - 0.25) < 0.01
+
+
+@pytest.mark.parametrize("cdtype", [torch.bfloat16, torch.float32])
+def test_gemm_streaming_dx_and_headmajor(ops, cdtype):
+    M, n_out = 4999, 256
+    for k_in in (256, 1024):
+        dy = _rand(M, n_out, seed=94).to(torch.bfloat16)
+        w = _rand(n_out, k_in, seed=95, scale=1 / 16).to(torch.bfloat16)
+        gate = _rand(M, k_in, seed=96).to(cdtype)
+        addend = _rand(M, k_in, seed=97).to(cdtype)
+        out = dev(addend.clone())
+        ops.linear_dx(dev(dy), dev(w), out, rows=M, add_src=out, gate_ref=dev(gate), gate_scale=1.25)
+        ref = (dy.float() @ w.float()) * 1.25 * (gate.float() > 0) + addend.float()
+        _close(out, ref, torch.bfloat16, msg=f"streaming dX k_in={k_in}")
+    Nn, S, Mh, D = 2, 2600, 16, 16
+    x = _rand(Nn * S, 256, seed=98).to(torch.bfloat16)
+    wv = _rand(Mh * D, 256, seed=99, scale=1 / 16).to(torch.bfloat16)
+    mask = (torch.arange(Nn * S) % 7 == 0).to(torch.uint8)
+    v = torch.empty(Nn, Mh, S, D, dtype=cdtype, device="cuda")
+    ops.linear_fwd(dev(x), dev(wv), None, v, row_mask=dev(mask), head_major=(Mh, S, D))
+    ref = (x.float() @ wv.float().t()).masked_fill(mask.bool()[:, None], 0).view(Nn, S, Mh, D).permute(0, 2, 1, 3)
+    _close(v, ref, torch.bfloat16, msg="streaming head-major")
