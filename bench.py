@@ -125,11 +125,28 @@ def build_model(cfg, feats, precision, device):
     return model, crit
 
 
+def usable_cores():
+    """Cores this process may actually use: the cgroup CPU quota when there is one (threads beyond it only get the whole
+    process descheduled for the rest of each 100 ms period), else the visible CPU count."""
+    n = os.cpu_count() or 8
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, max_seconds=45.0):
     """The oracle (CPU restatement of the reference's PyTorch path, grid_sample MSDA) timed on the host cores
     of this box on a BOUNDED sample: YCB-V geometry at bs=1, 1 warm-up + up to 2 timed optimisation steps."""
     from oracle import poet_ref
-    cores = min(os.cpu_count() or 8, 32)
+    cores = min(usable_cores(), 32)
     torch.set_num_threads(cores)
     feats, targets = synth_batch(cfg, 1, 99, "cpu")
     torch.manual_seed(0)

@@ -14,9 +14,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpoet_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "gemm_dw.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
+RESOURCES = os.path.join(CSRC, "kernel_resources.txt")      # per-kernel VGPRs / scratch of the last build (git-ignored)
 
 
 def _hipcc() -> str:
@@ -33,6 +34,61 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _is_remark_context(line: str) -> bool:
+    t = line.strip()
+    return t.startswith("|") or (t[:1].isdigit() and " | " in t)
+
+
+def _resource_report(stderr: str, src: str):
+    """Parse -Rpass-analysis=kernel-resource-usage remarks: [(source, kernel, vgprs, agprs, scratch_bytes, occupancy)]."""
+    out, cur = [], None
+    for line in stderr.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass")[0].strip()
+        if body.startswith("Function Name:"):
+            cur = dict(src=src, name=body.split(":", 1)[1].strip(), vgprs=0, agprs=0, scratch=0, occ=0)
+            out.append(cur)
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            try:
+                v = int(v)
+            except ValueError:
+                continue
+            if k.startswith("VGPRs Spill"):
+                cur["spill"] = v
+            elif k.startswith("VGPRs"):
+                cur["vgprs"] = v
+            elif k.startswith("AGPRs"):
+                cur["agprs"] = v
+            elif k.startswith("ScratchSize"):
+                cur["scratch"] = v
+            elif k.startswith("Occupancy"):
+                cur["occ"] = v
+    return out
+
+
+def _write_resources(reports, verbose):
+    """A kernel that starts using scratch memory (register spills, or a by-value argument array indexed at run time) is
+    typically 2-3x slower and nothing else tells you: list them loudly and keep the full table next to the library."""
+    rows = [k for rep in reports for k in rep]
+    old = {}
+    if os.path.exists(RESOURCES):
+        for line in open(RESOURCES):
+            parts = line.rstrip("\n").split("\t")
+            if len(parts) == 6:
+                old[(parts[0], parts[1])] = line
+    for k in rows:
+        old[(k["src"], k["name"])] = f'{k["src"]}\t{k["name"]}\t{k["vgprs"]}\t{k["agprs"]}\t{k["scratch"]}\t{k["occ"]}\n'
+    with open(RESOURCES, "w") as f:
+        f.writelines(old[key] for key in sorted(old))
+    bad = [k for k in rows if k["scratch"] > 0]
+    if bad and verbose:
+        print(f"[poet_amd.build] WARNING: {len(bad)} kernel(s) use scratch memory:", file=sys.stderr)
+        for k in bad:
+            print(f'    {k["src"]}: {k["name"]}  scratch={k["scratch"]} B/lane  vgprs={k["vgprs"]}', file=sys.stderr)
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "gemm.cuh"), os.path.join(os.path.dirname(HERE), "include", "poet_hip.h")]
     objs, jobs = [], []
@@ -46,11 +102,19 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     def run(cmd):
         if verbose:
             print("[poet_amd.build]", " ".join(cmd[-4:]), flush=True)
-        subprocess.check_call(cmd)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        usage = _resource_report(r.stderr, os.path.basename(cmd[-3]))
+        rest = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not _is_remark_context(l))
+        if rest.strip():
+            print(rest, file=sys.stderr, flush=True)
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        return usage
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
-            list(ex.map(run, jobs))
+            reports = list(ex.map(run, jobs))
+        _write_resources([r for r in reports if r], verbose)
     if force or jobs or _stale(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB

@@ -14,5 +14,7 @@ struct GemmK {
 
 // launches the streaming kernel and returns true when the problem is one it handles; false = use the generic kernel
 bool gemm_ws_try(const GemmK& p, hipStream_t st);
+// same contract for the weight-gradient kernel (gemm_dw.hip)
+bool gemm_dw_try(const GemmK& p, hipStream_t st);
 
 }  // namespace poet

@@ -413,7 +413,7 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-    if (gemm_ws_try(p, st)) {              // tall activations x small stationary weight: streaming kernel (gemm_ws.hip)
+    if (gemm_dw_try(p, st) || gemm_ws_try(p, st)) {              // tall activations x small stationary weight: streaming kernel (gemm_ws.hip)
         POET_LAUNCH_CHECK();
         return POET_OK;
     }

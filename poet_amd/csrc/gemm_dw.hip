@@ -1,0 +1,183 @@
+// Weight-gradient GEMM for gfx950:  dW[n1, n2] += sum_r dY[r, n1] * X[r, n2],  r over ~1e5 token rows, n1/n2 in
+// {256 .. 1024} -- the backward of every encoder nn.Linear (reference: autograd of the Linear layers in
+// models/deformable_transformer.py:215-240 and of MSDeformAttn's projections).  Both operands are stored row-major with
+// the REDUCTION index r as the slow dimension, the worst case for an MFMA (a lane needs 8 consecutive r of one column).
+//
+//  * a workgroup owns one 128x128 tile of dW and one contiguous range of rows; it streams 64-row stages of the two
+//    operand panels (64 x 128 bf16 each) through a double-buffered LDS image that is a plain row-major copy of memory
+//    (coalesced 16-byte global loads, 16-byte LDS stores) with the 32-byte pieces of a row XOR-swizzled by the row index;
+//  * fragments come out of LDS with ds_read_b64_tr_b16 (CDNA4 transpose read): 16 lanes pointing at a 4 (r) x 16
+//    (column) patch get, per lane, 4 consecutive r of ONE column -- two of them are an MFMA operand, no register shuffles,
+//    and the swizzle makes every 16/32-lane phase of the read hit distinct banks;
+//  * few row ranges (16..64, chosen so ~1.5 workgroups per CU exist): the fp32 atomics that merge the partial tiles are
+//    the expensive part (they execute memory-side), so their count S*n1*n2 is kept small instead of the usual
+//    "1024 small split-K workgroups";
+//  * the tiles of one row range run on the same XCD (workgroup b -> XCD b % 8), so each panel is fetched from HBM once
+//    and re-read by the other tiles of that range through the XCD's L2.
+#include "gemm.cuh"
+
+namespace poet {
+
+namespace {
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+
+constexpr int DW_T = 128;            // tile edge (both n1 and n2)
+constexpr int DW_RS = 64;            // rows per stage
+constexpr int DW_ROWB = DW_T * 2;    // bytes per LDS row (no padding: swizzled)
+constexpr int DW_PANEL = DW_RS * DW_ROWB;          // 16 KB
+constexpr int DW_STAGE = 2 * DW_PANEL;             // Y panel | X panel
+
+__device__ __forceinline__ int dw_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+struct DwP {
+    const bf16_t* Y;
+    const bf16_t* X;
+    float* C;
+    int64_t ldy, ldx, ldc;
+    int rows, n1, n2, ntiles, tiles_n2, splits;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // ---- work assignment: (tile, row range); the tiles of a range share an XCD ----
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % p.ntiles, split = (j / p.ntiles) * 8 + xcd;
+    if (split >= p.splits) return;
+    const int n1_0 = (tile / p.tiles_n2) * DW_T, n2_0 = (tile % p.tiles_n2) * DW_T;
+    const int nst = (p.rows + DW_RS - 1) / DW_RS;                        // stages in the whole problem
+    const int s_lo = (int)((int64_t)split * nst / p.splits), s_hi = (int)((int64_t)(split + 1) * nst / p.splits);
+    if (s_lo >= s_hi) return;
+
+    // ---- global -> register staging: 4 x 16 B of each panel per thread per stage ----
+    const bf16_t* Yp = p.Y + n1_0;
+    const bf16_t* Xp = p.X + n2_0;
+    // One stage lives in registers on top of the two in LDS (a second register stage measured no faster: with two
+    // workgroups per CU ~64 KB are in flight per CU, above the ~47 KB Little's law asks for at full HBM rate).
+    uint4 ry[1][4], rx[1][4];
+    // loads are UNCONDITIONAL (row clamped, zero selected at the LDS store): with a branch around them the compiler cannot
+    // count outstanding loads and every LDS store would drain the queue, collapsing the prefetch depth
+    auto load = [&](int s, uint4 (&y)[4], uint4 (&x)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256, row = id >> 4, c = id & 15;
+            const int gr = min(s * DW_RS + row, p.rows - 1);
+            y[i] = *reinterpret_cast<const uint4*>(Yp + (int64_t)gr * p.ldy + c * 8);
+            x[i] = *reinterpret_cast<const uint4*>(Xp + (int64_t)gr * p.ldx + c * 8);
+        }
+    };
+    auto store = [&](char* buf, int s, const uint4 (&y)[4], const uint4 (&x)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256, row = id >> 4, c = id & 15;
+            const uint32_t m = (s < s_hi && s * DW_RS + row < p.rows) ? 0xffffffffu : 0u;   // value select, never a pointer select
+            const int off = row * DW_ROWB + ((((c >> 1) ^ dw_swz(row)) << 5) | ((c & 1) << 4));
+            *reinterpret_cast<uint4*>(buf + off) = make_uint4(y[i].x & m, y[i].y & m, y[i].z & m, y[i].w & m);
+            *reinterpret_cast<uint4*>(buf + DW_PANEL + off) = make_uint4(x[i].x & m, x[i].y & m, x[i].z & m, x[i].w & m);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane constants of the transpose read: source lane r of a 16-lane block points at row 8b + (r>>2) (+4 for the
+    // second half), 8-byte chunk r&3 of the fragment's 32-byte piece
+    const int r16 = lane & 15, b4 = lane >> 4;
+    const int trow = 8 * b4 + (r16 >> 2), tswz = (r16 >> 2) | ((b4 & 1) << 2), tcol = (r16 & 3) * 8;
+
+    auto compute = [&](const char* yb) {
+        const char* xb = yb + DW_PANEL;
+#pragma unroll
+        for (int ks = 0; ks < DW_RS / 32; ++ks) {
+            bf16x8_t fy[4], fx[4];
+            const int row0 = ks * 32 + trow;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int py = (((wm * 4 + f) ^ tswz) << 5) + tcol, px = (((wn * 4 + f) ^ tswz) << 5) + tcol;
+                struct { v4s_t lo, hi; } u, v;
+                u.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(yb + row0 * DW_ROWB + py));
+                u.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(yb + (row0 + 4) * DW_ROWB + py));
+                v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(xb + row0 * DW_ROWB + px));
+                v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(xb + (row0 + 4) * DW_ROWB + px));
+                fy[f] = __builtin_bit_cast(bf16x8_t, u);
+                fx[f] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[jj], acc[i][jj], 0, 0, 0);
+        }
+    };
+
+    // prologue: stage s_lo -> LDS buffer 0; stage s_lo+1 -> registers
+    load(s_lo, ry[0], rx[0]);
+    store(smem, s_lo, ry[0], rx[0]);
+    load(s_lo + 1, ry[0], rx[0]);
+    __syncthreads();
+
+    // iteration s: LDS buffer `buf` holds stage s, the registers hold s+1.  Park them in the other LDS buffer (its
+    // readers passed the barrier that ended iteration s-1), refill with s+2, compute s, barrier.
+    int buf = 0;
+    for (int s = s_lo; s < s_hi; ++s) {
+        store(smem + (buf ^ 1) * DW_STAGE, s + 1, ry[0], rx[0]);
+        load(s + 2, ry[0], rx[0]);
+        __builtin_amdgcn_sched_barrier(0);                  // the refill goes out BEFORE the MFMA block (the scheduler sinks it)
+        compute(smem + buf * DW_STAGE);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- merge the partial tile: lane holds rows 4*b4 + t, column r16 of each 16x16 fragment ----
+    float* Cp = p.C + (int64_t)(n1_0 + wm * 64) * p.ldc + n2_0 + wn * 64 + r16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                atomicAdd(Cp + (int64_t)(i * 16 + b4 * 4 + t) * p.ldc + jj * 16, acc[i][jj][t]);
+}
+
+}  // namespace
+
+bool gemm_dw_try(const GemmK& g, hipStream_t st) {
+    const PoetGemmDesc& d = g.d;
+    static const int disabled = [] { const char* e = getenv("POET_GEMM_NO_DW"); return e && atoi(e) ? 1 : 0; }();
+    if (disabled) return false;
+    // the dW form of poet_gemm: A = dY stored [K = rows][M = n1], B = X stored [K = rows][N = n2], fp32 atomic output
+    if (!d.a_kmajor || !d.b_kmajor || !(d.atomic || d.splitk > 1) || d.batch != 1 || d.A2) return false;
+    if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || d.c_dtype != POET_F32 || d.compute != POET_BF16) return false;
+    if (d.M % DW_T != 0 || d.N % DW_T != 0 || d.K < 4096 || d.alpha != 1.f) return false;
+    if (!g.a_vec || !g.b_vec) return false;
+    DwP p;
+    p.Y = reinterpret_cast<const bf16_t*>(d.A);
+    p.X = reinterpret_cast<const bf16_t*>(d.B);
+    p.C = reinterpret_cast<float*>(d.C);
+    p.ldy = d.lda; p.ldx = d.ldb; p.ldc = d.ldc;
+    p.rows = d.K; p.n1 = d.M; p.n2 = d.N;
+    p.tiles_n2 = d.N / DW_T;
+    p.ntiles = (d.M / DW_T) * p.tiles_n2;
+    static const int target = [] { const char* e = getenv("POET_DW_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    int per = target / 8 / p.ntiles;                                   // row ranges per XCD
+    if (per < 1) per = 1;
+    p.splits = per * 8;
+    const int nst = (p.rows + DW_RS - 1) / DW_RS;
+    if (p.splits > nst) p.splits = nst;
+    const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_dw_kernel, dim3(nblocks), dim3(256), 2 * DW_STAGE, st, p);
+    return true;
+}
+
+}  // namespace poet

@@ -118,12 +118,12 @@ __device__ __forceinline__ void load_weights(const MsdaP& p, int64_t row, int m,
 
 // pixel coordinates (px,py) of the P points of level l for (row, m)
 template <typename TQ, int L, int P, bool FUSED>
-__device__ __forceinline__ void load_points(const MsdaP& p, int64_t row, int n, int q, int m, int l, float* xy) {
+__device__ __forceinline__ void load_points(const MsdaP& p, int64_t row, int n, int q, int m, int l, int Wl, int Hl, float* xy) {
     if constexpr (FUSED) {
         const TQ* op = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq + (m * L + l) * P * 2;
         load_p<TQ, P>(op, xy, 2 * P);
         const float* rp = p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * L + l) * 2;
-        const float rx = rp[0] * (float)p.W[l] - 0.5f, ry = rp[1] * (float)p.H[l] - 0.5f;
+        const float rx = rp[0] * (float)Wl - 0.5f, ry = rp[1] * (float)Hl - 0.5f;
 #pragma unroll
         for (int i = 0; i < P; ++i) { xy[2 * i] += rx; xy[2 * i + 1] += ry; }
     } else {
@@ -131,8 +131,8 @@ __device__ __forceinline__ void load_points(const MsdaP& p, int64_t row, int n, 
         load_p<TQ, P>(lp, xy, 2 * P);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            xy[2 * i] = xy[2 * i] * (float)p.W[l] - 0.5f;
-            xy[2 * i + 1] = xy[2 * i + 1] * (float)p.H[l] - 0.5f;
+            xy[2 * i] = xy[2 * i] * (float)Wl - 0.5f;
+            xy[2 * i + 1] = xy[2 * i + 1] * (float)Hl - 0.5f;
         }
     }
 }
@@ -145,10 +145,11 @@ __device__ __forceinline__ int64_t xcd_contiguous_block(int64_t b, int64_t nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// 256 VGPRs (2 waves/SIMD) on purpose: the compiler keeps all 64 corner loads of a thread in flight; capping the
-// registers for more occupancy measured 2.7x-3.8x slower, lifting the cap (1 wave/SIMD) 1.2x slower.
+// One level at a time in a ROLLED loop: 4*P corner loads (16 B each) are in flight per thread, 64 VGPRs, and the kernel
+// needs 168 (3 waves/SIMD; capped at 128 it spills the softmax weights), so other waves cover the gather latency.  (Fully unrolled, the allocator tries to keep all
+// 16*P loads resident: 256 VGPRs at best, and a spilling variant -- 3x slower -- whenever unrelated code shifts.)
 template <typename TV, typename TQ, int L, int P, bool FUSED>
-__global__ __launch_bounds__(256, 2) void msda_fwd_kernel(const MsdaP p) {
+__global__ __launch_bounds__(256, 3) void msda_fwd_kernel(const MsdaP p) {
     const int64_t t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= p.total) return;
     const int64_t row = t / p.groups;
@@ -161,14 +162,20 @@ __global__ __launch_bounds__(256, 2) void msda_fwd_kernel(const MsdaP p) {
     const TV* vbase = reinterpret_cast<const TV*>(p.value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8;
 
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
     for (int l = 0; l < L; ++l) {
+        int Hl = p.H[0], Wl = p.W[0], Sl = p.start[0];      // select chain: a run-time index into the by-value kernel
+#pragma unroll                                               // argument would put the arrays in scratch memory
+        for (int k = 1; k < L; ++k)
+            if (l == k) { Hl = p.H[k]; Wl = p.W[k]; Sl = p.start[k]; }
         float xy[2 * P];
-        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, xy);
+        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, Wl, Hl, xy);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const Corner c = make_corner(xy[2 * i], xy[2 * i + 1], p.H[l], p.W[l], p.start[l], p.vs_s);
-            const float aw = a[l * P + i];
+            const Corner c = make_corner(xy[2 * i], xy[2 * i + 1], Hl, Wl, Sl, p.vs_s);
+            float aw = a[0];
+#pragma unroll
+            for (int k = 1; k < L * P; ++k) aw = (k == l * P + i) ? a[k] : aw;      // a[] stays in registers (l is a run-time index)
             float v00[8], v01[8], v10[8], v11[8];
             vec<TV, 8>::ld(vbase + c.o00, v00);
             vec<TV, 8>::ld(vbase + c.o01, v01);
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         float xy[2 * P], dxy[2 * P];
-        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, xy);
+        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, p.W[l], p.H[l], xy);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const Corner c = make_corner(xy[2 * i], xy[2 * i + 1], p.H[l], p.W[l], p.start[l], p.vs_s);
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         float xy[2 * P];
-        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, xy);
+        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, p.W[l], p.H[l], xy);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const Corner cn = make_corner(xy[2 * i], xy[2 * i + 1], p.H[l], p.W[l], p.start[l], p.vs_s);

@@ -192,6 +192,19 @@ class PoseMatcher(nn.Module):
             raise NotImplementedError("PoseMatcher: only bbox_mode='gt' is implemented")
         self.cost_bbox, self.cost_class = cost_bbox, cost_class
         self._cache = (None, None)
+        self._tb_cache = {}
+
+    def _host_boxes(self, boxes: torch.Tensor) -> np.ndarray:
+        """Host copy of a target's boxes; device tensors are copied once per (storage, version) and remembered."""
+        if not boxes.is_cuda:
+            return boxes.detach().numpy().astype(np.float32, copy=False)
+        key = (boxes.data_ptr(), boxes._version, tuple(boxes.shape))
+        hit = self._tb_cache.get(key)
+        if hit is None:
+            if len(self._tb_cache) > 4096:
+                self._tb_cache.clear()
+            hit = self._tb_cache[key] = boxes.detach().cpu().numpy().astype(np.float32, copy=False)
+        return hit
 
     @torch.no_grad()
     def forward(self, outputs, targets, n_boxes):
@@ -201,16 +214,41 @@ class PoseMatcher(nn.Module):
             return self._cache[1]
         bs, nq = pb.shape[:2]
         host = outputs.get("_pred_boxes_host")          # same values, already on the host: no device sync
-        out_bbox = torch.from_numpy(host).flatten(0, 1) if host is not None else pb.flatten(0, 1).detach().cpu()
-        tgt_bbox = torch.cat([t["boxes"].detach().cpu() for t in targets])
-        cost = (self.cost_bbox * torch.cdist(out_bbox, tgt_bbox, p=1)).view(bs, nq, -1)
-        sizes = [len(t["boxes"]) for t in targets]
+        out_bbox = (np.asarray(host, dtype=np.float32) if host is not None else pb.detach().cpu().numpy()).reshape(bs, nq, -1)
         res = []
-        for i, c in enumerate(cost.split(sizes, -1)):
-            r, cidx = linear_sum_assignment(c[i][: n_boxes[i]])
+        for i, t in enumerate(targets):
+            # L1 cost matrix of matcher.py:60-75 in numpy: the matrices are <= 20 x 20, and a torch CPU op here would wake
+            # the whole OpenMP pool every step (its spinning workers eat the container's CPU quota and the process gets
+            # descheduled for tens of ms while the GPU queue runs dry)
+            tb = self._host_boxes(t["boxes"])
+            c = self.cost_bbox * np.abs(out_bbox[i, : n_boxes[i], None, :] - tb[None, :, :]).sum(-1)
+            r, cidx = linear_sum_assignment(c)
             res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
         self._cache = (pb, res)
         return res
+
+
+class _PinnedRing:
+    """Round-robin pinned host buffers for small per-step index uploads; a slot is rewritten only after the H2D copy that
+    read it has completed (event per slot), so the host may run several steps ahead of the GPU."""
+
+    def __init__(self, slots=8, capacity=4096):
+        self.slots = [dict(buf=torch.empty(capacity, dtype=torch.int64).pin_memory(), ev=None) for _ in range(slots)]
+        self.pos = 0
+
+    def stage(self, arr: np.ndarray, device):
+        slot = self.slots[self.pos]
+        self.pos = (self.pos + 1) % len(self.slots)
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        if slot["buf"].numel() < arr.size:
+            slot["buf"] = torch.empty(2 * arr.size, dtype=torch.int64).pin_memory()
+        view = slot["buf"][: arr.size].view(arr.shape)
+        view.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)))
+        out = view.to(device, non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record()
+        return out
 
 
 class SetCriterion(nn.Module):
@@ -220,15 +258,27 @@ class SetCriterion(nn.Module):
             raise NotImplementedError("only the translation + rotation (6d) losses are implemented")
         self.matcher, self.weight_dict, self.losses = matcher, weight_dict, list(losses)
 
-    @staticmethod
-    def _gather_targets(targets, indices, device):
-        b = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
-        s = torch.cat([src for (src, _) in indices])
-        mvi = lambda j, ref: j if not ref.is_cuda else j.pin_memory().to(ref.device, non_blocking=True)
-        tt = torch.cat([t["relative_position"][mvi(j, t["relative_position"])] for t, (_, j) in zip(targets, indices)], 0)
-        tr = torch.cat([t["relative_rotation"][mvi(j, t["relative_rotation"])] for t, (_, j) in zip(targets, indices)], 0)
-        mv = lambda t: t.to(device) if t.is_cuda or device.type != "cuda" else t.pin_memory().to(device, non_blocking=True)
-        return mv(b), mv(s), mv(tt), mv(tr)
+    def _gather_targets(self, targets, indices, device):
+        """(batch idx, query idx, matched target translation, matched target rotation) for pose_estimation_transformer.py:
+        649-668.  The matcher's indices live on the host; they travel as ONE packed int64 array through a preallocated
+        pinned ring (a fresh pin_memory() per index tensor makes the host allocator register new pages every few steps,
+        which stalls the GPU queue for tens of ms), and the targets are gathered with one index op per field."""
+        counts = [int(t["relative_position"].shape[0]) for t in targets]
+        offs = np.concatenate([[0], np.cumsum(counts)[:-1]]) if counts else np.zeros(0, np.int64)
+        b = np.concatenate([np.full(len(src), i, np.int64) for i, (src, _) in enumerate(indices)])
+        sq = np.concatenate([np.asarray(src, dtype=np.int64) for (src, _) in indices])
+        g = np.concatenate([np.asarray(j, dtype=np.int64) + offs[i] for i, (_, j) in enumerate(indices)])
+        packed = np.stack([b, sq, g])
+        pos = torch.cat([t["relative_position"] for t in targets], 0)
+        rot = torch.cat([t["relative_rotation"] for t in targets], 0)
+        if device.type != "cuda":
+            idx = torch.from_numpy(packed).to(device)
+        else:
+            if not hasattr(self, "_ring"):
+                self._ring = _PinnedRing()
+            idx = self._ring.stage(packed, device)
+        gi = idx[2].to(pos.device) if pos.device != idx.device else idx[2]
+        return idx[0], idx[1], pos[gi].to(device), rot[gi].to(device)
 
     def _losses(self, outputs, gathered):
         b, s, tt, tr = gathered

@@ -543,3 +543,20 @@ def test_gemm_streaming_dx_and_headmajor(ops, cdtype):
     ops.linear_fwd(dev(x), dev(wv), None, v, row_mask=dev(mask), head_major=(Mh, S, D))
     ref = (x.float() @ wv.float().t()).masked_fill(mask.bool()[:, None], 0).view(Nn, S, Mh, D).permute(0, 2, 1, 3)
     _close(v, ref, torch.bfloat16, msg="streaming head-major")
+
+
+@pytest.mark.parametrize("n_out,k_in", [(256, 256), (768, 256), (256, 1024), (128, 384)])
+def test_gemm_dw_streaming(ops, n_out, k_in):
+    """rows >= 4096, bf16 operands, 128-multiples: poet_gemm routes the dW form to gemm_dw.hip (LDS transpose reads).
+    Also with operands that are column slices (ld > width) and a ragged row count."""
+    rows = 9000 + 37
+    dyf = _rand(rows, n_out + 64, seed=110).to(torch.bfloat16)
+    xf = _rand(rows, k_in + 128, seed=111).to(torch.bfloat16)
+    dy, x = dyf[:, 64:], xf[:, :k_in]
+    dw = torch.zeros(n_out, k_in, device="cuda")
+    base = _rand(n_out, k_in, seed=112)
+    dw.copy_(base)                                       # accumulates onto existing content
+    gdy, gx = dev(dyf), dev(xf)
+    ops.linear_dw(gdy[:, 64:], gx[:, :k_in], dw, rows=rows, ldy=n_out + 64, ldx=k_in + 128)
+    ref = dy.float().t() @ x.float() + base
+    _close(dw, ref, torch.bfloat16, scale=math.sqrt(rows), msg="streaming dW")
