@@ -71,14 +71,18 @@ const char* poet_hip_last_error(void);
  *               C[((n*hm_M + m)*hm_S + s)*hm_D + d].
  *   batch > 1: A/B/C advance by strideA/B/C elements per batch index (bias shared or strided by
  *   stride_bias).  splitk > 1 or atomic != 0: fp32 atomicAdd into C (C must be f32, pre-zeroed
- *   or holding the value to accumulate onto); bias/act/gate are then not allowed.
+ *   or holding the value to accumulate onto); bias/act/gate are then not allowed -- with one
+ *   exception, the WEIGHT-GRADIENT FORM (a_kmajor && b_kmajor && atomic: A = dY stored [rows][M],
+ *   B = X stored [rows][N], C = dW): there `bias` is an optional fp32 OUTPUT [M] that receives
+ *   += the column sums of A, i.e. the bias gradient of the same nn.Linear, produced in the same
+ *   pass over dY whenever the streaming kernel handles the shape (batch must be 1).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct PoetGemmDesc {
     const void* A;
     const void* A2;        /* optional, same dtype/layout as A, added on load */
     const void* B;
     void* C;
-    const float* bias;     /* optional [N] */
+    const float* bias;     /* optional [N]; weight-gradient form: optional fp32 [M] output (see above) */
     const void* add_src;   /* optional, dtype c_dtype, [M, ld_add] */
     const void* gate_ref;  /* optional, dtype c_dtype, [M, ldc] */
     const uint8_t* row_mask; /* optional [M] */

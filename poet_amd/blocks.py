@@ -78,8 +78,7 @@ def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate,
     rows, d = N * S, M * D
     dVr = empty((rows, d), act or inp2d.dtype, inp2d)
     ops.vgrad_to_rows(dV, vstrides(M, S, D), row_mask, dVr, N, S, M, D)
-    ops.linear_dw(dVr, inp2d, gW, rows=rows)
-    ops.colsum(dVr, d, gb, 1, rows, d)
+    ops.linear_dw(dVr, inp2d, gW, rows=rows, db=gb)
     if dinp is not None:
         ops.linear_dx(dVr, Wb(W, dVr), dinp, rows=rows, add_src=dinp if accumulate else None)
 
@@ -103,15 +102,13 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
     dOA = torch.empty_like(OA)
     ops.msda_fused_bwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
                        grid_queries=grid_queries)
-    ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldq)
-    ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldq)
+    plain = seg_sums is None
+    ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldq, db=g_so_b if plain else None)
+    ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldq, db=g_aw_b if plain else None)
     if seg_sums is not None:      # per-level column sums (encoder): feeds both the biases and level_embed
         ops.colsum(dOA, ldq, seg_sums, N, Lq, ldq, geom.c_segs, geom.L)
         ops.colsum(seg_sums, ldq, g_so_b, 1, geom.L, 2 * mlp)
         ops.colsum(seg_sums[:, 2 * mlp:], ldq, g_aw_b, 1, geom.L, mlp)
-    else:
-        ops.colsum(dOA, ldq, g_so_b, 1, rows, 2 * mlp)
-        ops.colsum(dOA[:, 2 * mlp:], ldq, g_aw_b, 1, rows, mlp)
     if dq is not None:
         ops.linear_dx(dOA, Wb(so_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq if dq_accumulate else None)
         ops.linear_dx(dOA[:, 2 * mlp:], Wb(aw_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq)
@@ -140,8 +137,7 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
     separate = p > 0 or z.dtype != dy.dtype
     dxo = torch.empty_like(z) if separate else dz
     ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dxo if separate else None, ggamma, gbeta, rows, d, p, seed)
-    ops.linear_dw(dxo, x_in, gW, rows=rows)
-    ops.colsum(dxo, d, gb, 1, rows, d)
+    ops.linear_dw(dxo, x_in, gW, rows=rows, db=gb)
     dx_in = empty((rows, W.shape[1]), x_in.dtype, x_in)
     ops.linear_dx(dxo, Wb(W, dxo), dx_in, rows=rows, gate_ref=gate_ref, gate_scale=gate_scale)
     return dz, dx_in
@@ -162,8 +158,7 @@ def ffn_bwd(dy, x, W1, W2, gamma, saved, p_h, p_o, seed_o, gW1, gb1, gW2, gb2, g
     rows, f = Hd.shape
     dz, dh = proj_ln_bwd(dy, Hd, W2, gamma, ln_saved, p_o, seed_o, gW2, gb2, ggamma, gbeta,
                          gate_ref=Hd, gate_scale=1.0 / (1.0 - p_h) if p_h > 0 else 1.0)
-    ops.linear_dw(dh, x, gW1, rows=rows)
-    ops.colsum(dh, f, gb1, 1, rows, f)
+    ops.linear_dw(dh, x, gW1, rows=rows, db=gb1)
     ops.linear_dx(dh, Wb(W1, dh), dz, rows=rows, add_src=dz)
     return dz
 

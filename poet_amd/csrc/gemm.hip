@@ -393,10 +393,15 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.batch < 1) d.batch = 1;
     if (d.splitk < 1) d.splitk = 1;
     const bool atomic = d.atomic || d.splitk > 1;
+    // weight-gradient form (A = dY and B = X both stored [rows][.], fp32 accumulate): `bias` is then an OUTPUT, the fp32
+    // [M] vector that receives += the column sums of A, i.e. the bias gradient that always accompanies a weight gradient
+    const bool dw_form = atomic && d.a_kmajor && d.b_kmajor;
+    float* ysum = dw_form ? const_cast<float*>(d.bias) : nullptr;
     if (atomic) {
         POET_CHECK(d.c_dtype == POET_F32, POET_ERR_ARG, "poet_gemm: atomic/split-K needs fp32 C");
-        POET_CHECK(!d.bias && !d.act && !d.gate_ref && !d.add_src && d.drop_p == 0.f && !d.row_mask, POET_ERR_ARG,
+        POET_CHECK((!d.bias || dw_form) && !d.act && !d.gate_ref && !d.add_src && d.drop_p == 0.f && !d.row_mask, POET_ERR_ARG,
                    "poet_gemm: atomic/split-K allows no epilogue");
+        POET_CHECK(!ysum || d.batch == 1, POET_ERR_UNSUPPORTED, "poet_gemm: bias-gradient output needs batch == 1");
     }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.out_mode == 1) POET_CHECK(d.hm_M > 0 && d.hm_S > 0 && d.hm_D > 0 && d.hm_M * d.hm_D == d.N, POET_ERR_ARG, "poet_gemm: head-major dims");
@@ -413,7 +418,16 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-    if (gemm_dw_try(p, st) || gemm_ws_try(p, st)) {              // tall activations x small stationary weight: streaming kernel (gemm_ws.hip)
+    if (gemm_dw_try(p, st)) {              // weight gradients of tall activations (gemm_dw.hip), bias gradient fused
+        POET_LAUNCH_CHECK();
+        return POET_OK;
+    }
+    if (ysum) {                            // generic path: the column sums are a separate launch
+        const int rc = poet_colsum(d.A, d.lda, ysum, 1, d.K, d.M, nullptr, 1, d.a_dtype, stream);
+        if (rc) return rc;
+        d.bias = nullptr;
+    }
+    if (gemm_ws_try(p, st)) {              // tall activations x small stationary weight: streaming kernel (gemm_ws.hip)
         POET_LAUNCH_CHECK();
         return POET_OK;
     }

@@ -35,6 +35,7 @@ struct DwP {
     const bf16_t* Y;
     const bf16_t* X;
     float* C;
+    float* ysum;          // optional [n1]: += column sums of Y (the bias gradient), accumulated by the n2-tile-0 workgroups
     int64_t ldy, ldx, ldc;
     int rows, n1, n2, ntiles, tiles_n2, splits;
 };
@@ -70,13 +71,22 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
             x[i] = *reinterpret_cast<const uint4*>(Xp + (int64_t)gr * p.ldx + c * 8);
         }
     };
+    const bool do_sum = p.ysum != nullptr && n2_0 == 0;                 // workgroup-uniform
+    float ys[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};            // this thread's 8 columns (chunk tid & 15) of Y
     auto store = [&](char* buf, int s, const uint4 (&y)[4], const uint4 (&x)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + i * 256, row = id >> 4, c = id & 15;
             const uint32_t m = (s < s_hi && s * DW_RS + row < p.rows) ? 0xffffffffu : 0u;   // value select, never a pointer select
             const int off = row * DW_ROWB + ((((c >> 1) ^ dw_swz(row)) << 5) | ((c & 1) << 4));
-            *reinterpret_cast<uint4*>(buf + off) = make_uint4(y[i].x & m, y[i].y & m, y[i].z & m, y[i].w & m);
+            const uint4 ym = make_uint4(y[i].x & m, y[i].y & m, y[i].z & m, y[i].w & m);
+            if (do_sum) {
+                ys[0] += __uint_as_float(ym.x << 16); ys[1] += __uint_as_float(ym.x & 0xffff0000u);
+                ys[2] += __uint_as_float(ym.y << 16); ys[3] += __uint_as_float(ym.y & 0xffff0000u);
+                ys[4] += __uint_as_float(ym.z << 16); ys[5] += __uint_as_float(ym.z & 0xffff0000u);
+                ys[6] += __uint_as_float(ym.w << 16); ys[7] += __uint_as_float(ym.w & 0xffff0000u);
+            }
+            *reinterpret_cast<uint4*>(buf + off) = ym;
             *reinterpret_cast<uint4*>(buf + DW_PANEL + off) = make_uint4(x[i].x & m, x[i].y & m, x[i].z & m, x[i].w & m);
         }
     };
@@ -134,6 +144,20 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
         buf ^= 1;
     }
 
+    // ---- bias gradient: 16 threads (tid >> 4) hold partial sums of the same 8 columns; fold them through LDS ----
+    if (do_sum) {                                                        // (the last barrier of the loop freed smem)
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * DW_T + (tid & 15) * 8 + e] = ys[e];
+        __syncthreads();
+        if (tid < DW_T) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g * DW_T + tid];
+            atomicAdd(p.ysum + n1_0 + tid, t);
+        }
+    }
+
     // ---- merge the partial tile: lane holds rows 4*b4 + t, column r16 of each 16x16 fragment ----
     float* Cp = p.C + (int64_t)(n1_0 + wm * 64) * p.ldc + n2_0 + wn * 64 + r16;
 #pragma unroll
@@ -160,6 +184,7 @@ bool gemm_dw_try(const GemmK& g, hipStream_t st) {
     p.Y = reinterpret_cast<const bf16_t*>(d.A);
     p.X = reinterpret_cast<const bf16_t*>(d.B);
     p.C = reinterpret_cast<float*>(d.C);
+    p.ysum = const_cast<float*>(d.bias);
     p.ldy = d.lda; p.ldx = d.ldb; p.ldc = d.ldc;
     p.rows = d.K; p.n1 = d.M; p.n2 = d.N;
     p.tiles_n2 = d.N / DW_T;

@@ -208,11 +208,12 @@ def _splitk_for(M, N, K):
     return max(1, min(-(-1024 // tiles), -(-K // (512 if big else 128))))
 
 
-def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None):
-    """dW[N_out, K_in] += dy[rows, N_out]^T @ x[rows, K_in]   (fp32 atomics, split-K over rows)."""
+def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None, db=None):
+    """dW[N_out, K_in] += dy[rows, N_out]^T @ x[rows, K_in]   (fp32 atomics, split-K over rows);
+    db[N_out] += column sums of dy (optional: the bias gradient, fused into the same pass where possible)."""
     n_out, k_in = dW.shape
     return gemm(dy, x, dW, n_out, k_in, rows, lda=ldy or n_out, ldb=ldx or k_in, ldc=k_in, a_kmajor=True, b_kmajor=True,
-                splitk=_splitk_for(n_out, k_in, rows), atomic=True)
+                splitk=_splitk_for(n_out, k_in, rows), atomic=True, bias=db)
 
 
 # ---- MSDA ------------------------------------------------------------------------------------------

@@ -560,3 +560,17 @@ def test_gemm_dw_streaming(ops, n_out, k_in):
     ops.linear_dw(gdy[:, 64:], gx[:, :k_in], dw, rows=rows, ldy=n_out + 64, ldx=k_in + 128)
     ref = dy.float().t() @ x.float() + base
     _close(dw, ref, torch.bfloat16, scale=math.sqrt(rows), msg="streaming dW")
+
+
+@pytest.mark.parametrize("rows,n_out,k_in", [(9037, 256, 384), (9037, 1024, 256), (700, 256, 256), (5000, 66, 256)])
+def test_gemm_dw_bias_gradient(ops, rows, n_out, k_in):
+    """linear_dw(db=...): db += column sums of dy -- fused in gemm_dw.hip (first two) or a separate launch behind the
+    same C call (small / ragged shapes)."""
+    dy = _rand(rows, n_out, seed=120).to(torch.bfloat16)
+    x = _rand(rows, k_in, seed=121).to(torch.bfloat16)
+    dw = torch.zeros(n_out, k_in, device="cuda")
+    db0 = _rand(n_out, seed=122)
+    db = dev(db0.clone())
+    ops.linear_dw(dev(dy), dev(x), dw, rows=rows, db=db)
+    _close(dw, dy.float().t() @ x.float(), torch.bfloat16, scale=math.sqrt(rows), msg="dW")
+    _close(db, dy.float().sum(0) + db0, torch.float32, scale=math.sqrt(rows), msg="db")
