@@ -35,6 +35,8 @@
  *       deformable_transformer.py:128-141).
  *   poet_enc_ref_points        deformable_transformer.py:217-230.
  *   poet_pose_finish_fwd/_bwd  class-slice gather + 6D->R (pose_estimation_transformer.py:354-393,434-451).
+ *   poet_pose_loss             translation / rotation losses of all decoder layers + their gradients
+ *                              (pose_estimation_transformer.py:635-674).
  *   poet_adamw / poet_sqnorm   optimizer.step + clip_grad_norm_ over the flat arenas (engine.py:75-81).
  */
 #ifndef POET_HIP_H
@@ -252,6 +254,15 @@ int poet_pose_finish_fwd(const float* rot_all, const float* trans_all, const int
                          float* rot, float* trans, int R, int ncls, void* stream);
 int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* drot, const float* dtrans,
                          float* drot_all, float* dtrans_all, int R, int ncls, void* stream);
+
+/* Pose losses of ALL decoder layers in one launch (pose_estimation_transformer.py:635-674, the 'translation' and
+ * 'rotation' terms of SetCriterion): trans (L, NQ, 3), rot (L, NQ, 3, 3) fp32 predictions; the n_obj matched pairs are
+ * (query_idx[i] in [0, NQ) = image*Q + query, tgt_trans[i] (3), tgt_rot[i] (3,3)).  losses (L, 2) =
+ * [mean ||t - t_gt||_2, mean acos(clamp((tr(R R_gt^T) - 1)/2, -1+1e-6, 1-1e-6))]; grad_trans / grad_rot (same shapes as
+ * the predictions, fully written) = d losses[l][0] / d trans[l] and d losses[l][1] / d rot[l]. */
+int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_idx, const float* tgt_trans,
+                   const float* tgt_rot, int n_obj, int L, int NQ, float* losses, float* grad_trans, float* grad_rot,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Flat-arena optimizer pieces.  poet_sqnorm: out[0] += sum(g^2) (fp32, caller zero-fills).

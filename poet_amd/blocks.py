@@ -289,9 +289,8 @@ def dec_layer_bwd(dt3, sv, P_, G, pre, ref_in, geom, N, Q, M, npts, dV):
                 pd, seeds[0])
     Win = P_["self_attn.in_proj_weight"]
     gWin, gbin = g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias")
-    ops.linear_dw(dpk, sv["qk"], gWin[: 2 * d], rows=rows, ldy=3 * d)
-    ops.linear_dw(dpk[:, 2 * d:], sv["tgt"], gWin[2 * d:], rows=rows, ldy=3 * d)
-    ops.colsum(dpk, 3 * d, gbin, 1, rows, 3 * d)
+    ops.linear_dw(dpk, sv["qk"], gWin[: 2 * d], rows=rows, ldy=3 * d, db=gbin[: 2 * d])
+    ops.linear_dw(dpk[:, 2 * d:], sv["tgt"], gWin[2 * d:], rows=rows, ldy=3 * d, db=gbin[2 * d:])
     ops.linear_dx(dpk, Win[: 2 * d], dtgt, rows=rows, ldy=3 * d, add_src=dtgt)
     ops.linear_dx(dpk[:, 2 * d:], Win[2 * d:], dtgt, rows=rows, ldy=3 * d, add_src=dtgt)
     return dtgt
@@ -311,14 +310,11 @@ def mlp3_fwd(h, Ws, bs):
 def mlp3_bwd(dc, h, Ws, saved, gWs, gbs, dh, accumulate):
     a, b = saved
     rows = h.shape[0]
-    ops.linear_dw(dc, b, gWs[2], rows=rows)
-    ops.colsum(dc, dc.shape[1], gbs[2], 1, rows, dc.shape[1])
+    ops.linear_dw(dc, b, gWs[2], rows=rows, db=gbs[2])
     db_ = torch.empty_like(b)
     ops.linear_dx(dc, Ws[2], db_, rows=rows, gate_ref=b)
-    ops.linear_dw(db_, a, gWs[1], rows=rows)
-    ops.colsum(db_, db_.shape[1], gbs[1], 1, rows, db_.shape[1])
+    ops.linear_dw(db_, a, gWs[1], rows=rows, db=gbs[1])
     da = torch.empty_like(a)
     ops.linear_dx(db_, Ws[1], da, rows=rows, gate_ref=a)
-    ops.linear_dw(da, h, gWs[0], rows=rows)
-    ops.colsum(da, da.shape[1], gbs[0], 1, rows, da.shape[1])
+    ops.linear_dw(da, h, gWs[0], rows=rows, db=gbs[0])
     ops.linear_dx(da, Ws[0], dh, rows=rows, add_src=dh if accumulate else None)

@@ -305,6 +305,55 @@ __global__ __launch_bounds__(256) void pose_fwd_kernel(const float* __restrict__
     for (int i = 0; i < 3; ++i) trans[(int64_t)r * 3 + i] = trans_all[(int64_t)r * ncls * 3 + c * 3 + i];
 }
 
+
+// ---- pose losses (pose_estimation_transformer.py:635-674) for all decoder layers in one launch ----
+// One workgroup per layer: L2 translation distance and geodesic rotation angle of the matched (query, target) pairs,
+// averaged over the pairs, PLUS the gradient of each of the two losses w.r.t. that layer's predictions (zero rows for
+// unmatched queries).  Replaces ~70 stack / index / elementwise launches of the PyTorch formulation and their backward.
+__global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict__ trans, const float* __restrict__ rot,
+                                                        const int64_t* __restrict__ qi, const float* __restrict__ tt,
+                                                        const float* __restrict__ tr, int n_obj, int NQ,
+                                                        float* __restrict__ losses, float* __restrict__ gt, float* __restrict__ gr) {
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const float* T = trans + (int64_t)l * NQ * 3;
+    const float* Rm = rot + (int64_t)l * NQ * 9;
+    float* GT = gt + (int64_t)l * NQ * 3;
+    float* GR = gr + (int64_t)l * NQ * 9;
+    for (int i = tid; i < NQ * 3; i += 256) GT[i] = 0.f;
+    for (int i = tid; i < NQ * 9; i += 256) GR[i] = 0.f;
+    __syncthreads();
+    const float inv_n = 1.f / (float)max(n_obj, 1);
+    float lt = 0.f, lr = 0.f;
+    for (int i = tid; i < n_obj; i += 256) {
+        const int64_t q = qi[i];
+        float d[3], s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d[k] = T[q * 3 + k] - tt[i * 3 + k]; s2 += d[k] * d[k]; }
+        const float nrm = sqrtf(s2);
+        lt += nrm;
+        const float sc = nrm > 0.f ? inv_n / nrm : 0.f;            // d||d||/dd = d/||d|| (0 at d = 0, where torch gives NaN)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) GT[q * 3 + k] = d[k] * sc;
+        float tg[9], trc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { tg[k] = tr[i * 9 + k]; trc += Rm[q * 9 + k] * tg[k]; }   // trace(R_pred R_gt^T)
+        const float x = 0.5f * (trc - 1.f);
+        const float xc = fminf(fmaxf(x, -1.f + 1e-6f), 1.f - 1e-6f);
+        lr += acosf(xc);
+        const float dac = (x == xc) ? -0.5f * inv_n * rsqrtf(1.f - xc * xc) : 0.f;   // clamp passes the gradient only inside
+#pragma unroll
+        for (int k = 0; k < 9; ++k) GR[q * 9 + k] = dac * tg[k];
+    }
+    lt = wave_sum(lt); lr = wave_sum(lr);
+    __shared__ float red[2][4];
+    if ((tid & 63) == 0) { red[0][tid >> 6] = lt; red[1][tid >> 6] = lr; }
+    __syncthreads();
+    if (tid == 0) {
+        losses[l * 2 + 0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_n;
+        losses[l * 2 + 1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_n;
+    }
+}
+
 __global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__ rot_all, const int32_t* __restrict__ cls,
                                                        const float* __restrict__ drot, const float* __restrict__ dtrans,
                                                        float* __restrict__ drot_all, float* __restrict__ dtrans_all,
@@ -560,6 +609,17 @@ extern "C" int poet_pose_finish_fwd(const float* rot_all, const float* trans_all
 extern "C" int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* drot, const float* dtrans, float* drot_all, float* dtrans_all, int R, int ncls, void* stream) {
     POET_CHECK(rot_all && cls && drot && dtrans && drot_all && dtrans_all && R > 0 && ncls > 0, POET_ERR_ARG, "pose_finish_bwd: bad args");
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, ST, rot_all, cls, drot, dtrans, drot_all, dtrans_all, R, ncls);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_idx, const float* tgt_trans,
+                              const float* tgt_rot, int n_obj, int L, int NQ, float* losses, float* grad_trans, float* grad_rot,
+                              void* stream) {
+    POET_CHECK(trans && rot && losses && grad_trans && grad_rot && L > 0 && NQ > 0 && n_obj >= 0, POET_ERR_ARG, "pose_loss: bad args");
+    POET_CHECK(n_obj == 0 || (query_idx && tgt_trans && tgt_rot), POET_ERR_ARG, "pose_loss: null match arrays");
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(L), dim3(256), 0, ST, trans, rot, query_idx, tgt_trans, tgt_rot, n_obj, NQ, losses,
+                       grad_trans, grad_rot);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

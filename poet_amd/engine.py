@@ -307,6 +307,21 @@ class SetCriterion(nn.Module):
             # pose_estimation_transformer.py:635-674 are evaluated in ONE batched pass -- same values, ~10x fewer launches
             b, s, tt, tr = self._gather_targets(targets, indices, dev)
             n_obj = len(tt)
+            stacked = outputs.get("_stacked")
+            if stacked is not None and dev.type == "cuda" and stacked[0].shape[0] == len(aux_list) + 1:
+                # all layers, both terms and their gradients in ONE kernel (the PyTorch form below is ~70 launches forward
+                # plus as many backward, all tiny and all on the critical path between the two HIP graphs)
+                from .functional import PoseLossFn
+                trans_all, rot_all = stacked
+                Q = trans_all.shape[2]
+                vec = PoseLossFn.apply(trans_all, rot_all, b * Q + s, tt, tr, n_obj)
+                L = vec.shape[0]
+                losses = LossDict({"loss_trans": vec[L - 1, 0], "loss_rot": vec[L - 1, 1]})
+                for i in range(L - 1):
+                    losses[f"loss_trans_{i}"] = vec[i, 0]
+                    losses[f"loss_rot_{i}"] = vec[i, 1]
+                losses.vec = vec
+                return losses
             layers = [outputs] + list(aux_list)
             st = torch.stack([o["pred_translation"] for o in layers])[:, b, s]              # (L, n_obj, 3)
             sr = torch.stack([o["pred_rotation"] for o in layers])[:, b, s]                 # (L, n_obj, 3, 3)
@@ -325,6 +340,29 @@ class SetCriterion(nn.Module):
                 gathered, last = self._gather_targets(targets, ix, dev), ix
             losses.update({f"{k}_{i}": v for k, v in self._losses(aux, gathered).items()})
         return losses
+
+
+    def total(self, loss_dict):
+        """sum_k weight_dict[k] * loss_dict[k] (engine.py:62 of the reference).  With the fused loss kernel the terms are
+        rows of one (L, 2) tensor and the weighted sum is two launches instead of ~20 (and as many in backward)."""
+        vec = getattr(loss_dict, "vec", None)
+        if vec is None:
+            return sum(loss_dict[k] * self.weight_dict[k] for k in loss_dict if k in self.weight_dict)
+        L = vec.shape[0]
+        key = (vec.device, L)
+        if getattr(self, "_wkey", None) != key:
+            w = torch.zeros((L, 2), dtype=torch.float32)
+            for i in range(L):
+                suffix = "" if i == L - 1 else f"_{i}"
+                w[i, 0] = self.weight_dict.get("loss_trans" + suffix, 0.0)
+                w[i, 1] = self.weight_dict.get("loss_rot" + suffix, 0.0)
+            self._w, self._wkey = w.to(vec.device), key
+        return (vec * self._w).sum()
+
+
+class LossDict(dict):
+    """dict of differentiable scalar losses that also carries them stacked (`vec`, (L, 2)) for SetCriterion.total()."""
+    vec = None
 
 
 def build_weight_dict(dec_layers, t_coef=1.0, r_coef=1.0, aux=True):
@@ -386,7 +424,7 @@ class Trainer:
         out, n_boxes = self.model(samples, targets)
         loss_dict = self.criterion(out, targets, n_boxes)
         wd = self.criterion.weight_dict
-        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        total = self.criterion.total(loss_dict) if hasattr(self.criterion, "total") else sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
         self.arena.zero_grad()
         total.backward()
         if self.reducer is not None:
@@ -514,6 +552,6 @@ class GraphedTrainer(Trainer):
         out = m.make_outputs(rot, trans, self.s_boxes, self.s_cls, boxes)
         loss_dict = self.criterion(out, targets, n_boxes)
         wd = self.criterion.weight_dict
-        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        total = self.criterion.total(loss_dict) if hasattr(self.criterion, "total") else sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
         total.backward()
         return total.detach(), loss_dict

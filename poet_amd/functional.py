@@ -77,6 +77,7 @@ class EncoderFn(torch.autograd.Function):
             dx = B.enc_layer_bwd(dx, ctx.saved[i], _pdict(names, params, pre), G, pre, ctx.ref, S * geom.L * 2, ctx.mask, geom,
                                  N, cfg["M"], cfg["P"], g_level)
             ctx.saved[i] = None
+        ops.SIDE.join()
         announce("2_encoder")
         dsrc = dx.view(N, S, d) if ctx.need_src else None
         return (dsrc, None, G.ret[-1], None, None, None, None, None, *G.ret[:-1])
@@ -138,6 +139,7 @@ class DecoderFn(torch.autograd.Function):
                              cfg.get("act"))
             first = False
             ctx.saved[i] = None
+        ops.SIDE.join()
         announce("1_decoder")
         dmemory = dmem.view(N, S, d) if ctx.need_mem else None
         dtgt = dx.view(N, Q, d) if ctx.need_tgt else None
@@ -189,6 +191,7 @@ class HeadsFn(torch.autograd.Function):
                        [G(pr + f"{k}.bias") for k in range(3)], dh, False)
             B.mlp3_bwd(dt_all, h, [Pt[f"{k}.weight"] for k in range(3)], ts, [G(pt + f"{k}.weight") for k in range(3)],
                        [G(pt + f"{k}.bias") for k in range(3)], dh, True)
+        ops.SIDE.join()
         announce("0_heads")
         return (dhs, None, None, None, *G.ret)
 
@@ -261,6 +264,7 @@ class InputProjFn(torch.autograd.Function):
                          strideA=HW * d, strideB=C * HW, strideC=0, atomic=True, splitk=max(1, min(8, HW // 512)))
             else:
                 ops.linear_dw(dpre.view(N * HW, d), col, gW.view(d, -1), rows=N * HW)
+        ops.SIDE.join()
         announce("3_input_proj")
         return (None, None, None, None, None, *G.ret)
 
@@ -270,6 +274,28 @@ class InputProjFn(torch.autograd.Function):
 # ====================================================================================================
 MSDA_PARAMS = ("sampling_offsets.weight", "sampling_offsets.bias", "attention_weights.weight", "attention_weights.bias",
                "value_proj.weight", "value_proj.bias", "output_proj.weight", "output_proj.bias")
+
+
+class PoseLossFn(torch.autograd.Function):
+    """losses (L, 2) = per-layer [translation, rotation] loss of the matched pairs (poet_pose_loss); the kernel also
+    returns d losses / d predictions, so backward is two broadcast multiplies."""
+
+    @staticmethod
+    def forward(ctx, trans, rot, qi, tt, tr, n_obj):
+        trans, rot = trans.contiguous(), rot.contiguous()
+        L = trans.shape[0]
+        losses = torch.empty((L, 2), dtype=torch.float32, device=trans.device)
+        gt, gr = torch.empty_like(trans), torch.empty_like(rot)
+        ops.pose_loss(trans, rot, qi, tt.contiguous(), tr.contiguous(), int(n_obj), losses, gt, gr)
+        ctx.save_for_backward(gt, gr)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        gt, gr = ctx.saved_tensors
+        L = gt.shape[0]
+        return (gt * g[:, 0].reshape(L, *([1] * (gt.dim() - 1))), gr * g[:, 1].reshape(L, *([1] * (gr.dim() - 1))),
+                None, None, None, None)
 
 
 class MSDeformAttnFn(torch.autograd.Function):
@@ -299,8 +325,7 @@ class MSDeformAttnFn(torch.autograd.Function):
         G = B.GradSink(MSDA_PARAMS, params)
         dy = dout.contiguous().view(N * Lq, d)
         rows = N * Lq
-        ops.linear_dw(dy, out_m, G("output_proj.weight"), rows=rows)
-        ops.colsum(dy, d, G("output_proj.bias"), 1, rows, d)
+        ops.linear_dw(dy, out_m, G("output_proj.weight"), rows=rows, db=G("output_proj.bias"))
         d_out_m = torch.empty_like(out_m)
         ops.linear_dx(dy, P_["output_proj.weight"], d_out_m, rows=rows)
         dV = torch.zeros(V.shape, dtype=torch.float32, device=dy.device)
@@ -310,5 +335,6 @@ class MSDeformAttnFn(torch.autograd.Function):
                      G("attention_weights.weight"), G("attention_weights.bias"), dq, False)
         dinp = torch.empty_like(in2) if ctx.need[1] else None
         B.value_proj_bwd(dV, in2, P_["value_proj.weight"], mask, N, S, M, D, G("value_proj.weight"), G("value_proj.bias"), dinp, False)
+        ops.SIDE.join()
         return (dq.view(N, Lq, d) if dq is not None else None, None, dinp.view(N, S, d) if dinp is not None else None,
                 None, None, None, None, *G.ret)

@@ -440,6 +440,7 @@ class PoET(nn.Module):
             out["aux_outputs"] = [{"pred_translation": t, "pred_rotation": r, "pred_boxes": pred_boxes,
                                    "pred_classes": pred_classes} for t, r in zip(trans[:-1], rot[:-1])]
         out["_pred_boxes_host"] = boxes_host          # lets the matcher run without a device->host sync
+        out["_stacked"] = (trans, rot)                # (L, N, Q, 3) / (L, N, Q, 3, 3): lets the criterion take all layers at once
         return out
 
     def forward(self, samples, targets=None):
