@@ -198,7 +198,7 @@ __device__ __forceinline__ float group_sum(float v, int tpg) {
 
 template <typename TV, typename TQ, int L, int P, bool FUSED>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // same L2 argument as the forward
     if (t >= p.total) return;
     const int64_t row = t / p.groups;
     const int c8 = (int)(t - row * p.groups);
@@ -316,6 +316,13 @@ struct TileP { int TX, TY, HALO; };
 constexpr int TILED_NT = 1024;
 
 __device__ __forceinline__ int cdiv_i(int a, int b) { return (a >= 0) ? (a + b - 1) / b : -((-a) / b); }
+
+// round to nearest (ties toward +inf) in ONE instruction; __float2int_rn is v_rndne + v_cvt
+__device__ __forceinline__ int cvt_rpi(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 
 // value of lane J of the caller's 16-lane DPP row, for every lane of the row (gfx90a+ row_newbcast)
 template <int J>
@@ -455,7 +462,15 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
                 // from image borders) run the branch-free body: 2 DPP moves + mul + cvt + add + ds_add per corner
                 const bool inwin = !has || (cidx[0] >= 0 && cidx[1] >= 0 && cidx[2] >= 0 && cidx[3] >= 0);
                 if (__all(inwin)) {
-                    row_points<LP>(cidx, cw, [&](int ii, float wv) { atomicAdd(&win[ii * 16 + c], __float2int_rn(wv * gs)); });
+                    // 3 VALU + 1 LDS op per corner: v_mul_f32_dpp (weight broadcast folded), v_cvt_rpi, v_add_u32_dpp (the
+                    // owner lane ships BYTE offsets, so the index broadcast folds into the address add), ds_add_u32
+                    int coff[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) coff[k] = cidx[k] * 64;
+                    const int lane_off = c * 4;
+                    row_points<LP>(coff, cw, [&](int off, float wv) {
+                        atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (off + lane_off)), cvt_rpi(wv * gs));
+                    });
                 } else {
                     row_points<LP>(cidx, cw, [&](int ii, float wv) {
                         if (ii >= 0) atomicAdd(&win[ii * 16 + c], __float2int_rn(wv * gs));

@@ -414,6 +414,7 @@ class Trainer:
         self.reducer = BucketReducer(self.arena) if distributed else None
         if self.reducer is not None and self.reducer.world > 1:
             dist.broadcast(self.arena.flat, src=0)      # DDP's initial parameter sync
+            self.arena.refresh_shadow()                 # the bf16 operand copies must follow the broadcast values
 
     def step(self, samples, targets):
         with ops.pinned_stream():
@@ -466,12 +467,12 @@ class GraphedTrainer(Trainer):
     Requirements: fixed batch size / image geometry, model in train() mode for the whole run."""
 
     def __init__(self, model, criterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=3):
-        super().__init__(model, criterion, lr=lr, weight_decay=weight_decay, max_norm=max_norm, distributed=False)
+        # the base class broadcasts the parameters and owns the bucket reducer used by the EAGER warm-up steps (without it
+        # the ranks would drift apart before the graphs are captured); the captured steps all-reduce the whole arena
+        # themselves (see _Replay.backward) and run with the reducer detached
+        super().__init__(model, criterion, lr=lr, weight_decay=weight_decay, max_norm=max_norm, distributed=None)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena.world = self.world
-        if self.world > 1:
-            dist.broadcast(self.arena.flat, src=0)
-            self.arena.refresh_shadow()
         self.warm, self.calls, self.ready = warm, 0, False
 
     def _static_inputs(self, samples, targets):
