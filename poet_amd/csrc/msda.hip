@@ -324,6 +324,18 @@ __device__ __forceinline__ int cvt_rpi(float x) {
     return r;
 }
 
+// all-reduce over the caller's 16-lane DPP row with cyclic row rotations (VALU only, no LDS traffic)
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, row_ror<1>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<4>(v)); return fmaxf(v, row_ror<8>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row_ror<1>(v); v += row_ror<2>(v); v += row_ror<4>(v); return v + row_ror<8>(v);
+}
+
 // value of lane J of the caller's 16-lane DPP row, for every lane of the row (gfx90a+ row_newbcast)
 template <int J>
 __device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false); }
@@ -419,10 +431,17 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             const float gs = n_g * scale, lg = n_lg, ox = n_ox, oy = n_oy, rx = n_rx, ry = n_ry;
             if (i + nslots < nq) fetch(i + nslots);
             // ---- lane j (< L*P) of the slot prepares sample point j ----
-            float mx = lg;
-            for (int o = 1; o < 16 && o < D; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            float e = has ? __expf(lg - mx) : 0.f, sum = e;
-            for (int o = 1; o < 16 && o < D; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            float mx = lg, e, sum;
+            if (D == 16) {                                    // a slot is one DPP row: rotations instead of ds_bpermute
+                mx = row16_max(mx);
+                e = has ? __expf(lg - mx) : 0.f;
+                sum = row16_sum(e);
+            } else {
+                for (int o = 1; o < 16 && o < D; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                e = has ? __expf(lg - mx) : 0.f;
+                sum = e;
+                for (int o = 1; o < 16 && o < D; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            }
             const float aj = e / sum;
             int cidx[4];
             float cw[4];
