@@ -189,7 +189,10 @@ bool gemm_dw_try(const GemmK& g, hipStream_t st) {
     p.rows = d.K; p.n1 = d.M; p.n2 = d.N;
     p.tiles_n2 = d.N / DW_T;
     p.ntiles = (d.M / DW_T) * p.tiles_n2;
-    static const int target = [] { const char* e = getenv("POET_DW_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    // ~2 workgroups per CU for the wide problems; the 4-tile (256x256) ones run faster with one per CU: half the row
+    // ranges means half the memory-side atomics (measured 46.9 -> 40.6 us), which outweighs the lost latency hiding
+    static const int forced = [] { const char* e = getenv("POET_DW_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const int target = forced ? forced : (p.ntiles <= 4 ? 256 : 512);
     int per = target / 8 / p.ntiles;                                   // row ranges per XCD
     if (per < 1) per = 1;
     p.splits = per * 8;
