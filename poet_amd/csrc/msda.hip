@@ -315,6 +315,15 @@ struct TileP { int TX, TY, HALO; };
 // 512 threads: twice the waves on the same LDS windows (the accumulate loop is VALU/LDS-issue bound at 2 waves/SIMD)
 constexpr int TILED_NT = 1024;
 
+// i / d for 0 <= i < 2^20, d >= 1, with inv = 1.f / d: float multiply + one correction instead of the ~30-instruction
+// integer division sequence (the quotient estimate is off by at most 1)
+__device__ __forceinline__ int idiv_small(int i, int d, float inv) {
+    int q = (int)((float)i * inv);
+    const int r = i - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
+
 __device__ __forceinline__ int cdiv_i(int a, int b) { return (a >= 0) ? (a + b - 1) / b : -((-a) / b); }
 
 // round to nearest (ties toward +inf) in ONE instruction; __float2int_rn is v_rndne + v_cvt
@@ -385,8 +394,10 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
         const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
         const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
+        const float inv_qw = 1.f / (float)max(qw, 1);
         for (int i = slot; i < nq; i += nslots) {
-            const int64_t row = (int64_t)n * p.Lq + p.start[lq] + (qy0 + i / qw) * W + qx0 + i % qw;
+            const int iy = idiv_small(i, qw, inv_qw);
+            const int64_t row = (int64_t)n * p.Lq + p.start[lq] + (qy0 + iy) * W + qx0 + (i - iy * qw);
             gm = fmaxf(gm, fabsf(io<TQ>::ld(gob + row * gstride)));
         }
     }
@@ -408,13 +419,15 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
         const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
         const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
+        const float inv_qw = 1.f / (float)max(qw, 1);
         // software prefetch: the operands of query i + nslots are in flight while query i is scattered
         const int j = c;
         const bool has = j < LP;
         const int l = has ? j / P : 0;
         float n_g = 0.f, n_lg = -3.0e38f, n_ox = 0.f, n_oy = 0.f, n_rx = 0.f, n_ry = 0.f;
         auto fetch = [&](int i) {
-            const int q = p.start[lq] + (qy0 + i / qw) * W + qx0 + i % qw;
+            const int iy = idiv_small(i, qw, inv_qw);
+            const int q = p.start[lq] + (qy0 + iy) * W + qx0 + (i - iy * qw);
             const int64_t row = (int64_t)n * p.Lq + q;
             n_g = io<TQ>::ld(gob + row * gstride);
             if (has) {
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
                 sum = e;
                 for (int o = 1; o < 16 && o < D; o <<= 1) sum += __shfl_xor(sum, o, 64);
             }
-            const float aj = e / sum;
+            const float aj = e * __builtin_amdgcn_rcpf(sum);          // 1-ulp reciprocal: the weights feed a 2^-18 fixed point
             int cidx[4];
             float cw[4];
 #pragma unroll

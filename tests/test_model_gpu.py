@@ -134,7 +134,8 @@ def test_full_size_ycbv_checksums(gpu, golden_dir, init):
             # max|dR| 0.9e-2 .. 4.6e-2 and rms 1.7e-3 .. 5.6e-3 with max|dt| <= 1.1e-3 ("bf16 parity"): the max
             # over 180 rotation entries is a heavy-tailed draw dominated by one ill-conditioned query, so at full size the
             # 1e-2 tolerance is asserted on the rms and the max is bounded at 2x; the strict max bound is asserted on
-            # translations here and on both outputs of every small config (test_forward_bf16_vs_reference_golden).
+            # translations here, on both outputs of every small config (test_forward_bf16_vs_reference_golden) and on
+            # rotations with well-conditioned heads (test_bf16_full_size_seed_sweep[conditioned]: 6e-4 .. 9e-4).
             assert rms_r < tol and er < 2 * tol, (dtype, er, rms_r)
         else:
             assert er < tol, (dtype, et, er)
@@ -276,3 +277,50 @@ def test_graphed_trainer_matches_eager(gpu):
     assert runs["graph"][0] == pytest.approx(runs["eager"][0], rel=2e-3, abs=2e-3), runs
     worst = max((runs["graph"][1][n] - runs["eager"][1][n]).abs().max().item() for n in runs["eager"][1])
     assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("input_seed,init_seed", [(1, 11), (2, 22), (5, 55)])
+@pytest.mark.parametrize("conditioned", [False, True])
+def test_bf16_full_size_seed_sweep(gpu, input_seed, init_seed, conditioned):
+    """bf16 forward at YCB-V geometry against the fp32 oracle run on this box's CPU, over different inputs and different
+    default initialisations.
+    conditioned=False: the reference's random init as is.  Translations stay within 1e-2 (measured <= 1.1e-3).  Rotations
+      are reported and only loosely bounded: at random init the 6D output has |a1| ~ 0.1 or less and the Gram-Schmidt
+      normalisation amplifies the ~1e-3 relative bf16 error of `hs` without limit (measured max 1.7e-2 .. 9e-2).
+    conditioned=True: same models, but the last Linear of every rotation head gets the bias [1,0,0, 0,1,0] per class, i.e.
+      a 6D output of unit scale as trained heads produce.  Then the strict max-norm 1e-2 holds on both outputs."""
+    import tests.oracle_runner as orr
+    from oracle import poet_ref
+    from oracle.formula import CONFIGS, make_inputs, make_samples
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg = CONFIGS["ycbv"]
+    feats, sizes, targets = make_inputs(cfg, seed=input_seed, batch=1, pad=False)
+    torch.manual_seed(init_seed)
+    omodel, _ = poet_ref.build_poet(cfg, feats)
+    real_seed = torch.manual_seed
+    torch.manual_seed = lambda s: real_seed(init_seed)          # build_product seeds the default init with a fixed value
+    try:
+        r = gpu("ycbv", 1, False, torch.bfloat16, seed=input_seed, default_init=True)
+    finally:
+        torch.manual_seed = real_seed
+    if conditioned:
+        with torch.no_grad():
+            for model in (omodel, r["model"]):
+                for head in model.rotation_head:
+                    b = head.layers[-1].bias
+                    b.copy_(torch.tensor([1.0, 0, 0, 0, 1, 0], device=b.device).repeat(b.numel() // 6))
+    for (n, p), (_, po) in zip(r["model"].named_parameters(), omodel.named_parameters()):
+        assert torch.equal(p.detach().cpu(), po.detach()), n          # same weights in both models
+    omodel.eval(); r["model"].eval()
+    with torch.no_grad():
+        oout, _ = omodel(poet_ref.nested_from_list(make_samples(cfg, sizes)), targets)
+        out, _ = r["model"](r["samples"], r["targets"])
+    dt = (out["pred_translation"].cpu() - oout["pred_translation"]).abs().max().item()
+    dR = out["pred_rotation"].cpu() - oout["pred_rotation"]
+    rms, mx = dR.pow(2).mean().sqrt().item(), dR.abs().max().item()
+    print(f"bf16 ycbv seeds ({input_seed},{init_seed}) conditioned={conditioned}: max|dt| {dt:.2e} rms dR {rms:.2e} max|dR| {mx:.2e}")
+    assert dt < TOL_BF16, dt
+    if conditioned:
+        assert mx < TOL_BF16, (rms, mx)
+    else:
+        assert rms < 5e-2 and mx < 0.5, (rms, mx)
