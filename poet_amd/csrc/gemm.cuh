@@ -16,5 +16,7 @@ struct GemmK {
 bool gemm_ws_try(const GemmK& p, hipStream_t st);
 // same contract for the weight-gradient kernel (gemm_dw.hip)
 bool gemm_dw_try(const GemmK& p, hipStream_t st);
+// latency-oriented fp32 kernel for the <= 1024-row decoder / head Linears (gemm_small.hip)
+bool gemm_small_try(const GemmK& p, hipStream_t st);
 
 }  // namespace poet

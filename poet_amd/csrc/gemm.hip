@@ -418,8 +418,8 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-    if (gemm_dw_try(p, st)) {              // weight gradients of tall activations (gemm_dw.hip), bias gradient fused
-        POET_LAUNCH_CHECK();
+    if (gemm_dw_try(p, st) || gemm_small_try(p, st)) {     // streaming dW (gemm_dw.hip) / latency-oriented 320-row kernels
+        POET_LAUNCH_CHECK();                                // (gemm_small.hip); both fuse the bias gradient of the dW form
         return POET_OK;
     }
     if (ysum) {                            // generic path: the column sums are a separate launch
@@ -427,7 +427,7 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         if (rc) return rc;
         d.bias = nullptr;
     }
-    if (gemm_ws_try(p, st)) {              // tall activations x small stationary weight: streaming kernel (gemm_ws.hip)
+    if (gemm_ws_try(p, st)) {
         POET_LAUNCH_CHECK();
         return POET_OK;
     }

@@ -1,0 +1,182 @@
+// Latency-oriented fp32 GEMM for the 320-row decoder / pose-head Linears (reference: nn.MultiheadAttention in/out
+// projections, decoder FFN and MSDeformAttn query-side projections, models/deformable_transformer.py:253-292; MLP heads,
+// models/pose_estimation_transformer.py:106-122,684-688).  At M = N_img * Q = 320 rows these are ~40 MFLOP each: nothing
+// is bandwidth- or MFMA-bound, the cost is the dependent chain launch -> load -> LDS -> barrier -> MFMA -> LDS -> store of
+// the tiled kernel.  Here one wave owns one 16x16 output tile and loads BOTH operands straight from global memory in
+// MFMA operand layout -- no LDS, no barrier, one memory round trip:
+//   v_mfma_f32_16x16x4_f32 takes A[i = lane&15][k = lane>>4]; the contraction is invariant under a permutation of k that
+//   is applied to both operands, so lane group g = lane>>4 is given the CONTIGUOUS k range [g*K/4, (g+1)*K/4) and MFMA
+//   number t consumes element t of that range: every lane reads K/4 consecutive floats of one row with 16-byte loads.
+// Four accumulators (element x/y/z/w of each float4) break the 64-deep dependent MFMA chain.
+#include "gemm.cuh"
+
+namespace poet {
+
+namespace {
+
+__device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// fold the 4 waves' partial 16x16 tiles (lane layout preserved) through LDS; afterwards wave 0 holds the sum
+__device__ __forceinline__ f32x4_t fold_waves(f32x4_t v, float* red, int lane, int wid) {
+    if (wid) *reinterpret_cast<f32x4_t*>(red + ((wid - 1) * 64 + lane) * 4) = v;
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4_t*>(red + (w * 64 + lane) * 4);
+    }
+    return v;
+}
+
+// ---- C[m][n] = epi(sum_k A[m][k] * W[n][k])   (forward; W rows K-contiguous) ----
+// ---- C[m][n] = epi(sum_k A[m][k] * W[k][n])   (input gradient; BKM: W stored [K][N]) ----
+// SPLIT = false: one wave per tile, 4 tiles per workgroup, whole K per wave (K <= 256: a single memory round trip).
+// SPLIT = true : one tile per workgroup, wave w reduces K range [w K/4, (w+1) K/4), partial tiles folded through LDS.
+template <bool BKM, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmK p) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
+    const PoetGemmDesc& d = p.d;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tn = (d.N + 15) >> 4, tile = SPLIT ? blockIdx.x : blockIdx.x * 4 + wid;
+    const int m0 = (tile / tn) << 4, n0 = (tile % tn) << 4;
+    if (m0 >= d.M) return;                                              // SPLIT: workgroup-uniform
+    const int r = lane & 15, g = lane >> 4;
+    const int kw = SPLIT ? d.K >> 2 : d.K, kbase = SPLIT ? wid * kw : 0; // this wave's K range
+    const int kq = kw >> 2;                                             // floats per lane group, multiple of 4
+    const int ncol = min(n0 + r, d.N - 1);                              // ragged N: clamp the operand, mask the store
+    const float* ap = reinterpret_cast<const float*>(d.A) + (int64_t)min(m0 + r, d.M - 1) * d.lda + kbase + g * kq;
+    const float* wp = BKM ? reinterpret_cast<const float*>(d.B) + (int64_t)(kbase + g * kq) * d.ldb + ncol
+                          : reinterpret_cast<const float*>(d.B) + (int64_t)ncol * d.ldb + kbase + g * kq;
+    f32x4_t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int k0 = 0; k0 < kq; k0 += 64) {                               // 64 floats per operand per trip
+        float4 a[16], w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = k0 + i * 4 < kq;
+            a[i] = ok ? *reinterpret_cast<const float4*>(ap + k0 + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (!BKM) {
+                w[i] = ok ? *reinterpret_cast<const float4*>(wp + k0 + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float* q = wp + (int64_t)(k0 + i * 4) * d.ldb;
+                w[i] = ok ? make_float4(q[0], q[d.ldb], q[2 * d.ldb], q[3 * d.ldb]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[0] = mfma4(a[i].x, w[i].x, acc[0]);
+            acc[1] = mfma4(a[i].y, w[i].y, acc[1]);
+            acc[2] = mfma4(a[i].z, w[i].z, acc[2]);
+            acc[3] = mfma4(a[i].w, w[i].w, acc[3]);
+        }
+    }
+    f32x4_t c4 = acc[0] + acc[1] + acc[2] + acc[3];
+    if constexpr (SPLIT) {
+        c4 = fold_waves(c4, red, lane, wid);
+        if (wid) return;
+    }
+    // lane holds C[m0 + 4g + t][n0 + r], t = 0..3: 16 lanes of a row are 64 contiguous bytes
+    const int col = n0 + r;
+    if (col >= d.N) return;
+    const float b = d.bias ? d.bias[col] : 0.f;
+    const uint32_t sd = d.seed ^ (d.seed_dev ? *d.seed_dev * 0x9E3779B1u : 0u);
+    const float* addp = reinterpret_cast<const float*>(d.add_src);
+    const float* gate = reinterpret_cast<const float*>(d.gate_ref);
+    float* C = reinterpret_cast<float*>(d.C);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = m0 + g * 4 + t;
+        if (row >= d.M) continue;
+        float v = c4[t] * d.alpha + b;
+        if (d.act == 1) v = fmaxf(v, 0.f);
+        if (gate) v = gate[(int64_t)row * d.ldc + col] > 0.f ? v * d.gate_scale : 0.f;
+        if (p.drop_thresh) v = drop_keep(sd, (uint32_t)row * (uint32_t)d.N + (uint32_t)col, p.drop_thresh) ? v * p.drop_scale : 0.f;
+        if (addp) v += addp[(int64_t)row * d.ld_add + col];
+        C[(int64_t)row * d.ldc + col] = v;
+    }
+}
+
+// ---- dW[n1][n2] += sum_r Y[r][n1] * X[r][n2];  db[n1] += sum_r Y[r][n1]  (rows r = the reduction, both operands [rows][.]) ----
+// One 16x16 tile per workgroup; wave w reduces rows [w K/4, (w+1) K/4), lane group g a quarter of those: at 320 rows a lane
+// issues 2 x 20 independent 4-byte loads (one memory round trip), 20 MFMAs, and the partial tiles are folded through
+// LDS.  The tile has one owner, so the accumulation onto the existing gradient is a plain read-modify-write.
+__global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
+    __shared__ float reds[4][16];
+    const PoetGemmDesc& d = p.d;                                        // M = n1, N = n2, K = rows
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tn = (d.N + 15) >> 4, tile = blockIdx.x;
+    const int m0 = (tile / tn) << 4, n0 = (tile % tn) << 4;
+    const int r = lane & 15, g = lane >> 4;
+    const int kq = (d.K + 15) >> 4;                                     // rows per (wave, lane group)
+    const int rbase = (wid * 4 + g) * kq;
+    const int ycol = min(m0 + r, d.M - 1), xcol = min(n0 + r, d.N - 1);
+    const float* yp = reinterpret_cast<const float*>(d.A) + ycol;
+    const float* xp = reinterpret_cast<const float*>(d.B) + xcol;
+    f32x4_t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float ysum = 0.f;
+    for (int k0 = 0; k0 < kq; k0 += 32) {
+        float y[32], x[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int row = rbase + k0 + i;
+            const bool ok = k0 + i < kq && row < d.K;
+            y[i] = ok ? yp[(int64_t)row * d.lda] : 0.f;
+            x[i] = ok ? xp[(int64_t)row * d.ldb] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            acc[i & 3] = mfma4(y[i], x[i], acc[i & 3]);
+            ysum += y[i];
+        }
+    }
+    const bool do_sum = d.bias && n0 == 0;                              // workgroup-uniform
+    if (do_sum) {
+        ysum += __shfl_xor(ysum, 16, 64);
+        ysum += __shfl_xor(ysum, 32, 64);
+        if (g == 0) reds[wid][r] = ysum;
+    }
+    f32x4_t c4 = fold_waves(acc[0] + acc[1] + acc[2] + acc[3], red, lane, wid);     // (barrier inside)
+    if (wid) return;
+    float* C = reinterpret_cast<float*>(d.C);
+    const int col = n0 + r;
+    if (col < d.N) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = m0 + g * 4 + t;
+            if (row < d.M) C[(int64_t)row * d.ldc + col] += c4[t];
+        }
+    }
+    if (do_sum && g == 0 && m0 + r < d.M) const_cast<float*>(d.bias)[m0 + r] += reds[0][r] + reds[1][r] + reds[2][r] + reds[3][r];
+}
+
+}  // namespace
+
+bool gemm_small_try(const GemmK& p, hipStream_t st) {
+    const PoetGemmDesc& d = p.d;
+    static const int disabled = [] { const char* e = getenv("POET_GEMM_NO_SMALL"); return e && atoi(e) ? 1 : 0; }();
+    if (disabled) return false;
+    if (d.compute != POET_F32 || d.a_dtype != POET_F32 || d.b_dtype != POET_F32 || d.c_dtype != POET_F32) return false;
+    if (d.batch != 1 || d.A2 || d.row_mask || d.out_mode) return false;
+    const bool dw_form = d.a_kmajor && d.b_kmajor && (d.atomic || d.splitk > 1);
+    if (dw_form) {                                                      // M = n_out, N = k_in, K = rows
+        if (d.K > 1024 || d.alpha != 1.f) return false;
+        const int tiles = ((d.M + 15) >> 4) * ((d.N + 15) >> 4);
+        hipLaunchKernelGGL(gemm_small_dw_kernel, dim3(tiles), dim3(256), 0, st, p);
+        return true;
+    }
+    if (d.a_kmajor || d.splitk != 1 || d.atomic) return false;
+    if (d.M > 1024 || d.K % 16 != 0 || d.K > 4096 || !p.a_vec) return false;   // A rows: 16-byte loads
+    if (!d.b_kmajor && !p.b_vec) return false;
+    const int tiles = ((d.M + 15) >> 4) * ((d.N + 15) >> 4);
+    const bool split = d.K >= 512 && d.K % 64 == 0;                      // long reductions: 4 waves share one tile
+    const dim3 grid(split ? tiles : (tiles + 3) / 4);
+    if (d.b_kmajor) {
+        if (split) hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (split) hipLaunchKernelGGL((gemm_small_kernel<false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, dim3(256), 0, st, p);
+    }
+    return true;
+}
+
+}  // namespace poet
