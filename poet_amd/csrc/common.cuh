@@ -109,16 +109,24 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
 }
 __host__ __device__ __forceinline__ uint32_t drop_thresh(float p) { return (uint32_t)(p * 65536.0f); }
 
-// ---- wave-level reductions (64 lanes) ----------------------------------------------------------
+// ---- wave-level all-reduce (64 lanes) without LDS traffic ---------------------------------------
+// 4 cyclic DPP row rotations reduce inside each 16-lane row, then the four row totals are read with v_readlane and
+// combined: ~12 VALU ops and no ds_bpermute (6 dependent LDS round trips per reduction with __shfl_xor).
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_row_ror<1>(v); v += dpp_row_ror<2>(v); v += dpp_row_ror<4>(v); v += dpp_row_ror<8>(v);
+    const int i = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_row_ror<1>(v)); v = fmaxf(v, dpp_row_ror<2>(v)); v = fmaxf(v, dpp_row_ror<4>(v)); v = fmaxf(v, dpp_row_ror<8>(v));
+    const int i = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -289,7 +289,7 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     int nb = cdiv(rows, 4);
-    if (nb > 512) nb = 512;
+    if (nb > 512) nb = 512;          // one row per wave iteration, no prefetch: occupancy is what hides the load latency
     dim3 grid(nb), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev)
