@@ -279,6 +279,9 @@ def main():
         if prof is not None:
             out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)
             out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"])
+            if out["roofline"]["kernel"].startswith("msda_bwd_dvalue_scatter"):
+                # the contract's two bounds do not name this kernel's real limiter; say so next to the HBM fraction
+                out["roofline"]["limiter"] = "LDS integer atomics (ds_add_u32) + per-query setup, not HBM: DESIGN.md section 5/9"
             out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
                                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         if world == 1 and not args.no_cpu_baseline:

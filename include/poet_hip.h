@@ -77,7 +77,10 @@ const char* poet_hip_last_error(void);
  *   exception, the WEIGHT-GRADIENT FORM (a_kmajor && b_kmajor && atomic: A = dY stored [rows][M],
  *   B = X stored [rows][N], C = dW): there `bias` is an optional fp32 OUTPUT [M] that receives
  *   += the column sums of A, i.e. the bias gradient of the same nn.Linear, produced in the same
- *   pass over dY whenever the streaming kernel handles the shape (batch must be 1).
+ *   pass over dY whenever the streaming kernel handles the shape (batch must be 1).  In this form C
+ *   is ACCUMULATED (fp32 atomicAdd, or a single-owner read-modify-write in the small-row kernel): the
+ *   caller zero-fills it once per optimisation step and must not touch it concurrently on another
+ *   stream.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct PoetGemmDesc {
     const void* A;

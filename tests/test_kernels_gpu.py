@@ -607,3 +607,43 @@ def test_pose_loss_fused_matches_torch(ops):
     assert torch.allclose(t1.grad.cpu(), t0.grad, atol=1e-6, rtol=1e-4)
     # the layer-2 pair with an identical target sits exactly on the clamp: torch passes no gradient there either
     assert torch.allclose(r1.grad.cpu(), r0.grad, atol=2e-5, rtol=2e-3), (r1.grad.cpu() - r0.grad).abs().max()
+
+
+# ------------------------------------------------------------------ latency-oriented fp32 kernels (gemm_small.hip)
+@pytest.mark.parametrize("M,N,K", [(320, 256, 256), (320, 132, 256), (320, 1024, 256), (320, 256, 1024), (37, 48, 512), (1000, 256, 768)])
+def test_gemm_small_fwd_dx(ops, M, N, K):
+    """fp32, <= 1024 rows: poet_gemm routes forward and input-gradient products to gemm_small.hip (K >= 512 and a multiple
+    of 64: reduction split over the 4 waves).  Dropout pattern against the tiled kernel (disabled by a K that is not a
+    multiple of 16) is index-based, so only its rate is checked here."""
+    x = _rand(M, K, seed=130)
+    w = _rand(N, K, seed=131, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=132)
+    add = _rand(M, N, seed=133)
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), out, act=1, add_src=dev(add))
+    _close(out, torch.relu(x @ w.t() + b) + add, torch.float32, msg="small fwd")
+    o2 = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), o2, drop_p=0.3, seed=5)
+    ref = x @ w.t() + b
+    keep = o2.cpu() != 0
+    assert abs(keep.float().mean().item() - 0.7) < 0.03
+    assert torch.allclose(o2.cpu()[keep], (ref / 0.7)[keep], atol=2e-4, rtol=2e-4)
+    # input gradient: dy (M, N_out = N) @ W (N, K) with ReLU gate and in-place accumulate
+    dy = _rand(M, N, seed=134)
+    gate = _rand(M, K, seed=135)
+    acc0 = _rand(M, K, seed=136)
+    dx = dev(acc0.clone())
+    ops.linear_dx(dev(dy), dev(w), dx, rows=M, add_src=dx, gate_ref=dev(gate), gate_scale=1.5)
+    _close(dx, (dy @ w) * 1.5 * (gate > 0) + acc0, torch.float32, msg="small dX")
+
+
+@pytest.mark.parametrize("rows,n_out,k_in", [(320, 256, 256), (320, 132, 256), (320, 1024, 256), (333, 256, 1024), (1024, 48, 40)])
+def test_gemm_small_dw_db(ops, rows, n_out, k_in):
+    dy = _rand(rows, n_out, seed=140)
+    x = _rand(rows, k_in, seed=141)
+    w0, b0 = _rand(n_out, k_in, seed=142), _rand(n_out, seed=143)
+    dw, db = dev(w0.clone()), dev(b0.clone())
+    ops.linear_dw(dev(dy), dev(x), dw, rows=rows, db=db)
+    ops.linear_dw(dev(dy), dev(x), dw, rows=rows, db=db)          # accumulates onto what is there
+    _close(dw, 2 * (dy.t() @ x) + w0, torch.float32, scale=math.sqrt(rows), msg="small dW")
+    _close(db, 2 * dy.sum(0) + b0, torch.float32, scale=math.sqrt(rows), msg="small db")
