@@ -39,6 +39,7 @@ __device__ __forceinline__ int ws_inv_perm(int n) {
 
 enum : int { WS_GATE = 1, WS_ADD = 2, WS_MASK = 4 };
 
+
 template <typename TC> struct run8;                        // 8 consecutive C-typed values <-> raw 16-byte registers
 template <> struct run8<bf16_t> {
     static constexpr int NV = 1;
@@ -62,9 +63,9 @@ template <> struct run8<float> {
     }
 };
 
-template <typename TC, int KIND, bool WKM>
-__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmK p) {
-    constexpr int BN = 128, KS = 8;
+template <typename TC, int KIND, bool WKM, int FM, int NTH>
+__global__ __launch_bounds__(NTH, 2) void gemm_ws_kernel(const GemmK p) {
+    constexpr int BN = 128, KS = 8, NWV = NTH / 64;
     constexpr int K = KS * 32, PITCH = K * 2 + 16, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
     constexpr bool GATE = KIND & WS_GATE, ADD = KIND & WS_ADD, MASK = KIND & WS_MASK;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [BN][PITCH] bf16 rows of W (permuted) | bias[BN] f32
@@ -77,24 +78,23 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmK p) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
     const int NT = d.N / BN, groups = per / NT;
     if (j >= groups * NT) return;
-    const int nt = j % NT, G = (j / NT) * 8 + xcd, NW = groups * 8 * 4;
+    const int nt = j % NT, G = (j / NT) * 8 + xcd, NW = groups * 8 * NWV;
     const int n0 = nt * BN;
-    const int U = (d.M + 15) >> 4, wv = G * 4 + wid;
+    const int U = (d.M + 15) >> 4, wv = G * NWV + wid;
     const int u_lo = (int)((int64_t)wv * U / NW), u_hi = (int)((int64_t)(wv + 1) * U / NW);
 
     // ---- A prefetch for the first 32 rows goes out before W is touched ----
     const bf16_t* A = reinterpret_cast<const bf16_t*>(d.A);
-    uint4 a[2][KS];
+    uint4 a[FM][KS];
     auto arow = [&](int u, int fm) {                                   // row of fragment fm of the unit pair starting at u, clamped
         return max(min(min(u + fm, u_hi - 1) * 16 + frow, d.M - 1), 0);
     };
     if (u_lo < u_hi) {
-        const bf16_t* p0 = A + (int64_t)arow(u_lo, 0) * d.lda + g * 8;
-        const bf16_t* p1 = A + (int64_t)arow(u_lo, 1) * d.lda + g * 8;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            a[0][kk] = *reinterpret_cast<const uint4*>(p0 + kk * 32);
-            a[1][kk] = *reinterpret_cast<const uint4*>(p1 + kk * 32);
+        for (int fm = 0; fm < FM; ++fm) {
+            const bf16_t* p0 = A + (int64_t)arow(u_lo, fm) * d.lda + g * 8;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a[fm][kk] = *reinterpret_cast<const uint4*>(p0 + kk * 32);
         }
     }
 
@@ -102,30 +102,30 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmK p) {
     const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B);
     // (all of a thread's requests are in flight before its first LDS store: one exposed latency, not one per chunk)
     if constexpr (!WKM) {                                               // W[n][k], k contiguous
-        constexpr int CPR = K / 8, NIT = BN * CPR / 256;
+        constexpr int CPR = K / 8, NIT = BN * CPR / NTH;
         uint4 wv[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + i * 256, rho = idx / CPR, kc = idx - rho * CPR;
+            const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
             wv[i] = *reinterpret_cast<const uint4*>(B + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 8);
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + i * 256, rho = idx / CPR, kc = idx - rho * CPR;
+            const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
             *reinterpret_cast<uint4*>(smem + rho * PITCH + kc * 16) = wv[i];
         }
     } else {                                                            // W[k][n] (input-gradient GEMMs): transpose on the way in
-        constexpr int NG = BN / 8, NIT = (K / 4) * NG / 256;            // item: 4 consecutive k x 8 consecutive n
+        constexpr int NG = BN / 8, NIT = (K / 4) * NG / NTH;            // item: 4 consecutive k x 8 consecutive n
         uint4 wv[NIT][4];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + i * 256, kq = idx / NG, nl = (idx - kq * NG) * 8;
+            const int idx = tid + i * NTH, kq = idx / NG, nl = (idx - kq * NG) * 8;
 #pragma unroll
             for (int r = 0; r < 4; ++r) wv[i][r] = *reinterpret_cast<const uint4*>(B + (int64_t)(kq * 4 + r) * d.ldb + n0 + nl);
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + i * 256, kq = idx / NG, nl = (idx - kq * NG) * 8;
+            const int idx = tid + i * NTH, kq = idx / NG, nl = (idx - kq * NG) * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 uint32_t h[4];
@@ -154,13 +154,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmK p) {
     // wave's range are clamped on load and skipped on store.
     auto iteration = [&](int u, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        int grow[2];
-        grow[0] = TAIL ? arow(u, 0) : u * 16 + frow;
-        grow[1] = TAIL ? arow(u, 1) : u * 16 + 16 + frow;
-        uint4 gq[GATE ? 2 : 1][NQ][2][NV], rq[ADD ? 2 : 1][NQ][2][NV];
-        uint32_t mk[2] = {0u, 0u};
+        int grow[FM];
 #pragma unroll
-        for (int fm = 0; fm < 2; ++fm) {
+        for (int fm = 0; fm < FM; ++fm) grow[fm] = TAIL ? arow(u, fm) : (u + fm) * 16 + frow;
+        uint4 gq[GATE ? FM : 1][NQ][2][NV], rq[ADD ? FM : 1][NQ][2][NV];
+        uint32_t mk[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            mk[fm] = 0u;
             if constexpr (MASK) mk[fm] = d.row_mask[grow[fm]];
 #pragma unroll
             for (int jq = 0; jq < NQ; ++jq)
@@ -171,33 +172,34 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmK p) {
                     if constexpr (ADD) run8<TC>::ld(addp + (int64_t)grow[fm] * d.ld_add + gcol, rq[fm][jq][h]);
                 }
         }
-        f32x4_t acc[2][FNT];
+        f32x4_t acc[FM][FNT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int jn = 0; jn < FNT; ++jn) acc[i][jn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         asm volatile("" : "+v"(woff));          // W fragments are loop-invariant: keep them in LDS, not hoisted into 256 VGPRs
         const char* wl = smem + woff;
-        const int un = TAIL ? u : u + 2;        // the refill of the last iteration re-reads its own rows (cache hit, never used)
-        const bf16_t* q0 = A + (int64_t)arow(un, 0) * d.lda + g * 8;
-        const bf16_t* q1 = A + (int64_t)arow(un, 1) * d.lda + g * 8;
+        const int un = TAIL ? u : u + FM;       // the refill of the last iteration re-reads its own rows (cache hit, never used)
+        const bf16_t* qn[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) qn[fm] = A + (int64_t)arow(un, fm) * d.lda + g * 8;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, a[0][kk]), a1 = __builtin_bit_cast(bf16x8_t, a[1][kk]);
 #pragma unroll
             for (int jn = 0; jn < FNT; ++jn) {
                 const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl + jn * 16 * PITCH + kk * 64));
-                acc[0][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[0][jn], 0, 0, 0);
-                acc[1][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[1][jn], 0, 0, 0);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acc[fm][jn], 0, 0, 0);
             }
-            a[0][kk] = *reinterpret_cast<const uint4*>(q0 + kk * 32);
-            a[1][kk] = *reinterpret_cast<const uint4*>(q1 + kk * 32);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) a[fm][kk] = *reinterpret_cast<const uint4*>(qn[fm] + kk * 32);
             __builtin_amdgcn_sched_barrier(0);                          // keep the refill HERE (the scheduler sinks it otherwise)
         }
 
         // ---- epilogue on registers: lane = row frow of fragment fm, columns [8g, 8g+8) and [32+8g, 32+8g+8) of each 64 ----
 #pragma unroll
-        for (int fm = 0; fm < 2; ++fm) {
+        for (int fm = 0; fm < FM; ++fm) {
             const bool live = !TAIL || ((u + fm) < u_hi && (u + fm) * 16 + frow < d.M);
 #pragma unroll
             for (int jq = 0; jq < NQ; ++jq)
@@ -261,20 +263,31 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const GemmK p) {
 
     int u = u_lo;
     const int u_full = min(u_hi, d.M >> 4);                             // units below u_full are wholly inside [0, M)
-    for (; u + 2 <= u_full; u += 2) iteration(u, std::false_type{});
+    for (; u + FM <= u_full; u += FM) iteration(u, std::false_type{});
     if (u < u_hi) iteration(u, std::true_type{});
 }
 
-template <typename TC, int KIND, bool WKM>
-void ws_launch(const GemmK& p, int nblocks, hipStream_t st) {
+template <typename TC, int KIND, bool WKM, int FM, int NTH>
+void ws_launch_cfg(const GemmK& p, int nblocks, hipStream_t st) {
     constexpr int LDS = 128 * (8 * 64 + 16) + 128 * 4;
-    auto kern = gemm_ws_kernel<TC, KIND, WKM>;
+    auto kern = gemm_ws_kernel<TC, KIND, WKM, FM, NTH>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTH), LDS, st, p);
+}
+
+// Two shapes of the same kernel.  Narrow outputs (N <= 256: 1-2 column slices) are latency-bound: 16 rows per wave need
+// ~120-150 VGPRs, so eight waves share one weight slice and 3-4 waves per SIMD hide the latency (and the f32-residual
+// variants stop spilling).  Wide outputs (N >= 512) re-use every weight fragment for two row fragments instead, which
+// halves the LDS traffic that would otherwise bound them (measured at M = 102080: N = 256 31.3 -> 29.3 us with 16 rows,
+// N = 1024 90 -> 105 us).
+template <typename TC, int KIND, bool WKM>
+void ws_launch(const GemmK& p, int nblocks, hipStream_t st) {
+    if (p.d.N <= 256) ws_launch_cfg<TC, KIND, WKM, 1, 512>(p, nblocks, st);
+    else ws_launch_cfg<TC, KIND, WKM, 2, 256>(p, nblocks, st);
 }
 
 // the epilogue kinds that occur on the path: forward {plain, +residual, +row mask}, input gradient {plain, ReLU gate,
