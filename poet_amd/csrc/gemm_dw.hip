@@ -60,34 +60,50 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
     // One stage lives in registers on top of the two in LDS (a second register stage measured no faster: with two
     // workgroups per CU ~64 KB are in flight per CU, above the ~47 KB Little's law asks for at full HBM rate).
     uint4 ry[1][4], rx[1][4];
+    // Per-thread constants hoisted out of the stage loop (the staging code used to cost more issue slots than the MFMAs):
+    // chunk c = tid & 15 of row (tid >> 4) + 16 i; 32-bit element offsets (rows * ld < 2^31 is checked on the host).
+    const int c16 = tid & 15, rt = tid >> 4;
+    int yo[4], xo[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rt + 16 * i;
+        yo[i] = row * (int)p.ldy + c16 * 8;
+        xo[i] = row * (int)p.ldx + c16 * 8;
+        lo[i] = row * DW_ROWB + ((((c16 >> 1) ^ dw_swz(row)) << 5) | ((c16 & 1) << 4));
+    }
+    const int ystep = DW_RS * (int)p.ldy, xstep = DW_RS * (int)p.ldx;
+    const int ytail = (p.rows - 1) * (int)p.ldy + c16 * 8, xtail = (p.rows - 1) * (int)p.ldx + c16 * 8;
     // loads are UNCONDITIONAL (row clamped, zero selected at the LDS store): with a branch around them the compiler cannot
     // count outstanding loads and every LDS store would drain the queue, collapsing the prefetch depth
     auto load = [&](int s, uint4 (&y)[4], uint4 (&x)[4]) {
+        const int r0 = s * DW_RS + rt;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * 256, row = id >> 4, c = id & 15;
-            const int gr = min(s * DW_RS + row, p.rows - 1);
-            y[i] = *reinterpret_cast<const uint4*>(Yp + (int64_t)gr * p.ldy + c * 8);
-            x[i] = *reinterpret_cast<const uint4*>(Xp + (int64_t)gr * p.ldx + c * 8);
+            const bool in = r0 + 16 * i < p.rows;
+            y[i] = *reinterpret_cast<const uint4*>(Yp + (in ? s * ystep + yo[i] : ytail));
+            x[i] = *reinterpret_cast<const uint4*>(Xp + (in ? s * xstep + xo[i] : xtail));
         }
     };
     const bool do_sum = p.ysum != nullptr && n2_0 == 0;                 // workgroup-uniform
     float ys[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};            // this thread's 8 columns (chunk tid & 15) of Y
     auto store = [&](char* buf, int s, const uint4 (&y)[4], const uint4 (&x)[4]) {
+        const bool whole = s < s_hi && (s + 1) * DW_RS <= p.rows;       // workgroup-uniform: no masking on interior stages
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * 256, row = id >> 4, c = id & 15;
-            const uint32_t m = (s < s_hi && s * DW_RS + row < p.rows) ? 0xffffffffu : 0u;   // value select, never a pointer select
-            const int off = row * DW_ROWB + ((((c >> 1) ^ dw_swz(row)) << 5) | ((c & 1) << 4));
-            const uint4 ym = make_uint4(y[i].x & m, y[i].y & m, y[i].z & m, y[i].w & m);
+            uint4 ym = y[i], xm = x[i];
+            if (!whole) {                                               // value selects, never pointer selects
+                const uint32_t m = (s < s_hi && s * DW_RS + rt + 16 * i < p.rows) ? 0xffffffffu : 0u;
+                ym = make_uint4(ym.x & m, ym.y & m, ym.z & m, ym.w & m);
+                xm = make_uint4(xm.x & m, xm.y & m, xm.z & m, xm.w & m);
+            }
             if (do_sum) {
                 ys[0] += __uint_as_float(ym.x << 16); ys[1] += __uint_as_float(ym.x & 0xffff0000u);
                 ys[2] += __uint_as_float(ym.y << 16); ys[3] += __uint_as_float(ym.y & 0xffff0000u);
                 ys[4] += __uint_as_float(ym.z << 16); ys[5] += __uint_as_float(ym.z & 0xffff0000u);
                 ys[6] += __uint_as_float(ym.w << 16); ys[7] += __uint_as_float(ym.w & 0xffff0000u);
             }
-            *reinterpret_cast<uint4*>(buf + off) = ym;
-            *reinterpret_cast<uint4*>(buf + DW_PANEL + off) = make_uint4(x[i].x & m, x[i].y & m, x[i].z & m, x[i].w & m);
+            *reinterpret_cast<uint4*>(buf + lo[i]) = ym;
+            *reinterpret_cast<uint4*>(buf + DW_PANEL + lo[i]) = xm;
         }
     };
 
@@ -180,6 +196,7 @@ bool gemm_dw_try(const GemmK& g, hipStream_t st) {
     if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || d.c_dtype != POET_F32 || d.compute != POET_BF16) return false;
     if (d.M % DW_T != 0 || d.N % DW_T != 0 || d.K < 4096 || d.alpha != 1.f) return false;
     if (!g.a_vec || !g.b_vec) return false;
+    if ((int64_t)d.K * d.lda >= (1LL << 31) || (int64_t)d.K * d.ldb >= (1LL << 31)) return false;   // 32-bit element offsets in the kernel
     DwP p;
     p.Y = reinterpret_cast<const bf16_t*>(d.A);
     p.X = reinterpret_cast<const bf16_t*>(d.B);
