@@ -5,6 +5,7 @@ and an op-for-op PyTorch counterpart of the reference's matcher/loss (kept uncha
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -435,6 +436,9 @@ class Trainer:
         return total.detach(), loss_dict
 
 
+SEGMENT_TAGS = ("0_heads", "1_decoder", "2_encoder", "3_input_proj")      # bucket names of ParamArena, backward order
+
+
 class _Replay(torch.autograd.Function):
     """Autograd shim around the two captured graphs: forward replays the model-forward graph and hands out its static
     outputs; backward copies the loss gradients into the static grad buffers and replays backward (+ optimiser)."""
@@ -450,10 +454,17 @@ class _Replay(torch.autograd.Function):
         t = ctx.trainer
         t.s_drot.copy_(drot)
         t.s_dtrans.copy_(dtrans)
-        t.g_bwd.replay()
-        if t.world > 1:                      # one large collective on the whole flat gradient arena, then the optimiser graph
-            dist.all_reduce(t.arena.grad, op=dist.ReduceOp.SUM)
-            t.g_opt.replay()
+        if t.segs is None:
+            t.g_bwd.replay()                 # backward + clip + AdamW in one graph (single GPU)
+            return None, None
+        reduce = t.reducer is not None and t.world > 1
+        for g, tag in zip(t.segs, SEGMENT_TAGS):
+            g.replay()
+            if reduce:
+                t.reducer.bucket_done(tag)   # event on this stream -> all-reduce of the bucket on the comm stream
+        if reduce:
+            t.reducer.finish()               # remaining ranges (0.1x-LR tail), then this stream waits for the comm stream
+        t.g_opt.replay()
         return None, None
 
 
@@ -461,12 +472,14 @@ class GraphedTrainer(Trainer):
     """Trainer whose device work is replayed from HIP graphs (the step has ~700 kernel launches; enqueuing them from
     Python costs about as much as executing them).  Three graphs, captured after `warm` eager steps:
         g_fwd : bump the device-side dropout word; PoET.forward_core (input_proj .. heads)
-        g_bwd : zero the gradient arena; the four backward programs (+ clip + AdamW when world == 1)
-        g_opt : clip + AdamW (world > 1 only; the RCCL all-reduce of the whole arena runs eagerly between g_bwd and g_opt)
+        g_bwd : zero the gradient arena; the four backward programs + clip + AdamW (world == 1)
+        world > 1: backward is FOUR graphs (heads, decoder, encoder, input_proj = the gradient buckets); each bucket's RCCL
+                all-reduce is enqueued on the comm stream right after its segment and overlaps the later segments; then
+        g_opt : clip + AdamW
     Host work per step: pad/pack the boxes, three small H2D copies, the matcher, the loss and its backward (eager).
     Requirements: fixed batch size / image geometry, model in train() mode for the whole run."""
 
-    def __init__(self, model, criterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=3):
+    def __init__(self, model, criterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=3, segment_backward=None):
         # the base class broadcasts the parameters and owns the bucket reducer used by the EAGER warm-up steps (without it
         # the ranks would drift apart before the graphs are captured); the captured steps all-reduce the whole arena
         # themselves (see _Replay.backward) and run with the reducer detached
@@ -474,6 +487,9 @@ class GraphedTrainer(Trainer):
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena.world = self.world
         self.warm, self.calls, self.ready = warm, 0, False
+        if segment_backward is None:         # per-bucket backward graphs: needed (only) to overlap all-reduces with backward
+            segment_backward = self.world > 1 or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
+        self.segment_backward = bool(segment_backward)
 
     def _static_inputs(self, samples, targets):
         m = self.model
@@ -507,18 +523,43 @@ class GraphedTrainer(Trainer):
         with torch.cuda.graph(self.g_fwd):
             with ops.pinned_stream():
                 ops.counter_add(self.seed_word, 1)
-                rot, trans, _ = m.forward_core(self.s_feats, self.s_fmasks, self.s_imask, self.s_boxes, self.s_valid, self.s_cls)
+                rot, trans, hs = m.forward_core(self.s_feats, self.s_fmasks, self.s_imask, self.s_boxes, self.s_valid, self.s_cls)
         self.s_rot, self.s_trans = rot, trans
         self.s_drot, self.s_dtrans = torch.zeros_like(rot), torch.zeros_like(trans)
-        self.g_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
-            with ops.pinned_stream():
+        self.segs = None
+        if self.segment_backward:
+            # Backward captured as FOUR graphs, one per autograd node (= one gradient bucket each): at replay time the
+            # bucket's RCCL all-reduce is enqueued on the comm stream right after its segment, so it overlaps the
+            # remaining segments (main.py:282's DDP overlap, with graphs).  The optimiser is a fifth graph.
+            mem, src = m.transformer._last_memory, m._last_src
+            self.segs = []
+
+            def seg(fn):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.g_fwd.pool()):
+                    with ops.pinned_stream():
+                        out = fn()
+                self.segs.append(g)
+                return out
+
+            def first():
                 self.arena.zero_grad()
-                torch.autograd.backward([rot, trans], [self.s_drot, self.s_dtrans])
-                if self.world == 1:
+                return torch.autograd.grad([rot, trans], [hs], [self.s_drot, self.s_dtrans], retain_graph=True)[0]
+
+            dhs = seg(first)
+            dmem = seg(lambda: torch.autograd.grad([hs], [mem], [dhs], retain_graph=True)[0])
+            dsrc = seg(lambda: torch.autograd.grad([mem], [src], [dmem], retain_graph=True)[0])
+            seg(lambda: torch.autograd.backward([src], [dsrc]))
+            self._seg_keep = (dhs, dmem, dsrc)
+        else:
+            self.g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+                with ops.pinned_stream():
+                    self.arena.zero_grad()
+                    torch.autograd.backward([rot, trans], [self.s_drot, self.s_dtrans])
                     ops.counter_add(self.step_word, 1)
                     self.arena.step(self.max_norm, step_dev=self.step_word)
-        if self.world > 1:
+        if self.segs is not None:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
                 with ops.pinned_stream():

@@ -419,6 +419,7 @@ class PoET(nn.Module):
         geom = LevelGeom(shapes)
         names, params = _named(self.input_proj)
         src = Fn.InputProjFn.apply(feats, geom, 32, (act, stream), names, *params)
+        self._last_src = src                          # autograd-node boundaries: the graphed trainer splits backward here
         pos = torch.empty((N, geom.S, self.hidden_dim), dtype=act, device=dev)
         lvl_embed = tr.level_embed.detach().contiguous()
         for l, (h, w) in enumerate(geom.shapes):

@@ -48,6 +48,8 @@ def _worker(rank, world, port, q):
         assert not any("reference_points" in n for n in names)
         # buckets are contiguous, ordered by backward completion, and cover the arena exactly
         tags = [b[0] for b in arena.buckets]
+        from poet_amd.engine import SEGMENT_TAGS          # the graphed trainer announces exactly these after its backward segments
+        assert list(SEGMENT_TAGS) == tags[: len(SEGMENT_TAGS)], (SEGMENT_TAGS, tags)
         assert tags == ["0_heads", "1_decoder", "2_encoder", "3_input_proj", "4_proj"], tags
         assert arena.buckets[0][1] == 0 and arena.buckets[-1][2] == arena.total
         for (_, _, e), (_, s, _) in zip(arena.buckets[:-1], arena.buckets[1:]):

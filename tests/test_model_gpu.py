@@ -260,23 +260,31 @@ def test_graphed_trainer_matches_eager(gpu):
     from oracle.formula import CONFIGS, make_inputs
     cfg = CONFIGS["tiny"]
     runs = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "segmented"):
         r = gpu("tiny", 2, True, "bf16", dropout=0.0)
         r["model"].train()
         if mode == "eager":
             tr = poet_amd.Trainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
         else:
-            tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1)
+            # "segmented": backward captured as one graph per autograd node (what world > 1 uses to overlap the bucket
+            # all-reduces with the remaining backward); forced here on one GPU
+            tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1,
+                                         segment_backward=(mode == "segmented"))
         losses = []
         for step in range(5):
             _, _, targets = make_inputs(cfg, seed=100 + step, batch=2, pad=True)
             gt = [{k: (v.cuda() if k.startswith("relative") else v) for k, v in t.items()} for t in targets]
             total, _ = tr.step(r["samples"], gt)
             losses.append(float(total))
+        if mode != "eager":
+            assert (tr.segs is not None) == (mode == "segmented")
         runs[mode] = (losses, {n: p.detach().float().cpu().clone() for n, p in r["model"].named_parameters()})
-    assert runs["graph"][0] == pytest.approx(runs["eager"][0], rel=2e-3, abs=2e-3), runs
-    worst = max((runs["graph"][1][n] - runs["eager"][1][n]).abs().max().item() for n in runs["eager"][1])
-    assert worst < 1e-3, worst
+    for mode in ("graph", "segmented"):
+        assert runs[mode][0] == pytest.approx(runs["eager"][0], rel=2e-3, abs=2e-3), (mode, runs)
+        worst = max((runs[mode][1][n] - runs["eager"][1][n]).abs().max().item() for n in runs["eager"][1])
+        assert worst < 1e-3, (mode, worst)
+    worst = max((runs["segmented"][1][n] - runs["graph"][1][n]).abs().max().item() for n in runs["graph"][1])
+    assert worst < 1e-3, worst                    # same kernels in the same order (fp32 atomics make runs differ at ~1e-4 after AdamW)
 
 
 @pytest.mark.parametrize("input_seed,init_seed", [(1, 11), (2, 22), (5, 55)])
