@@ -49,6 +49,7 @@ extern "C" {
 #endif
 
 #define POET_ABI_VERSION 1
+#define POET_SQNORM_SCRATCH 1024
 
 #define POET_F32 0
 #define POET_BF16 1
@@ -268,7 +269,9 @@ int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_id
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Flat-arena optimizer pieces.  poet_sqnorm: out[0] += sum(g^2) (fp32, caller zero-fills).
+ * Flat-arena optimizer pieces.  poet_sqnorm: out[0] += sum(g^2) (fp32, caller zero-fills out[0]); `out` must have room
+ * for 1 + POET_SQNORM_SCRATCH floats: out[1..] receives per-workgroup partial sums that are then added in a fixed order,
+ * so the result is bit-reproducible (data-parallel replicas must derive identical clip factors from identical gradients).
  * poet_adamw: torch.optim.AdamW semantics on a flat fp32 range; grads are first multiplied by
  * clip = min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) when sqnorm != NULL; optionally writes the
  * bf16 shadow copy of the updated parameters.

@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__
 }
 
 // ---- flat-arena optimizer ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// Two launches, no atomics: every replica of a data-parallel job must get the SAME bits for the clip factor out of the
+// same reduced gradients (float atomics would make ranks drift apart by an ulp per step).
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
     __shared__ float sm[4];
     float s = 0.f;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
@@ -417,7 +419,17 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];              // fixed order per thread
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -628,7 +640,8 @@ extern "C" int poet_sqnorm(const float* g, int64_t n, float* out, void* stream) 
     POET_CHECK(g && out && n > 0, POET_ERR_ARG, "sqnorm: bad args");
     int nb = cdiv(n, 1024);
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(nb), dim3(256), 0, ST, g, n, out);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, ST, g, n, out + 1);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, ST, out + 1, nb, out);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

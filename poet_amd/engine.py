@@ -73,7 +73,7 @@ class ParamArena:
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sq = torch.zeros(1 + 1024, dtype=torch.float32, device=dev)       # [0] = sum of squares, [1:] = poet_sqnorm's partials
         # bf16 shadow of every weight: the second MFMA operand of the bf16 GEMMs; rewritten by the AdamW kernel
         self.flat_bf16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
         for n, p, o in self.entries:
@@ -416,6 +416,11 @@ class Trainer:
         if self.reducer is not None and self.reducer.world > 1:
             dist.broadcast(self.arena.flat, src=0)      # DDP's initial parameter sync
             self.arena.refresh_shadow()                 # the bf16 operand copies must follow the broadcast values
+            in_arena = {id(p) for _, p, _ in self.arena.entries}
+            with torch.no_grad():                       # parameters outside the arena (never trained) are synced too, as DDP does
+                for p in model.parameters():
+                    if id(p) not in in_arena:
+                        dist.broadcast(p.data, src=0)
 
     def step(self, samples, targets):
         with ops.pinned_stream():

@@ -472,6 +472,9 @@ def pose_finish_bwd(rot_all, cls, drot, dtrans, drot_all, dtrans_all, R, ncls):
 
 
 def sqnorm(g, out):
+    """out[0] += sum(g^2); out needs 1 + 1024 floats (poet_sqnorm keeps its per-workgroup partials in out[1:])."""
+    if out.numel() < 1025:
+        raise ValueError("sqnorm: `out` must hold 1 + 1024 floats")
     lib = _lib.load()
     _lib.check(lib.poet_sqnorm(_req(g, "g").data_ptr(), g.numel(), out.data_ptr(), _stream()), "poet_sqnorm")
 

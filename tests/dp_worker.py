@@ -1,0 +1,47 @@
+"""Helper for test_graphed_trainer_two_ranks: one data-parallel rank (gloo, both ranks on cuda:0).  Not a test module."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    graphed = sys.argv[5] == "graph"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import poet_amd
+    from oracle.formula import CONFIGS, make_inputs
+    from tests.product_runner import build_product
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r = build_product("tiny", 2, True, "bf16", dropout=0.0, seed=1234 + rank)     # different data, same formula weights
+    r["model"].train()
+    with torch.no_grad():                                                        # rank 1 starts perturbed: the broadcast must fix it
+        if rank:
+            for p in r["model"].parameters():
+                p.add_(0.01)
+    cls = poet_amd.GraphedTrainer if graphed else poet_amd.Trainer
+    kw = dict(warm=1) if graphed else {}
+    tr = cls(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, **kw)
+    if graphed:
+        assert tr.world == world and tr.segment_backward and tr.reducer is not None
+    cfg = CONFIGS["tiny"]
+    losses = []
+    for step in range(4):
+        _, _, targets = make_inputs(cfg, seed=100 + 10 * rank + step, batch=2, pad=True)
+        gt = [{k: (v.cuda() if k.startswith("relative") else v) for k, v in t.items()} for t in targets]
+        total, _ = tr.step(r["samples"], gt)
+        losses.append(float(total))
+    torch.cuda.synchronize()
+    if graphed:
+        assert tr.segs is not None and len(tr.segs) == 4
+    flat = torch.cat([p.detach().float().flatten() for p in r["model"].parameters()]).cpu().numpy()
+    np.savez(out, flat=flat, losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

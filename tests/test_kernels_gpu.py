@@ -411,8 +411,11 @@ def test_adamw_and_clip(ops):
         ref_p.grad = gs.clone()
         torch.nn.utils.clip_grad_norm_([ref_p], 0.1)
         opt.step()
-        sq = torch.zeros(1, device="cuda")
+        sq = torch.zeros(1 + 1024, device="cuda")      # [0] = sum, [1:] = partials (POET_SQNORM_SCRATCH)
         ops.sqnorm(dev(gs), sq)
+        sq2 = torch.zeros(1 + 1024, device="cuda")
+        ops.sqnorm(dev(gs), sq2)
+        assert torch.equal(sq[:1], sq2[:1])              # bit-reproducible (no atomics)
         ops.adamw(p, dev(gs), m, v, n, 2e-4, 0.9, 0.999, 1e-8, 1e-4, step, sqnorm_buf=sq, max_norm=0.1)
     assert torch.allclose(p.cpu(), ref_p.detach(), atol=1e-6)
 
