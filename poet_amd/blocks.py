@@ -14,7 +14,6 @@ import torch
 from . import ops
 
 _seed_state = {"base": 0x1234567, "count": 0}
-EXP = {}     # experiment knobs (dtype overrides), empty in production
 
 
 def manual_seed(seed: int):
@@ -182,14 +181,14 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
     q = empty(src.shape, src16.dtype, src)
     ops.add(src, pos, q)
     V = value_proj_fwd(src16, P_["self_attn.value_proj.weight"], P_["self_attn.value_proj.bias"], mask, N, S, M, D,
-                       EXP.get("v", act))
+                       act)
     out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
                            P_["self_attn.attention_weights.weight"], P_["self_attn.attention_weights.bias"],
-                           V, geom, ref, ref_bs, N, S, M, D, npts, EXP.get("oa", act))
+                           V, geom, ref, ref_bs, N, S, M, D, npts, act)
     x1, x1_16, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
                                  P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0])
     x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                             P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], EXP.get("h", act))
+                             P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act)
     saved = dict(src=src16, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1_16, ffn=ffn, seeds=seeds, pd=pd)
     return x2, x2_16, saved
 
