@@ -92,7 +92,7 @@ def gemm_flops_per_image(cfg):
 # WRITE_SIZE passes of this same command, profiles/collect_round1.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the
 # gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when the family is not in the summary.
 _PMC_NAMES = {"msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_kernel<", "msda_fused_fwd": "msda_fwd_kernel",
-              "gemm_dW": "gemm_dw_kernel", "gemm_dX": "gemm_ws_kernel<bf16, 1, true>", "gemm_fwd": "gemm_ws_kernel<bf16, 0, false>",
+              "gemm_dW": "gemm_dw_kernel", "gemm_dX": "gemm_ws_kernel<bf16, 1, true", "gemm_fwd": "gemm_ws_kernel<bf16, 0, false",
               "ln_fwd": "ln_fwd_kernel<bf16", "ln_bwd": "ln_bwd_kernel<bf16"}
 
 
