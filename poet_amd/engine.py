@@ -193,19 +193,6 @@ class PoseMatcher(nn.Module):
             raise NotImplementedError("PoseMatcher: only bbox_mode='gt' is implemented")
         self.cost_bbox, self.cost_class = cost_bbox, cost_class
         self._cache = (None, None)
-        self._tb_cache = {}
-
-    def _host_boxes(self, boxes: torch.Tensor) -> np.ndarray:
-        """Host copy of a target's boxes; device tensors are copied once per (storage, version) and remembered."""
-        if not boxes.is_cuda:
-            return boxes.detach().numpy().astype(np.float32, copy=False)
-        key = (boxes.data_ptr(), boxes._version, tuple(boxes.shape))
-        hit = self._tb_cache.get(key)
-        if hit is None:
-            if len(self._tb_cache) > 4096:
-                self._tb_cache.clear()
-            hit = self._tb_cache[key] = boxes.detach().cpu().numpy().astype(np.float32, copy=False)
-        return hit
 
     @torch.no_grad()
     def forward(self, outputs, targets, n_boxes):
@@ -216,12 +203,16 @@ class PoseMatcher(nn.Module):
         bs, nq = pb.shape[:2]
         host = outputs.get("_pred_boxes_host")          # same values, already on the host: no device sync
         out_bbox = (np.asarray(host, dtype=np.float32) if host is not None else pb.detach().cpu().numpy()).reshape(bs, nq, -1)
+        tgt_host = outputs.get("_tgt_boxes_host")        # host copy made by PoET.host_queries for this very batch
+        if tgt_host is None:                             # standalone use: copy now (one transfer; blocks like matcher.py:139 does)
+            from .modules import _to_host_list
+            tgt_host = _to_host_list([t["boxes"] for t in targets], np.float32)
         res = []
         for i, t in enumerate(targets):
             # L1 cost matrix of matcher.py:60-75 in numpy: the matrices are <= 20 x 20, and a torch CPU op here would wake
             # the whole OpenMP pool every step (its spinning workers eat the container's CPU quota and the process gets
             # descheduled for tens of ms while the GPU queue runs dry)
-            tb = self._host_boxes(t["boxes"])
+            tb = tgt_host[i]
             c = self.cost_bbox * np.abs(out_bbox[i, : n_boxes[i], None, :] - tb[None, :, :]).sum(-1)
             r, cidx = linear_sum_assignment(c)
             res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
@@ -298,8 +289,9 @@ class SetCriterion(nn.Module):
             self.matcher._cache = (None, None)      # the per-call cache must not outlive the call (static buffers are reused)
         aux_list = outputs.get("aux_outputs", [])
         for aux in aux_list:
-            if "_pred_boxes_host" in outputs:
-                aux["_pred_boxes_host"] = outputs["_pred_boxes_host"]
+            for k in ("_pred_boxes_host", "_tgt_boxes_host"):
+                if k in outputs:
+                    aux[k] = outputs[k]
         dev = outputs["pred_translation"].device
         indices = self.matcher(main, targets, n_boxes)
         all_idx = [indices] + [self.matcher(aux, targets, n_boxes) for aux in aux_list]

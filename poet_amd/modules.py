@@ -336,6 +336,22 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
 
+def _to_host_list(tensors, dtype):
+    """Per-image arrays on the host.  Device tensors are concatenated and copied with a single (blocking) transfer --
+    a `.cpu()` per image would drain the GPU queue N times per step."""
+    if not tensors:
+        return []
+    if all(torch.is_tensor(t) and t.is_cuda for t in tensors):
+        sizes = [int(t.shape[0]) for t in tensors]
+        flat = torch.cat([t.detach().reshape(t.shape[0], -1) for t in tensors], 0).cpu().numpy().astype(dtype, copy=False)
+        out, o = [], 0
+        for t, n in zip(tensors, sizes):
+            out.append(flat[o:o + n].reshape((n,) + tuple(t.shape[1:])))
+            o += n
+        return out
+    return [(t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)).astype(dtype, copy=False) for t in tensors]
+
+
 class PoET(nn.Module):
     """pose_estimation_transformer.py:32-451 for bbox_mode in {'gt','jitter'}, rotation_mode '6d',
     class_mode in {'specific','agnostic'}, query/ref-point mode 'bbox' (the reference's defaults)."""
@@ -386,9 +402,11 @@ class PoET(nn.Module):
         valid = np.zeros((N, Q), np.uint8)
         n_boxes = []
         key = "jitter_boxes" if self.bbox_mode == "jitter" else "boxes"
-        for i, t in enumerate(targets):
-            b = t[key].detach().cpu().numpy() if torch.is_tensor(t[key]) else np.asarray(t[key])
-            c = t["labels"].detach().cpu().numpy() if torch.is_tensor(t["labels"]) else np.asarray(t["labels"])
+        bl = _to_host_list([t[key] for t in targets], np.float32)       # ONE device->host copy per field, not one per image
+        cl = _to_host_list([t["labels"] for t in targets], np.int64)
+        # the matcher works on the ground-truth boxes: hand it this host copy instead of letting it sync again
+        self._tgt_boxes_host = bl if key == "boxes" else _to_host_list([t["boxes"] for t in targets], np.float32)
+        for i, (b, c) in enumerate(zip(bl, cl)):
             nb = len(b)
             if nb > Q:
                 raise ValueError(f"image {i} has {nb} boxes > num_queries={Q} (the reference assumes n <= Q in gt mode)")
@@ -441,6 +459,7 @@ class PoET(nn.Module):
             out["aux_outputs"] = [{"pred_translation": t, "pred_rotation": r, "pred_boxes": pred_boxes,
                                    "pred_classes": pred_classes} for t, r in zip(trans[:-1], rot[:-1])]
         out["_pred_boxes_host"] = boxes_host          # lets the matcher run without a device->host sync
+        out["_tgt_boxes_host"] = getattr(self, "_tgt_boxes_host", None)
         out["_stacked"] = (trans, rot)                # (L, N, Q, 3) / (L, N, Q, 3, 3): lets the criterion take all layers at once
         return out
 

@@ -287,6 +287,29 @@ def test_graphed_trainer_matches_eager(gpu):
     assert worst < 1e-3, worst                    # same kernels in the same order (fp32 atomics make runs differ at ~1e-4 after AdamW)
 
 
+def test_device_resident_targets_match_host_targets(gpu):
+    """The reference moves EVERY target field to the device (engine.py:63); boxes/labels on the GPU must give the same
+    losses as boxes/labels on the host, step after step with fresh target tensors (whose freed addresses get reused --
+    a pointer-keyed host cache of the boxes would hand the matcher the previous step's boxes)."""
+    import poet_amd
+    from oracle.formula import CONFIGS, make_inputs
+    cfg = CONFIGS["tiny"]
+    runs = {}
+    for where in ("host", "device"):
+        r = gpu("tiny", 2, True, torch.float32, dropout=0.0)
+        r["model"].train()
+        tr = poet_amd.Trainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+        losses = []
+        for step in range(6):
+            _, _, targets = make_inputs(cfg, seed=300 + step, batch=2, pad=True)
+            gt = [{k: (v.cuda() if (where == "device" or k.startswith("relative")) else v) for k, v in t.items()} for t in targets]
+            total, _ = tr.step(r["samples"], gt)
+            losses.append(float(total))
+            del gt, targets
+        runs[where] = losses
+    assert runs["device"] == pytest.approx(runs["host"], rel=1e-4, abs=1e-5), runs
+
+
 @pytest.mark.parametrize("input_seed,init_seed", [(1, 11), (2, 22), (5, 55)])
 @pytest.mark.parametrize("conditioned", [False, True])
 def test_bf16_full_size_seed_sweep(gpu, input_seed, init_seed, conditioned):
