@@ -358,35 +358,58 @@ __device__ __forceinline__ void row_points(const int (&cidx)[4], const float (&c
     }
 }
 
-template <typename TQ, int L, int P>
+// global load at a 32-bit BYTE offset from a uniform base: the address forms as SGPR base + VGPR offset, no 64-bit VALU
+template <typename T>
+__device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// D == 16, P == 4 (one DPP row of 16 lanes = the 16 channels of a head = the <= 16 sample points of a query).
+template <typename TQ, int L>
 __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP p, const TileP tp) {
     // LDS windows are INT32 FIXED POINT: ds_add_u32 sustains ~6.8 T lane-ops/s on MI355X, ds_add_f32 only ~0.2 T/s
     // (measured), i.e. float LDS atomics are no faster than L2 atomics.  Scale = 2^k per workgroup with
     // max|grad_out| * 2^k ~ 2^18: resolution 4e-6 of the tile's largest gradient, 2^13 contributions of headroom.
     // Used for bf16 storage only (the fp32 parity path keeps the exact float scatter).
+    static_assert(sizeof(TQ) == 2, "bf16 storage only");
     extern __shared__ __attribute__((aligned(16))) int win[];
     __shared__ float s_red[TILED_NT / 64];
-    constexpr int LP = L * P;
+    constexpr int P = 4, D = 16, LP = L * P, NSLOT = TILED_NT / D;
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m = blockIdx.y, n = blockIdx.z;
-    const int D = p.D;
-    int wx0[L], wy0[L], ww[L], wh[L], loff[L + 1];           // loff in pixels
+    int wx0[L], wy0[L], ww[L], wh[L], wp[L], loff[L + 1];    // loff in pixels; wp = LDS row pitch of the window
     loff[0] = 0;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const int W = p.W[l], H = p.H[l];
         const int ax = max((tx * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((tx + 1) * W, tp.TX) + tp.HALO, W);
         const int ay = max((ty * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((ty + 1) * H, tp.TY) + tp.HALO, H);
-        wx0[l] = ax; wy0[l] = ay; ww[l] = bx - ax; wh[l] = by - ay;
-        loff[l + 1] = loff[l] + ww[l] * wh[l];
+        wx0[l] = ax; wy0[l] = ay; ww[l] = bx - ax; wh[l] = by - ay; wp[l] = ww[l];
+        loff[l + 1] = loff[l] + wp[l] * wh[l];
     }
-    for (int i = tid; i < loff[L] * D; i += TILED_NT) win[i] = 0;
+    {
+        int4* w4 = reinterpret_cast<int4*>(win);
+        for (int i = tid; i < loff[L] * (D / 4); i += TILED_NT) w4[i] = make_int4(0, 0, 0, 0);
+    }
 
-    const int c = tid % D, slot = tid / D, nslots = TILED_NT / D;
-    const TQ* gob = reinterpret_cast<const TQ*>(p.grad_out) + (int64_t)m * D + c;
-    const int64_t gstride = (int64_t)p.M * D;
+    // lane roles (loop invariant): channel c of slot's query; and owner of sample point j = c (level l = j / P)
+    const int c = tid & 15, slot = tid >> 4, r = slot & 3;
+    const bool has = c < LP;
+    const int l = has ? (c >> 2) : 0;
+    int Wl = p.W[0], Hl = p.H[0], startl = p.start[0], lwx0 = wx0[0], lwy0 = wy0[0], lww = ww[0], lwh = wh[0], lwp = wp[0], lo = loff[0];
+#pragma unroll
+    for (int t = 1; t < L; ++t)
+        if (l == t) { Wl = p.W[t]; Hl = p.H[t]; startl = p.start[t]; lwx0 = wx0[t]; lwy0 = wy0[t]; lww = ww[t]; lwh = wh[t]; lwp = wp[t]; lo = loff[t]; }
+    const float WlF = (float)Wl, HlF = (float)Hl;
+    const uint32_t g_lane = (uint32_t)(m * D + c) * 2u, g_row = (uint32_t)(p.M * D) * 2u;             // byte offsets into grad_out
+    const uint32_t q_row = (uint32_t)p.ldq * 2u;
+    const uint32_t lg_lane = (uint32_t)(p.logit_col + m * LP + (has ? c : 0)) * 2u;
+    const uint32_t of_lane = (uint32_t)((m * LP + (has ? c : 0)) * 2) * 2u;
+    const uint32_t rf_lane = (uint32_t)(n * p.ref_bs + l * 2) * 4u, rf_q = (uint32_t)(L * 2) * 4u;
+    const int row0 = n * p.Lq;
 
-    // pass 1: max |grad_out| over this tile's queries -> power-of-two scale
+    // pass 1: max |grad_out| over this tile's queries (those whose pixel centre falls in the tile, at every level)
+    // -> power-of-two scale
     float gm = 0.f;
 #pragma unroll 1
     for (int lq = 0; lq < L; ++lq) {
@@ -395,11 +418,17 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
         const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
         const float inv_qw = 1.f / (float)max(qw, 1);
-        for (int i = slot; i < nq; i += nslots) {
+        const int qbase = row0 + p.start[lq] + qy0 * W + qx0;
+        auto g_of = [&](int i) __attribute__((always_inline)) {
             const int iy = idiv_small(i, qw, inv_qw);
-            const int64_t row = (int64_t)n * p.Lq + p.start[lq] + (qy0 + iy) * W + qx0 + (i - iy * qw);
-            gm = fmaxf(gm, fabsf(io<TQ>::ld(gob + row * gstride)));
+            return fabsf(bf2f(ldg32<TQ>(p.grad_out, (uint32_t)(qbase + iy * W + (i - iy * qw)) * g_row + g_lane)));
+        };
+        int i = slot;
+        for (; i + 3 * NSLOT < nq; i += 4 * NSLOT) {         // 4 independent loads in flight
+            const float g0 = g_of(i), g1 = g_of(i + NSLOT), g2 = g_of(i + 2 * NSLOT), g3 = g_of(i + 3 * NSLOT);
+            gm = fmaxf(fmaxf(gm, fmaxf(g0, g1)), fmaxf(g2, g3));
         }
+        for (; i < nq; i += NSLOT) gm = fmaxf(gm, g_of(i));
     }
     gm = wave_max(gm);
     if ((tid & 63) == 0) s_red[tid >> 6] = gm;
@@ -413,6 +442,12 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     const float scale = ldexpf(1.f, 18 - ex), inv = ldexpf(1.f, ex - 18);
 
     float* gvb = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;
+    const int lane_off = c * 4;
+    // One dummy pixel per DPP row of the wave, behind the windows.  (The LDS atomic unit works through a ds_add 16 lanes
+    // = one pixel = 16 consecutive banks at a time, so the 4 rows of a wave never conflict with each other: measured, a
+    // bank-quarter-aware corner order changes nothing.  The kernel is bound by the ~8 cycles the unit takes per ds_add.)
+    const int dummy = (loff[L] + r) * 64;
+
 #pragma unroll 1
     for (int lq = 0; lq < L; ++lq) {
         const int W = p.W[lq], H = p.H[lq];
@@ -420,104 +455,75 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
         const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
         const float inv_qw = 1.f / (float)max(qw, 1);
-        // software prefetch: the operands of query i + nslots are in flight while query i is scattered
-        const int j = c;
-        const bool has = j < LP;
-        const int l = has ? j / P : 0;
+        const int qbase = p.start[lq] + qy0 * W + qx0;
+        // software prefetch: the operands of query i + NSLOT are in flight while query i is scattered
         float n_g = 0.f, n_lg = -3.0e38f, n_ox = 0.f, n_oy = 0.f, n_rx = 0.f, n_ry = 0.f;
-        auto fetch = [&](int i) {
+        auto fetch = [&](int i) __attribute__((always_inline)) {
             const int iy = idiv_small(i, qw, inv_qw);
-            const int q = p.start[lq] + (qy0 + iy) * W + qx0 + (i - iy * qw);
-            const int64_t row = (int64_t)n * p.Lq + q;
-            n_g = io<TQ>::ld(gob + row * gstride);
-            if (has) {
-                const TQ* qrow = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq;
-                n_lg = io<TQ>::ld(qrow + p.logit_col + m * LP + j);
-                n_ox = io<TQ>::ld(qrow + (m * LP + j) * 2);
-                n_oy = io<TQ>::ld(qrow + (m * LP + j) * 2 + 1);
-                const float* rp = p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * L + l) * 2;
-                n_rx = rp[0]; n_ry = rp[1];
-            }
+            const int q = qbase + iy * W + (i - iy * qw);
+            const uint32_t row = (uint32_t)(row0 + q);
+            n_g = bf2f(ldg32<TQ>(p.grad_out, row * g_row + g_lane));
+            const uint32_t oxy = ldg32<uint32_t>(p.q1, row * q_row + of_lane);         // (off_x, off_y) bf16 pair
+            n_lg = has ? bf2f(ldg32<TQ>(p.q1, row * q_row + lg_lane)) : -3.0e38f;
+            n_ox = __uint_as_float(oxy << 16);
+            n_oy = __uint_as_float(oxy & 0xffff0000u);
+            const float2 rf = ldg32<float2>(p.ref, (uint32_t)q * rf_q + rf_lane);
+            n_rx = rf.x; n_ry = rf.y;
         };
         if (slot < nq) fetch(slot);
-        for (int i = slot; i < nq; i += nslots) {
+        for (int i = slot; i < nq; i += NSLOT) {
             const float gs = n_g * scale, lg = n_lg, ox = n_ox, oy = n_oy, rx = n_rx, ry = n_ry;
-            if (i + nslots < nq) fetch(i + nslots);
-            // ---- lane j (< L*P) of the slot prepares sample point j ----
-            float mx = lg, e, sum;
-            if (D == 16) {                                    // a slot is one DPP row: rotations instead of ds_bpermute
-                mx = row16_max(mx);
-                e = has ? __expf(lg - mx) : 0.f;
-                sum = row16_sum(e);
-            } else {
-                for (int o = 1; o < 16 && o < D; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                e = has ? __expf(lg - mx) : 0.f;
-                sum = e;
-                for (int o = 1; o < 16 && o < D; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            }
-            const float aj = e * __builtin_amdgcn_rcpf(sum);          // 1-ulp reciprocal: the weights feed a 2^-18 fixed point
+            if (i + NSLOT < nq) fetch(i + NSLOT);
+            // ---- lane j (< L*P) of the slot prepares sample point j: softmax over the DPP row, then its 4 corners ----
+            const float mx = row16_max(lg);
+            const float e = __expf(lg - mx);                             // lanes without a point carry -3e38: e = 0
+            const float aj = e * __builtin_amdgcn_rcpf(row16_sum(e));    // 1-ulp reciprocal: the weights feed a 2^-18 fixed point
+            const float px = fmaf(rx, WlF, ox - 0.5f), py = fmaf(ry, HlF, oy - 0.5f);
+            const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
+            const int x0 = (int)x0f, y0 = (int)y0f;                     // v_cvt saturates; every use below is an unsigned range test
+            const int lx0 = x0 - lwx0, ly0 = y0 - lwy0;
+            const bool wx_in[2] = {(unsigned)lx0 < (unsigned)lww, (unsigned)(lx0 + 1) < (unsigned)lww};
+            const bool wy_in[2] = {(unsigned)ly0 < (unsigned)lwh, (unsigned)(ly0 + 1) < (unsigned)lwh};
+            const bool ix_in[2] = {(unsigned)x0 < (unsigned)Wl, (unsigned)(x0 + 1) < (unsigned)Wl};
+            const bool iy_in[2] = {(unsigned)y0 < (unsigned)Hl, (unsigned)(y0 + 1) < (unsigned)Hl};
+            const float wxv[2] = {1.f - fx, fx}, wyv[2] = {(1.f - fy) * aj, fy * aj};
+            const int base = lo + ly0 * lwp + lx0;           // window slot corner 0 has (or would have)
+            // Per corner: window slot (>= 0) or -1 (nothing for the window: outside it, or outside the image -- at the coarse
+            // levels a +-4 px offset leaves an 8x10 map all the time).  Those go with weight 0 to a per-row dummy pixel behind
+            // the windows, so the accumulate loop below is branch-free; the rare in-image-but-outside-the-window corners are
+            // added with global atomics in a wave-voted second pass, and the result never depends on the halo.
             int cidx[4];
-            float cw[4];
+            float cw[4], cfar[4];
+            bool far = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { cidx[k] = -1; cw[k] = 0.f; }
-            if (has) {
-                const int Wl = p.W[l], Hl = p.H[l];
-                float px = ox + rx * (float)Wl - 0.5f;
-                float py = oy + ry * (float)Hl - 0.5f;
-                px = fminf(fmaxf(px, -2.f), (float)Wl + 1.f);
-                py = fminf(fmaxf(py, -2.f), (float)Hl + 1.f);
-                const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
-                const int x0 = (int)x0f, y0 = (int)y0f;
-                // window geometry of level l (runtime l: select from the unrolled per-level registers)
-                int lwx0 = wx0[0], lwy0 = wy0[0], lww = ww[0], lwh = wh[0], lo = loff[0];
-#pragma unroll
-                for (int t = 1; t < L; ++t)
-                    if (l == t) { lwx0 = wx0[t]; lwy0 = wy0[t]; lww = ww[t]; lwh = wh[t]; lo = loff[t]; }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
-                    const float wgt = ((k & 1) ? fx : 1.f - fx) * ((k >> 1) ? fy : 1.f - fy) * aj;
-                    if (xx >= 0 && xx < Wl && yy >= 0 && yy < Hl && wgt != 0.f) {
-                        const int lx = xx - lwx0, ly = yy - lwy0;
-                        cw[k] = wgt;
-                        cidx[k] = (lx >= 0 && lx < lww && ly >= 0 && ly < lwh) ? lo + ly * lww + lx
-                                                                                 : -2 - (p.start[l] + yy * Wl + xx);
-                    }
-                }
+            for (int k = 0; k < 4; ++k) {
+                const float wgt = wyv[k >> 1] * wxv[k & 1];
+                const bool inw = wx_in[k & 1] && wy_in[k >> 1] && has;
+                const bool inimg = ix_in[k & 1] && iy_in[k >> 1] && has;
+                cidx[k] = inw ? base + (k & 1) + (k >> 1) * lwp : -1;
+                cw[k] = inw ? wgt : 0.f;
+                cfar[k] = (inimg && !inw) ? wgt : 0.f;       // (the windows are clipped to the image: inw implies inimg)
+                far |= cfar[k] != 0.f;
             }
-            // ---- broadcast point by point to the channel lanes; int32 LDS accumulate ----
-            // D == 16: a slot is exactly one DPP row, so lane pt's registers reach the 16 channel lanes with
-            // v_mov_b32 row_newbcast (VALU) instead of ds_bpermute, which shares the LDS pipe with the atomics
-            // (measured: broadcasts were ~1.0 ms of this kernel's 1.5 ms at 640x480).
-            if (D == 16) {
-                // wave vote: when all 4 x LP x 4 corners of the wave are inside their windows (the common case away
-                // from image borders) run the branch-free body: 2 DPP moves + mul + cvt + add + ds_add per corner
-                const bool inwin = !has || (cidx[0] >= 0 && cidx[1] >= 0 && cidx[2] >= 0 && cidx[3] >= 0);
-                if (__all(inwin)) {
-                    // 3 VALU + 1 LDS op per corner: v_mul_f32_dpp (weight broadcast folded), v_cvt_rpi, v_add_u32_dpp (the
-                    // owner lane ships BYTE offsets, so the index broadcast folds into the address add), ds_add_u32
-                    int coff[4];
+            int coff[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) coff[k] = cidx[k] * 64;
-                    const int lane_off = c * 4;
-                    row_points<LP>(coff, cw, [&](int off, float wv) {
-                        atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (off + lane_off)), cvt_rpi(wv * gs));
-                    });
-                } else {
-                    row_points<LP>(cidx, cw, [&](int ii, float wv) {
-                        if (ii >= 0) atomicAdd(&win[ii * 16 + c], __float2int_rn(wv * gs));
-                        else if (ii <= -2) atomicAdd(gvb + (int64_t)(-2 - ii) * p.vs_s, wv * gs * inv);
-                    });
-                }
-            } else {
-#pragma unroll 4
+            for (int k = 0; k < 4; ++k) coff[k] = cidx[k] >= 0 ? cidx[k] * 64 : dummy;
+            // ---- broadcast point by point to the channel lanes; int32 LDS accumulate ----
+            // 3 VALU + 1 LDS op per corner: v_mul_f32_dpp (weight broadcast folded: row_newbcast, no ds_bpermute on the
+            // pipe the atomics use), v_cvt_rpi, v_add_u32_dpp (the owner lane ships BYTE offsets, so the index
+            // broadcast folds into the address add), ds_add_u32
+            row_points<LP>(coff, cw, [&](int off, float wv) {
+                atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (off + lane_off)), cvt_rpi(wv * gs));
+            });
+            if (__any(far)) {                                // compact and slow on purpose (rare)
+                const int gp0 = startl + y0 * Wl + x0;
+#pragma unroll 1
                 for (int pt = 0; pt < LP; ++pt) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int ii = __shfl(cidx[k], pt, D <= 64 ? D : 64);
-                        const float wv = __shfl(cw[k], pt, D <= 64 ? D : 64);
-                        if (ii >= 0) atomicAdd(&win[ii * D + c], __float2int_rn(wv * gs));
-                        else if (ii <= -2) atomicAdd(gvb + (int64_t)(-2 - ii) * p.vs_s, wv * gs * inv);
+                        const float wv = __shfl(cfar[k], pt, 16);
+                        const int gp = __shfl(gp0 + (k & 1) + (k >> 1) * Wl, pt, 16);
+                        if (wv != 0.f) atomicAdd(gvb + (int64_t)gp * p.vs_s, wv * gs * inv);
                     }
                 }
             }
@@ -525,15 +531,17 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     }
     __syncthreads();
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int cnt = ww[l] * wh[l] * D;
+    for (int l2 = 0; l2 < L; ++l2) {
+        const int cnt = wp[l2] * wh[l2] * D;
+        const float inv_wp = 1.f / (float)wp[l2];
+        float* gl = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)p.start[l2] * p.vs_s;
         for (int i = tid; i < cnt; i += TILED_NT) {
-            const int v = win[loff[l] * D + i];
+            const int v = win[loff[l2] * D + i];
             if (v != 0) {
-                const int cc = i % D, pix = i / D;
-                const int xx = wx0[l] + pix % ww[l], yy = wy0[l] + pix / ww[l];
-                atomicAdd(p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)(p.start[l] + yy * p.W[l] + xx) * p.vs_s + cc,
-                          (float)v * inv);
+                const int cc = i & 15, pix = i >> 4;
+                const int py = idiv_small(pix, wp[l2], inv_wp);
+                const int xx = wx0[l2] + pix - py * wp[l2], yy = wy0[l2] + py;
+                atomicAdd(gl + (int64_t)(yy * p.W[l2] + xx) * p.vs_s + cc, (float)v * inv);
             }
         }
     }
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
 
 // host: pick the tile grid / halo so the windows fit the LDS budget; returns bytes (0 = do not use the tiled kernel)
 static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
-    if (p.D < 16 || p.D > 64 || 256 % p.D != 0) return 0;
+    if (p.D != 16) return 0;
     const int budget = 150 * 1024;                         // two workgroups per CU (160 KB LDS); 640x480 fits a 4x4 tiling
     for (int halo = 4; halo >= 2; halo -= 2) {
         for (int t = 1; t <= 16; t *= 2) {
@@ -558,6 +566,7 @@ static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
                     }
                     worst = max(worst, fl);
                 }
+            worst += 4 * (size_t)p.D;                          // 4 dummy pixels behind the windows (see the kernel)
             if (worst * 4 <= (size_t)budget) { tp.TX = TX; tp.TY = TY; tp.HALO = halo; return worst * 4; }
         }
     }
@@ -566,16 +575,23 @@ static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
 
 template <typename TQ, int L>
 static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
-    if (P != 4 || L * P > 16 || sizeof(TQ) != 2) return false;
+    if constexpr (sizeof(TQ) != 2) return false;
+    else {
+    if (P != 4 || L * P > 16 || p.D != 16) return false;
+    // the kernel addresses grad_out / the offset|logit rows / the reference points with 32-bit byte offsets
+    const int64_t rows = (int64_t)p.N * p.Lq;
+    if (rows * p.M * p.D * 2 >= (1ll << 32) || rows * p.ldq * 2 >= (1ll << 32) || (p.ldq & 1) ||
+        ((int64_t)(p.N - 1) * p.ref_bs + (int64_t)p.Lq * L * 2) * 4 >= (1ll << 32) || (p.ref_bs & 1)) return false;
     TileP tp{};
     const size_t lds = plan_tiles(p, L, tp);
     { const char* e = getenv("POET_NO_TILED_SCATTER"); if (e && atoi(e)) return false; }
     if (!lds) return false;
-    auto kern = msda_bwd_dv_tiled_kernel<TQ, L, 4>;
+    auto kern = msda_bwd_dv_tiled_kernel<TQ, L>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr_set = true; }
     hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
     return true;
+    }
 }
 
 template <typename TV, typename TQ, int L, bool FUSED, bool BWD>
