@@ -93,6 +93,49 @@ __device__ __forceinline__ Corner make_corner(float px, float py, int H, int W, 
     return c;
 }
 
+// Corner geometry for the gather kernels.  Offsets are 32-bit BYTE offsets from MsdaP::value (the address forms as
+// SGPR base + VGPR offset, no 64-bit VALU; the host rejects value maps of 4 GiB and more), built with 24-bit multiplies
+// (v_mad_u32_u24 is full rate, v_mul_lo_u32 / v_mad_u64_u32 quarter rate: the 64-bit form of this address arithmetic was
+// a third of the forward kernel's VALU time).  v_cvt_i32_f32 saturates and every use of x0/y0 is an unsigned range test
+// or a clamp, so wild sampling locations need no float clamping.  Invalid corners get the address of a clamped pixel.
+// a * b + c with 24-bit a, b (full-rate v_mad_u32_u24; the compiler falls back to the quarter-rate v_mul_lo_u32 when it
+// cannot prove the operand ranges) and clamp(x, 0, hi) for hi >= 0 (v_med3_i32 instead of v_max + v_min)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int clamp0(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+
+struct Geo {
+    uint32_t o00, o01, o10, o11;
+    float fx, fy;
+    bool vx0, vx1, vy0, vy1;
+};
+__device__ __forceinline__ Geo corner_geo(float px, float py, int H, int W, uint32_t base, uint32_t pix_bytes) {
+    Geo g;
+    const float x0f = floorf(px), y0f = floorf(py);
+    g.fx = px - x0f;
+    g.fy = py - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);
+    g.vx0 = (unsigned)x0 < (unsigned)W; g.vx1 = (unsigned)x1 < (unsigned)W;
+    g.vy0 = (unsigned)y0 < (unsigned)H; g.vy1 = (unsigned)y1 < (unsigned)H;
+    const int xc0 = clamp0(x0, W - 1), xc1 = clamp0(x1, W - 1), yc0 = clamp0(y0, H - 1), yc1 = clamp0(y1, H - 1);
+    g.o00 = mad24(mad24(yc0, W, xc0), pix_bytes, base); g.o01 = mad24(mad24(yc0, W, xc1), pix_bytes, base);
+    g.o10 = mad24(mad24(yc1, W, xc0), pix_bytes, base); g.o11 = mad24(mad24(yc1, W, xc1), pix_bytes, base);
+    return g;
+}
+
+template <typename TV>
+__device__ __forceinline__ void gather8(const void* value, uint32_t byte_off, float* o) {
+    vec<TV, 8>::ld(reinterpret_cast<const TV*>(reinterpret_cast<const char*>(value) + byte_off), o);
+}
+
 template <typename TQ, int L, int P, bool FUSED>
 __device__ __forceinline__ void load_weights(const MsdaP& p, int64_t row, int m, float* a) {
     constexpr int LP = L * P;
@@ -145,9 +188,10 @@ __device__ __forceinline__ int64_t xcd_contiguous_block(int64_t b, int64_t nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// One level at a time in a ROLLED loop: 4*P corner loads (16 B each) are in flight per thread, 64 VGPRs, and the kernel
-// needs 168 (3 waves/SIMD; capped at 128 it spills the softmax weights), so other waves cover the gather latency.  (Fully unrolled, the allocator tries to keep all
-// 16*P loads resident: 256 VGPRs at best, and a spilling variant -- 3x slower -- whenever unrelated code shifts.)
+// One level at a time in a ROLLED loop: 4*P corner loads (16 B each) are in flight per thread, and other waves cover the
+// gather latency.  (Fully unrolled, the allocator tries to keep all 16*P loads resident: 256 VGPRs at best, and a spilling
+// variant -- 3x slower -- whenever unrelated code shifts.)  The kernel is VALU bound (PMC: ~80% VALU busy), so the body is
+// written for instruction count: 32-bit gather offsets, masked 1-D weights, FMA chains straight into the accumulators.
 template <typename TV, typename TQ, int L, int P, bool FUSED>
 __global__ __launch_bounds__(256, 3) void msda_fwd_kernel(const MsdaP p) {
     const int64_t t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
@@ -159,7 +203,8 @@ __global__ __launch_bounds__(256, 3) void msda_fwd_kernel(const MsdaP p) {
 
     float a[L * P];
     load_weights<TQ, L, P, FUSED>(p, row, m, a);
-    const TV* vbase = reinterpret_cast<const TV*>(p.value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8;
+    const uint32_t lane_base = (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8) * (int64_t)sizeof(TV));
+    const uint32_t pix_bytes = (uint32_t)p.vs_s * (uint32_t)sizeof(TV);
 
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -168,23 +213,31 @@ __global__ __launch_bounds__(256, 3) void msda_fwd_kernel(const MsdaP p) {
 #pragma unroll                                               // argument would put the arrays in scratch memory
         for (int k = 1; k < L; ++k)
             if (l == k) { Hl = p.H[k]; Wl = p.W[k]; Sl = p.start[k]; }
+        const uint32_t lvl_base = lane_base + (uint32_t)Sl * pix_bytes;
         float xy[2 * P];
         load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, Wl, Hl, xy);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const Corner c = make_corner(xy[2 * i], xy[2 * i + 1], Hl, Wl, Sl, p.vs_s);
-            float aw = a[0];
+            const Geo g = corner_geo(xy[2 * i], xy[2 * i + 1], Hl, Wl, lvl_base, pix_bytes);
+            float aw = a[i];
 #pragma unroll
-            for (int k = 1; k < L * P; ++k) aw = (k == l * P + i) ? a[k] : aw;      // a[] stays in registers (l is a run-time index)
+            for (int k = 1; k < L; ++k) aw = (l == k) ? a[k * P + i] : aw;          // a[] stays in registers (l is a run-time index)
             float v00[8], v01[8], v10[8], v11[8];
-            vec<TV, 8>::ld(vbase + c.o00, v00);
-            vec<TV, 8>::ld(vbase + c.o01, v01);
-            vec<TV, 8>::ld(vbase + c.o10, v10);
-            vec<TV, 8>::ld(vbase + c.o11, v11);
-            const float w00 = aw * c.w00, w01 = aw * c.w01, w10 = aw * c.w10, w11 = aw * c.w11;
+            gather8<TV>(p.value, g.o00, v00);
+            gather8<TV>(p.value, g.o01, v01);
+            gather8<TV>(p.value, g.o10, v10);
+            gather8<TV>(p.value, g.o11, v11);
+            const float wx0 = g.vx0 ? 1.f - g.fx : 0.f, wx1 = g.vx1 ? g.fx : 0.f;
+            const float wy0 = g.vy0 ? (1.f - g.fy) * aw : 0.f, wy1 = g.vy1 ? g.fy * aw : 0.f;
+            const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch)
-                acc[ch] += w00 * v00[ch] + w01 * v01[ch] + w10 * v10[ch] + w11 * v11[ch];
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w00, v00[ch], acc[ch]);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w01, v01[ch], acc[ch]);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w10, v10[ch], acc[ch]);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w11, v11[ch], acc[ch]);
         }
     }
     TQ* op = reinterpret_cast<TQ*>(p.out) + row * ((int64_t)p.M * p.D) + m * p.D + dsub * 8;
@@ -632,6 +685,13 @@ static void launch_l(const MsdaP& p, int L, int P, hipStream_t st) {
 
 template <bool FUSED, bool BWD>
 static int dispatch(const MsdaP& p, int L, int P, int v_dtype, int q_dtype, hipStream_t st) {
+    {   // the gather kernels address the value maps with 32-bit byte offsets and 24-bit pixel arithmetic
+        const int64_t esz = v_dtype == POET_BF16 ? 2 : 4;
+        const int64_t span = ((int64_t)(p.N - 1) * p.vs_n + (int64_t)(p.M - 1) * p.vs_m + (int64_t)(p.S - 1) * p.vs_s + p.D) * esz;
+        POET_CHECK(span < (1ll << 32) && p.vs_s * esz < (1 << 24) && p.S < (1 << 24) && p.vs_n >= 0 && p.vs_m >= 0 && p.vs_s > 0,
+                   POET_ERR_UNSUPPORTED, "msda: value maps of %lld bytes exceed the 4 GiB (32-bit offset) limit of the gather kernels",
+                   (long long)span);
+    }
     if (v_dtype == POET_BF16 && q_dtype == POET_BF16) launch_l<bf16_t, bf16_t, FUSED, BWD>(p, L, P, st);
     else if (v_dtype == POET_F32 && q_dtype == POET_F32) launch_l<float, float, FUSED, BWD>(p, L, P, st);
     else if (v_dtype == POET_BF16 && q_dtype == POET_F32) launch_l<bf16_t, float, FUSED, BWD>(p, L, P, st);
