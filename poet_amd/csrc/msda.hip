@@ -193,12 +193,17 @@ __device__ __forceinline__ int64_t xcd_contiguous_block(int64_t b, int64_t nb) {
 // variant -- 3x slower -- whenever unrelated code shifts.)  The kernel is VALU bound (PMC: ~80% VALU busy), so the body is
 // written for instruction count: 32-bit gather offsets, masked 1-D weights, FMA chains straight into the accumulators.
 template <typename TV, typename TQ, int L, int P, bool FUSED>
-__global__ __launch_bounds__(256, 3) void msda_fwd_kernel(const MsdaP p) {
+__global__ __launch_bounds__(256, 4) void msda_fwd_kernel(const MsdaP p) {
+    // lanes of a (query, head): [x corner 0/1][channel group]: the two x-neighbours of a sample are adjacent pixels of a
+    // head-major map, so the 2*tpg lanes read 2 * 16*tpg contiguous bytes per (sample, row) -- one L1 access, not two
     const int64_t t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (t >= p.total) return;
-    const int64_t row = t / p.groups;
-    const int c8 = (int)(t - row * p.groups);
-    const int m = c8 / p.tpg, dsub = c8 - m * p.tpg;
+    if (t >= p.total * 2) return;
+    const int g2 = p.groups * 2;
+    const int64_t row = t / g2;
+    const int c8 = (int)(t - row * g2);
+    const int m = c8 / (2 * p.tpg), rem = c8 - m * 2 * p.tpg;
+    const bool xc = rem >= p.tpg;
+    const int dsub = xc ? rem - p.tpg : rem;
     const int n = (int)(row / p.Lq), q = (int)(row - (int64_t)n * p.Lq);
 
     float a[L * P];
@@ -218,50 +223,89 @@ __global__ __launch_bounds__(256, 3) void msda_fwd_kernel(const MsdaP p) {
         load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, Wl, Hl, xy);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const Geo g = corner_geo(xy[2 * i], xy[2 * i + 1], Hl, Wl, lvl_base, pix_bytes);
             float aw = a[i];
 #pragma unroll
             for (int k = 1; k < L; ++k) aw = (l == k) ? a[k * P + i] : aw;          // a[] stays in registers (l is a run-time index)
-            float v00[8], v01[8], v10[8], v11[8];
-            gather8<TV>(p.value, g.o00, v00);
-            gather8<TV>(p.value, g.o01, v01);
-            gather8<TV>(p.value, g.o10, v10);
-            gather8<TV>(p.value, g.o11, v11);
-            const float wx0 = g.vx0 ? 1.f - g.fx : 0.f, wx1 = g.vx1 ? g.fx : 0.f;
-            const float wy0 = g.vy0 ? (1.f - g.fy) * aw : 0.f, wy1 = g.vy1 ? g.fy * aw : 0.f;
-            const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+            const float px = xy[2 * i], py = xy[2 * i + 1];
+            const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
+            const int x = (int)((unsigned)(int)x0f + (xc ? 1u : 0u)), y0 = (int)y0f, y1 = (int)((unsigned)y0 + 1u);
+            const float wx = (unsigned)x < (unsigned)Wl ? (xc ? fx : 1.f - fx) : 0.f;
+            const float w0 = (unsigned)y0 < (unsigned)Hl ? (1.f - fy) * aw * wx : 0.f;
+            const float w1 = (unsigned)y1 < (unsigned)Hl ? fy * aw * wx : 0.f;
+            const int xcl = clamp0(x, Wl - 1);
+            const uint32_t o0 = mad24(mad24(clamp0(y0, Hl - 1), Wl, xcl), pix_bytes, lvl_base);
+            const uint32_t o1 = mad24(mad24(clamp0(y1, Hl - 1), Wl, xcl), pix_bytes, lvl_base);
+            float v0[8], v1[8];
+            gather8<TV>(p.value, o0, v0);
+            gather8<TV>(p.value, o1, v1);
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w00, v00[ch], acc[ch]);
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[ch], acc[ch]);
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w01, v01[ch], acc[ch]);
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w10, v10[ch], acc[ch]);
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w11, v11[ch], acc[ch]);
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[ch], acc[ch]);
         }
     }
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) acc[ch] += __shfl_xor(acc[ch], p.tpg, 64);
+    if (xc) return;
     TQ* op = reinterpret_cast<TQ*>(p.out) + row * ((int64_t)p.M * p.D) + m * p.D + dsub * 8;
     vec<TQ, 8>::st(op, acc);
 }
 
-__device__ __forceinline__ float group_sum(float v, int tpg) {
-    for (int o = 1; o < tpg; o <<= 1) v += __shfl_xor(v, o, 64);
+// sum over the n (power of two) consecutive lanes of a group: DPP quad permutes for the first two steps (VALU only)
+__device__ __forceinline__ float group_sum(float v, int n) {
+    if (n >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    if (n >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    for (int o = 4; o < n; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// 8-channel slices as loaded (16 B for bf16, 32 B for fp32) and their dot product.  (v_dot2c_f32_bf16 would take the bf16
+// pairs directly, but measured here it was both slower than shift/and + FMA and wrong in this kernel: not used.)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    u32x4_t v;
+    __device__ __forceinline__ void load(const void* base, uint32_t byte_off) {
+        v = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(base) + byte_off);
+    }
+    __device__ __forceinline__ float f(int i) const { return (i & 1) ? __uint_as_float(v[i >> 1] & 0xffff0000u) : __uint_as_float(v[i >> 1] << 16); }
+};
+template <> struct Raw8<float> {
+    float x[8];
+    __device__ __forceinline__ void load(const void* base, uint32_t byte_off) {
+        vec<float, 8>::ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off), x);
+    }
+    __device__ __forceinline__ float f(int i) const { return x[i]; }
+};
+template <typename TA, typename TB>
+__device__ __forceinline__ float dot8(const float (&a)[8], const Raw8<TB>& b) {
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) { d0 = fmaf(a[i], b.f(i), d0); d1 = fmaf(a[i + 1], b.f(i + 1), d1); }
+    return d0 + d1;
+}
+
+// d(offsets | logits) (fused) or d(loc), d(attn) (plain).  Same lane layout as the forward: [x corner][channel group] per
+// (query, head), so a lane loads the two rows of ONE x corner; with T = (1-fy) d0 + fy d1 of that corner
+//   d/d(attn) = sum_x wx T,   d/d(px) = aw (T[x1] - T[x0]),   d/d(py) = aw sum_x wx (d1 - d0)
+// are all plain sums over the group's 2*tpg lanes.
 template <typename TV, typename TQ, int L, int P, bool FUSED>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
     const int64_t t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // same L2 argument as the forward
-    if (t >= p.total) return;
-    const int64_t row = t / p.groups;
-    const int c8 = (int)(t - row * p.groups);
-    const int m = c8 / p.tpg, dsub = c8 - m * p.tpg;
+    if (t >= p.total * 2) return;
+    const int g2 = p.groups * 2, gl = 2 * p.tpg;
+    const int64_t row = t / g2;
+    const int c8 = (int)(t - row * g2);
+    const int m = c8 / gl, rem = c8 - m * gl;
+    const bool xc = rem >= p.tpg;
+    const int dsub = xc ? rem - p.tpg : rem;
     const int n = (int)(row / p.Lq), q = (int)(row - (int64_t)n * p.Lq);
 
     float a[L * P];
     load_weights<TQ, L, P, FUSED>(p, row, m, a);
-    const int64_t voff = (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8;
-    const TV* vbase = reinterpret_cast<const TV*>(p.value) + voff;
+    const uint32_t lane_base = (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8) * (int64_t)sizeof(TV));
+    const uint32_t pix_bytes = (uint32_t)p.vs_s * (uint32_t)sizeof(TV);
 
     float g[8];
     vec<TQ, 8>::ld(reinterpret_cast<const TQ*>(p.grad_out) + row * ((int64_t)p.M * p.D) + m * p.D + dsub * 8, g);
@@ -269,45 +313,41 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
     float da[L * P];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
+        const int Wl = p.W[l], Hl = p.H[l];
+        const uint32_t lvl_base = lane_base + (uint32_t)p.start[l] * pix_bytes;
         float xy[2 * P], dxy[2 * P];
-        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, p.W[l], p.H[l], xy);
+        load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, Wl, Hl, xy);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const Corner c = make_corner(xy[2 * i], xy[2 * i + 1], p.H[l], p.W[l], p.start[l], p.vs_s);
-            const float aw = a[l * P + i];
-            float v00[8], v01[8], v10[8], v11[8];
-            vec<TV, 8>::ld(vbase + c.o00, v00);
-            vec<TV, 8>::ld(vbase + c.o01, v01);
-            vec<TV, 8>::ld(vbase + c.o10, v10);
-            vec<TV, 8>::ld(vbase + c.o11, v11);
-            float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                d00 += g[ch] * v00[ch]; d01 += g[ch] * v01[ch];
-                d10 += g[ch] * v10[ch]; d11 += g[ch] * v11[ch];
-            }
-            d00 *= c.m00; d01 *= c.m01; d10 *= c.m10; d11 *= c.m11;
-            float s_da = c.w00 * d00 + c.w01 * d01 + c.w10 * d10 + c.w11 * d11;   // weights already carry validity;
-            // (d.. were masked too, which is harmless: m*m = m)
-            float s_dx = aw * ((1.f - c.fy) * (d01 - d00) + c.fy * (d11 - d10));
-            float s_dy = aw * ((1.f - c.fx) * (d10 - d00) + c.fx * (d11 - d01));
-            da[l * P + i] = group_sum(s_da, p.tpg);
-            dxy[2 * i] = group_sum(s_dx, p.tpg);
-            dxy[2 * i + 1] = group_sum(s_dy, p.tpg);
+            const float px = xy[2 * i], py = xy[2 * i + 1];
+            const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
+            const int x = (int)((unsigned)(int)x0f + (xc ? 1u : 0u)), y0 = (int)y0f, y1 = (int)((unsigned)y0 + 1u);
+            const bool vx = (unsigned)x < (unsigned)Wl;
+            const int xcl = clamp0(x, Wl - 1);
+            Raw8<TV> v0, v1;
+            v0.load(p.value, mad24(mad24(clamp0(y0, Hl - 1), Wl, xcl), pix_bytes, lvl_base));
+            v1.load(p.value, mad24(mad24(clamp0(y1, Hl - 1), Wl, xcl), pix_bytes, lvl_base));
+            const float d0 = (vx && (unsigned)y0 < (unsigned)Hl) ? dot8<TQ, TV>(g, v0) : 0.f;
+            const float d1 = (vx && (unsigned)y1 < (unsigned)Hl) ? dot8<TQ, TV>(g, v1) : 0.f;
+            const float T = fmaf(fy, d1 - d0, d0);                       // (1-fy) d0 + fy d1
+            const float wx = xc ? fx : 1.f - fx, aw = a[l * P + i];
+            da[l * P + i] = group_sum(wx * T, gl);
+            dxy[2 * i] = group_sum(aw * (xc ? T : -T), gl);
+            dxy[2 * i + 1] = group_sum(aw * wx * (d1 - d0), gl);
         }
-        if (dsub == 0) {
+        if (rem == 0) {
             if constexpr (FUSED) {
                 TQ* gp = reinterpret_cast<TQ*>(p.g1) + row * p.ldq + (m * L + l) * P * 2;
                 store_p<TQ, P>(gp, dxy, 2 * P);          // d/d(offset) = (dpx, dpy): the W,H factors cancel
             } else {
 #pragma unroll
-                for (int i = 0; i < P; ++i) { dxy[2 * i] *= (float)p.W[l]; dxy[2 * i + 1] *= (float)p.H[l]; }
+                for (int i = 0; i < P; ++i) { dxy[2 * i] *= (float)Wl; dxy[2 * i + 1] *= (float)Hl; }
                 TQ* gp = reinterpret_cast<TQ*>(p.g1) + ((row * p.M + m) * L + l) * P * 2;
                 store_p<TQ, P>(gp, dxy, 2 * P);
             }
         }
     }
-    if (dsub == 0) {
+    if (rem == 0) {
         constexpr int LP = L * P;
         if constexpr (FUSED) {
             float dot = 0.f;
@@ -650,7 +690,7 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
 template <typename TV, typename TQ, int L, bool FUSED, bool BWD>
 static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     dim3 grid(cdiv(p.total, 256)), block(256);
-    dim3 gridv(cdiv(p.total * 8, 256));
+    dim3 gridv(cdiv(p.total * 8, 256)), gridf(cdiv(p.total * 2, 256));
     bool dv_done = !(p.parts & 2);
     if constexpr (BWD && FUSED) {
         if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
@@ -662,14 +702,14 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     }
     if (BWD && !(p.parts & 1)) return;
     if (P == 4) {
-        if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 4, FUSED>), grid, block, 0, st, p);
+        if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
+        else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
     } else if (P == 2) {
-        if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 2, FUSED>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 2, FUSED>), grid, block, 0, st, p);
+        if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 2, FUSED>), gridf, block, 0, st, p);
+        else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 2, FUSED>), gridf, block, 0, st, p);
     } else {
-        if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 1, FUSED>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 1, FUSED>), grid, block, 0, st, p);
+        if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 1, FUSED>), gridf, block, 0, st, p);
+        else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 1, FUSED>), gridf, block, 0, st, p);
     }
 }
 
