@@ -91,9 +91,12 @@ def gemm_flops_per_image(cfg):
 # HBM traffic per launch of a kernel family from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
 # WRITE_SIZE passes of this same command, profiles/collect_round1.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the
 # gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when the family is not in the summary.
+# profile tag (poet_amd/ops.py) -> substring of the kernel symbols in profiles/round1_pmc_hbm.csv
 _PMC_NAMES = {"msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_kernel<", "msda_fused_fwd": "msda_fwd_kernel",
-              "gemm_dW": "gemm_dw_kernel", "gemm_dX": "gemm_ws_kernel<bf16, 1, true", "gemm_fwd": "gemm_ws_kernel<bf16, 0, false",
+              "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws_kernel<", "gemm_stream_fwd": "gemm_ws_kernel<",
+              "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
               "ln_fwd": "ln_fwd_kernel<bf16", "ln_bwd": "ln_bwd_kernel<bf16"}
+_PMC_FILTER = {"gemm_stream_dX": ", true,", "gemm_stream_fwd": ", false,"}     # ws kernels: W stored [K][N] (dX) or not
 
 
 def pmc_traffic_bytes(tag):
@@ -103,10 +106,13 @@ def pmc_traffic_bytes(tag):
         return None
     import csv
     rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))][1:]
-    for r in rows:
-        if key in r[0]:
-            return int((2 * float(r[2]) + float(r[4])) * 1024)
-    return None
+    flt = _PMC_FILTER.get(tag, "")
+    tot = n = 0.0
+    for r in rows:                                      # launch-weighted mean over the symbols of the family
+        if key in r[0] and flt in r[0]:
+            tot += float(r[1]) * (2 * float(r[2]) + float(r[4])) * 1024
+            n += float(r[1])
+    return int(tot / n) if n else None
 
 
 def build_model(cfg, feats, precision, device):

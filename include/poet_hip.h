@@ -20,7 +20,7 @@
  *   poet_msda_fused_fwd / _bwd
  *       the same sampling with MSDeformAttn.forward's softmax over L*P logits and the
  *       loc = ref + offset/(W,H) arithmetic folded in (models/deformable_transformer.py:201,283).
- *   poet_gemm
+ *   poet_gemm, poet_gemm_last_path
  *       every nn.Linear / 1x1 nn.Conv2d on the path (deformable_transformer.py:182,185,258,261,
  *       the 4 Linears of MSDeformAttn, nn.MultiheadAttention's in/out projections :253,
  *       pose_estimation_transformer.py:106-122,684-688) and their backward contractions.
@@ -109,6 +109,10 @@ typedef struct PoetGemmDesc {
                                  fresh dropout mask on every replay (the host bumps the word between replays) */
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
+/* Which kernel family the calling thread's last successful poet_gemm launched (profiling aid: lets a caller attribute a
+ * launch time to the kernel symbol a rocprofv3 trace shows). */
+enum { POET_GEMM_PATH_NONE = 0, POET_GEMM_PATH_TILED = 1, POET_GEMM_PATH_STREAM = 2, POET_GEMM_PATH_DW = 3, POET_GEMM_PATH_SMALL = 4 };
+int poet_gemm_last_path(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-scale deformable attention core (upstream boundary).  Layouts as upstream:

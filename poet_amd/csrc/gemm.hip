@@ -381,6 +381,9 @@ static bool vec_ok(const void* ptr, int64_t ld, int64_t stride) {
 
 }  // namespace poet
 
+static thread_local int g_last_path = POET_GEMM_PATH_NONE;
+extern "C" int poet_gemm_last_path(void) { return g_last_path; }
+
 extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     using namespace poet;
     POET_CHECK(desc != nullptr, POET_ERR_ARG, "poet_gemm: null descriptor");
@@ -418,8 +421,14 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-    if (gemm_dw_try(p, st) || gemm_small_try(p, st)) {     // streaming dW (gemm_dw.hip) / latency-oriented 320-row kernels
-        POET_LAUNCH_CHECK();                                // (gemm_small.hip); both fuse the bias gradient of the dW form
+    if (gemm_dw_try(p, st)) {                               // streaming dW (gemm_dw.hip); fuses the bias gradient of the dW form
+        g_last_path = POET_GEMM_PATH_DW;
+        POET_LAUNCH_CHECK();
+        return POET_OK;
+    }
+    if (gemm_small_try(p, st)) {                            // latency-oriented 320-row kernels (gemm_small.hip); same fusion
+        g_last_path = POET_GEMM_PATH_SMALL;
+        POET_LAUNCH_CHECK();
         return POET_OK;
     }
     if (ysum) {                            // generic path: the column sums are a separate launch
@@ -428,9 +437,11 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         d.bias = nullptr;
     }
     if (gemm_ws_try(p, st)) {
+        g_last_path = POET_GEMM_PATH_STREAM;
         POET_LAUNCH_CHECK();
         return POET_OK;
     }
+    g_last_path = POET_GEMM_PATH_TILED;
     const int key = (d.a_dtype << 3) | (d.b_dtype << 2) | (d.c_dtype << 1) | d.compute;
     switch (key) {
         case (POET_BF16 << 3) | (POET_F32 << 2) | (POET_BF16 << 1) | POET_BF16:

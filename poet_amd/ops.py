@@ -153,7 +153,8 @@ class _Profile:
         tag = max(agg, key=lambda k: agg[k]["total_ms"])
         a = agg[tag]
         sec = a["total_ms"] / 1e3
-        mfma = tag.startswith("gemm")
+        # the binding roof is the one this family's own algorithmic flops / bytes take longer on
+        mfma = tag.startswith("gemm") and a["flops"] / (mfma_peak_tfs * 1e12) > a["bytes"] / (hbm_peak_gbs * 1e9)
         if mfma:
             ach, peak, unit = a["flops"] / sec / 1e12, mfma_peak_tfs, "TFLOP/s"
         else:
@@ -171,6 +172,9 @@ SIDE = _SideStream()
 
 def _esz(t):
     return t.element_size()
+
+
+_GEMM_PATHS = {0: "none", 1: "tiled", 2: "stream", 3: "dw", 4: "small"}
 
 
 class LevelGeom:
@@ -218,9 +222,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if PROFILE.on:
         e0 = PROFILE.begin()
         _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
-        kind = "gemm_dW" if (a_kmajor and atomic) else ("gemm_dX" if b_kmajor else "gemm_fwd")
+        # tag = the kernel family that ran (the symbol a rocprofv3 trace shows) x the GEMM's role
+        path = _GEMM_PATHS[lib.poet_gemm_last_path()]
+        role = "dW" if (a_kmajor and atomic) else ("dX" if b_kmajor else "fwd")
         nb = batch * (M * K * _esz(A) + M * N * _esz(Cout)) + N * K * _esz(B) * (batch if strideB else 1)
-        PROFILE.end(kind if M * N * K * batch > (1 << 28) else "gemm_small", e0, 2.0 * M * N * K * batch, nb)
+        for extra in (add_src, gate_ref):                     # epilogue operands the kernel also streams
+            if extra is not None:
+                nb += batch * M * N * _esz(extra)
+        PROFILE.end("gemm_small" if path == "small" else f"gemm_{path}_{role}", e0, 2.0 * M * N * K * batch, nb)
         return Cout
     _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
     return Cout
