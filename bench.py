@@ -205,7 +205,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    forced = os.environ.get("POET_FORCE_COLLECTIVES", "0") not in ("", "0")    # 1-rank RCCL group: exercises the N > 1 code path on one GPU
+    if world > 1 or (forced and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)      # 'nccl' == RCCL on ROCm
 
@@ -227,7 +228,7 @@ def main():
     samples = poet_amd.NestedTensor(None, torch.zeros((batch, ih, iw), dtype=torch.bool, device=device))
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -255,7 +256,7 @@ def main():
             eager.step(samples, targets)
             sync()
         prof = ops.PROFILE.stop()
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -293,7 +294,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -119,6 +119,18 @@ class ParamArena:
         return torch.sqrt(self.sq[0]) / self.world
 
 
+# Stream capture in THREAD-LOCAL error mode: with a live RCCL process group its watchdog thread polls hipEventQuery on the
+# work objects of earlier all-reduces, which the default (global) mode turns into hipErrorStreamCaptureUnsupported -- the
+# watchdog then aborts the process in the middle of the capture.  Only this thread's calls need policing.
+_CAPTURE = dict(capture_error_mode="thread_local")
+
+
+def collectives_forced() -> bool:
+    """POET_FORCE_COLLECTIVES=1: run the data-parallel machinery (broadcast, bucket all-reduces on the comm stream, segmented
+    backward graphs) even in a 1-rank process group.  Lets a single-GPU box exercise the RCCL code path end to end."""
+    return os.environ.get("POET_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
 class BucketReducer:
     """Data-parallel gradient all-reduce (the reference's DDP, main.py:282): one process per GPU,
     `torch.distributed` backend 'nccl' == RCCL over xGMI.  Buckets are whole contiguous arena ranges;
@@ -130,14 +142,15 @@ class BucketReducer:
     def __init__(self, arena: ParamArena, group=None):
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (collectives_forced() and dist.is_available() and dist.is_initialized())
         arena.world = self.world
         self.on_gpu = arena.grad.is_cuda
-        self.comm = torch.cuda.Stream() if (self.on_gpu and self.world > 1) else None
+        self.comm = torch.cuda.Stream() if (self.on_gpu and self.active) else None
         self.pending = []
         self.done = set()
 
     def bucket_done(self, tag: str):
-        if self.world == 1:
+        if not self.active:
             return
         for name, a, b in self.arena.buckets:
             if name == tag and name not in self.done:
@@ -157,7 +170,7 @@ class BucketReducer:
 
     def finish(self):
         """Reduce whatever was not announced (e.g. the 0.1x-LR tail), then make the compute stream wait."""
-        if self.world == 1:
+        if not self.active:
             return
         for name, a, b in self.arena.buckets:
             if name not in self.done:
@@ -403,9 +416,9 @@ class Trainer:
         self.model, self.criterion, self.max_norm = model, criterion, max_norm
         self.arena = ParamArena(model, lr=lr, weight_decay=weight_decay)
         if distributed is None:
-            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or collectives_forced())
         self.reducer = BucketReducer(self.arena) if distributed else None
-        if self.reducer is not None and self.reducer.world > 1:
+        if self.reducer is not None and self.reducer.active:
             dist.broadcast(self.arena.flat, src=0)      # DDP's initial parameter sync
             self.arena.refresh_shadow()                 # the bf16 operand copies must follow the broadcast values
             in_arena = {id(p) for _, p, _ in self.arena.entries}
@@ -454,7 +467,7 @@ class _Replay(torch.autograd.Function):
         if t.segs is None:
             t.g_bwd.replay()                 # backward + clip + AdamW in one graph (single GPU)
             return None, None
-        reduce = t.reducer is not None and t.world > 1
+        reduce = t.reducer is not None and t.reducer.active
         for g, tag in zip(t.segs, SEGMENT_TAGS):
             g.replay()
             if reduce:
@@ -485,7 +498,7 @@ class GraphedTrainer(Trainer):
         self.arena.world = self.world
         self.warm, self.calls, self.ready = warm, 0, False
         if segment_backward is None:         # per-bucket backward graphs: needed (only) to overlap all-reduces with backward
-            segment_backward = self.world > 1 or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
+            segment_backward = (self.reducer is not None and self.reducer.active) or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
         self.segment_backward = bool(segment_backward)
 
     def _static_inputs(self, samples, targets):
@@ -517,7 +530,7 @@ class GraphedTrainer(Trainer):
         set_reducer(None)
         torch.cuda.synchronize()
         self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd):
+        with torch.cuda.graph(self.g_fwd, **_CAPTURE):
             with ops.pinned_stream():
                 ops.counter_add(self.seed_word, 1)
                 rot, trans, hs = m.forward_core(self.s_feats, self.s_fmasks, self.s_imask, self.s_boxes, self.s_valid, self.s_cls)
@@ -533,7 +546,7 @@ class GraphedTrainer(Trainer):
 
             def seg(fn):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.g_fwd.pool()):
+                with torch.cuda.graph(g, pool=self.g_fwd.pool(), **_CAPTURE):
                     with ops.pinned_stream():
                         out = fn()
                 self.segs.append(g)
@@ -550,7 +563,7 @@ class GraphedTrainer(Trainer):
             self._seg_keep = (dhs, dmem, dsrc)
         else:
             self.g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), **_CAPTURE):
                 with ops.pinned_stream():
                     self.arena.zero_grad()
                     torch.autograd.backward([rot, trans], [self.s_drot, self.s_dtrans])
@@ -558,7 +571,7 @@ class GraphedTrainer(Trainer):
                     self.arena.step(self.max_norm, step_dev=self.step_word)
         if self.segs is not None:
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
+            with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool(), **_CAPTURE):
                 with ops.pinned_stream():
                     ops.counter_add(self.step_word, 1)
                     self.arena.step(self.max_norm, step_dev=self.step_word)

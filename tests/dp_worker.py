@@ -1,4 +1,5 @@
-"""Helper for test_graphed_trainer_two_ranks: one data-parallel rank (gloo, both ranks on cuda:0).  Not a test module."""
+"""Helper for the data-parallel GPU tests: one rank.  argv: rank world port out.npz graph|eager [backend=gloo]
+(gloo: several ranks share cuda:0; nccl: RCCL, one rank per GPU -- world 1 with POET_FORCE_COLLECTIVES=1).  Not a test module."""
 import os
 import sys
 
@@ -10,13 +11,17 @@ import torch.distributed as dist
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     graphed = sys.argv[5] == "graph"
+    backend = sys.argv[6] if len(sys.argv) > 6 else "gloo"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import poet_amd
     from oracle.formula import CONFIGS, make_inputs
     from tests.product_runner import build_product
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     r = build_product("tiny", 2, True, "bf16", dropout=0.0, seed=1234 + rank)     # different data, same formula weights
     r["model"].train()
     with torch.no_grad():                                                        # rank 1 starts perturbed: the broadcast must fix it
@@ -38,6 +43,7 @@ def main():
     torch.cuda.synchronize()
     if graphed:
         assert tr.segs is not None and len(tr.segs) == 4
+    assert tr.reducer is not None and tr.reducer.active
     flat = torch.cat([p.detach().float().flatten() for p in r["model"].parameters()]).cpu().numpy()
     np.savez(out, flat=flat, losses=np.array(losses))
     dist.destroy_process_group()

@@ -383,3 +383,38 @@ def test_data_parallel_two_ranks_one_gpu(gpu, tmp_path, mode):
     assert np.isfinite(a["flat"]).all() and np.isfinite(a["losses"]).all() and np.isfinite(b["losses"]).all()
     assert np.array_equal(a["flat"], b["flat"]), float(np.abs(a["flat"] - b["flat"]).max())
     assert not np.array_equal(a["losses"], b["losses"])          # the ranks really saw different data
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_rccl_code_path_one_rank(gpu, tmp_path, mode):
+    """The data-parallel machinery over the real backend ('nccl' == RCCL): a 1-rank process group with
+    POET_FORCE_COLLECTIVES=1 runs the broadcast, the bucket all-reduces on the comm stream and the segmented backward
+    graphs exactly as N ranks would (capturing HIP graphs next to a live RCCL watchdog thread is the part that a gloo run
+    cannot cover).  With one rank the all-reduce is the identity, so the result must equal the plain trainer's."""
+    import subprocess, sys as _sys
+    import poet_amd
+    from oracle.formula import CONFIGS, make_inputs
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = str(29000 + (os.getpid() % 300) + (0 if mode == "graph" else 400))
+    out = str(tmp_path / "rank0.npz")
+    env = dict(os.environ, POET_FORCE_COLLECTIVES="1")
+    p = subprocess.run([_sys.executable, os.path.join(here, "dp_worker.py"), "0", "1", port, out, mode, "nccl"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    a = np.load(out)
+    r = gpu("tiny", 2, True, "bf16", dropout=0.0, seed=1234)
+    r["model"].train()
+    if mode == "graph":
+        tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1, segment_backward=True)
+    else:
+        tr = poet_amd.Trainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+    losses = []
+    for step in range(4):
+        _, _, targets = make_inputs(CONFIGS["tiny"], seed=100 + step, batch=2, pad=True)
+        gt = [{k: (v.cuda() if k.startswith("relative") else v) for k, v in t.items()} for t in targets]
+        total, _ = tr.step(r["samples"], gt)
+        losses.append(float(total))
+    flat = torch.cat([q.detach().float().flatten() for q in r["model"].parameters()]).cpu().numpy()
+    assert np.isfinite(a["flat"]).all()
+    assert a["losses"] == pytest.approx(np.array(losses), rel=2e-3, abs=2e-3)
+    assert np.abs(a["flat"] - flat).max() < 1e-3                # (fp32 atomics in the dW kernels: runs differ at ~1e-4 after AdamW)
