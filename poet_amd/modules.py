@@ -343,7 +343,8 @@ def _to_host_list(tensors, dtype):
         return []
     if all(torch.is_tensor(t) and t.is_cuda for t in tensors):
         sizes = [int(t.shape[0]) for t in tensors]
-        flat = torch.cat([t.detach().reshape(t.shape[0], -1) for t in tensors], 0).cpu().numpy().astype(dtype, copy=False)
+        width = [int(np.prod(t.shape[1:])) for t in tensors]          # explicit: reshape(0, -1) of an object-less image is ambiguous
+        flat = torch.cat([t.detach().reshape(t.shape[0], w) for t, w in zip(tensors, width)], 0).cpu().numpy().astype(dtype, copy=False)
         out, o = [], 0
         for t, n in zip(tensors, sizes):
             out.append(flat[o:o + n].reshape((n,) + tuple(t.shape[1:])))

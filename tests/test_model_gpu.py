@@ -385,6 +385,40 @@ def test_data_parallel_two_ranks_one_gpu(gpu, tmp_path, mode):
     assert not np.array_equal(a["losses"], b["losses"])          # the ranks really saw different data
 
 
+def test_images_without_objects(gpu):
+    """Ragged and empty targets (the reference pads the query set per image and clamps the box count to >= 1,
+    pose_estimation_transformer.py:604-606): one image without objects == the oracle's loss; a batch with no objects at all
+    gives a zero loss and a finite step; the graphed trainer takes the same targets."""
+    import poet_amd
+    r = gpu("tiny", 2, True, torch.float32, dropout=0.0)
+    o = run_oracle("tiny", 2, True, backward=False)
+    strip = lambda t: {k: v[:0] for k, v in t.items()}
+    tg, to = [r["targets"][0], strip(r["targets"][1])], [o["targets"][0], strip(o["targets"][1])]
+    om = o["model"]
+    for m in om.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    om.transformer.decoder.layers.apply(lambda m: setattr(m, "dropout", 0.0) if isinstance(m, torch.nn.MultiheadAttention) else None)
+    om.train()
+    out, nb = om(o["samples"], to)
+    ls = o["crit"](out, to, nb)
+    ref = float(sum(ls[k] * o["crit"].weight_dict[k] for k in ls).detach())
+    assert list(nb)[1] == 0
+    r["model"].train()
+    tr = poet_amd.Trainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, distributed=False)
+    total, _ = tr.step(r["samples"], tg)
+    assert abs(float(total) - ref) < 2e-4 * max(1.0, abs(ref))
+    total, _ = tr.step(r["samples"], [strip(t) for t in r["targets"]])
+    assert float(total) == 0.0
+    assert all(torch.isfinite(p).all() for p in r["model"].parameters())
+    rb = gpu("tiny", 2, True, "bf16", dropout=0.0)
+    rb["model"].train()
+    gt = poet_amd.GraphedTrainer(rb["model"], rb["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1)
+    for _ in range(3):
+        total, _ = gt.step(rb["samples"], [rb["targets"][0], strip(rb["targets"][1])])
+    assert np.isfinite(float(total))
+
+
 @pytest.mark.parametrize("mode", ["graph", "eager"])
 def test_rccl_code_path_one_rank(gpu, tmp_path, mode):
     """The data-parallel machinery over the real backend ('nccl' == RCCL): a 1-rank process group with
