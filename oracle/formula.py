@@ -117,6 +117,28 @@ def make_inputs(cfg: dict, seed: int = 1234, batch: int | None = None, pad: bool
     return feats, sizes, targets
 
 
+def make_predictions(cfg: dict, seed: int = 77, batch: int = 3):
+    """Detector output for the inference path (pose_estimation_transformer.py:240-305): per image rows
+    (x0, y0, x1, y1, score, class) in pixels.  Image 0 has MORE rows than queries (top-k by score), image 1 fewer
+    (dummy padding), image 2 none at all (None); further images alternate.  Scores are distinct."""
+    rng = np.random.default_rng(seed)
+    ih, iw = cfg["image_hw"]
+    q, c = cfg["num_queries"], cfg["n_classes"]
+    preds = []
+    for i in range(batch):
+        kind = i % 3
+        if kind == 2:
+            preds.append(None)
+            continue
+        k = q + 3 if kind == 0 else max(1, q // 2)
+        cx, cy = rng.uniform(0.2, 0.8, k) * iw, rng.uniform(0.2, 0.8, k) * ih
+        w, h = rng.uniform(0.05, 0.25, k) * iw, rng.uniform(0.05, 0.25, k) * ih
+        score = rng.permutation(k).astype(np.float64) / k * 0.9 + 0.05
+        cls = rng.integers(1, c + 1, k)
+        preds.append(torch.from_numpy(np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, score, cls], 1).astype(np.float32)))
+    return preds
+
+
 def make_samples(cfg: dict, sizes):
     """Image batch as a list of (3,h,w) zero images -- content is irrelevant (backbone is synthetic),
     only the sizes (=> masks) matter."""

@@ -60,7 +60,7 @@ def _install_shims():
     sys.path.insert(0, REF)
 
 
-def _ref_model(cfg, feats):
+def _ref_model(cfg, feats, bbox_mode="gt", predictions=None):
     """Build the reference's own PoET around a Joiner-like synthetic backbone."""
     import torch.nn as nn
     import torch.nn.functional as F
@@ -87,7 +87,7 @@ def _ref_model(cfg, feats):
                 out.append(NestedTensor(f, m))
             for x in out:
                 pos.append(self.pe(x).to(x.tensors.dtype))
-            return out, pos, None
+            return out, pos, predictions
 
     tr = DeformableTransformer(d_model=cfg["d_model"], nhead=cfg["nheads"], num_encoder_layers=cfg["enc_layers"],
                                num_decoder_layers=cfg["dec_layers"], dim_feedforward=cfg["d_ffn"],
@@ -95,7 +95,7 @@ def _ref_model(cfg, feats):
                                num_feature_levels=cfg["n_levels"], dec_n_points=cfg["n_points"],
                                enc_n_points=cfg["n_points"])
     model = PoET(Joinerish(), tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
-                 n_classes=cfg["n_classes"], bbox_mode="gt", ref_points_mode="bbox", query_embedding_mode="bbox",
+                 n_classes=cfg["n_classes"], bbox_mode=bbox_mode, ref_points_mode="bbox", query_embedding_mode="bbox",
                  rotation_mode="6d", class_mode="specific", aleatoric=False, aux_loss=True, backbone_type="yolo")
     crit = SetCriterion(PoseMatcher(bbox_mode="gt", class_mode="specific"), build_weight_dict(cfg["dec_layers"]),
                         ["translation", "rotation"])
@@ -171,6 +171,29 @@ def _run_model(name, batch, pad, full, default_init=False):
     print("wrote", tag, "loss", float(total))
 
 
+def _run_inference(name, batch=3):
+    """The inference path (bbox_mode='backbone', eval, no targets): queries come from the detector rows."""
+    from oracle.formula import CONFIGS, formula_fill, make_inputs, make_predictions, make_samples
+    from util.misc import nested_tensor_from_tensor_list
+
+    cfg = CONFIGS[name]
+    feats, sizes, _ = make_inputs(cfg, seed=1234, batch=batch, pad=False)
+    preds = make_predictions(cfg, seed=77, batch=batch)
+    model, _ = _ref_model(cfg, feats, bbox_mode="backbone", predictions=preds)
+    formula_fill(model)
+    model.eval()
+    samples = nested_tensor_from_tensor_list(make_samples(cfg, sizes))
+    with torch.no_grad():
+        out, n_boxes = model(samples, None)
+    rec = {"pred_translation": out["pred_translation"].numpy(), "pred_rotation": out["pred_rotation"].numpy(),
+           "pred_boxes": out["pred_boxes"].numpy(), "pred_classes": out["pred_classes"].numpy(),
+           "aux_translation": np.stack([a["pred_translation"].numpy() for a in out["aux_outputs"]]) if out["aux_outputs"] else np.zeros((0,)),
+           "aux_rotation": np.stack([a["pred_rotation"].numpy() for a in out["aux_outputs"]]) if out["aux_outputs"] else np.zeros((0,)),
+           "n_boxes": np.asarray(n_boxes)}
+    np.savez_compressed(os.path.join(GOLD, f"poet_{name}_b{batch}_infer.npz"), **rec)
+    print("wrote", f"{name}_b{batch}_infer", "n_boxes", list(n_boxes))
+
+
 def _small_units():
     from models.position_encoding import PositionEmbeddingSine, BoundingBoxEmbeddingSine
     from models.pose_estimation_transformer import PoET
@@ -227,6 +250,10 @@ def main():
     if not os.path.isdir(REF):
         raise SystemExit("gen_golden needs /root/reference (build container only)")
     _install_shims()
+    if "--infer" in sys.argv:                 # only the inference goldens (added after the training ones)
+        _run_inference("tiny")
+        _run_inference("cfg0")
+        return
     _small_units()
     _run_model("tiny", 2, True, True)
     _run_model("tiny", 2, False, True)
@@ -235,6 +262,8 @@ def main():
     _run_model("ycbv", 1, False, False)
     _run_model("ycbv", 1, False, False, default_init=True)
     _run_model("tiny", 2, True, True, default_init=True)
+    _run_inference("tiny")
+    _run_inference("cfg0")
     subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", "--hf"], cwd=ROOT)
 
 

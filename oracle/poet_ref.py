@@ -343,12 +343,14 @@ def rotation_6d_to_matrix(rot_6d):
 
 class SyntheticBackbone(nn.Module):
     """Stands at the backbone interface (models/backbone.py:26-50 ``Joiner``): frozen, returns
-    pre-made multi-scale feature maps as NestedTensors, their sine encodings, and no detections.
-    ``self[1]`` is the position embedding (pose_estimation_transformer.py:332)."""
+    pre-made multi-scale feature maps as NestedTensors, their sine encodings, and the detections given at
+    construction (``predictions``: per image None or rows (x0, y0, x1, y1, score, class) in pixels; None = a training
+    backbone).  ``self[1]`` is the position embedding (pose_estimation_transformer.py:332)."""
 
-    def __init__(self, features: List[torch.Tensor], strides, num_channels, pos_feats=128):
+    def __init__(self, features: List[torch.Tensor], strides, num_channels, pos_feats=128, predictions=None):
         super().__init__()
         self.features = features
+        self.predictions = predictions
         self.strides, self.num_channels = list(strides), list(num_channels)
         self.position_embedding = PositionEmbeddingSine(pos_feats, normalize=True)
         self.train_backbone = False
@@ -363,7 +365,7 @@ class SyntheticBackbone(nn.Module):
             outs.append(NestedTensor(f, m))
         for x in outs:
             pos.append(self.position_embedding(x).to(x.tensors.dtype))
-        return outs, pos, None
+        return outs, pos, self.predictions
 
 
 class PoET(nn.Module):
@@ -416,9 +418,42 @@ class PoET(nn.Module):
             cls_all.append(cls)
         return torch.stack(emb_all), torch.stack(boxes_all), torch.stack(cls_all), n_boxes
 
-    def forward(self, samples: NestedTensor, targets):
-        features, pos, _ = self.backbone(samples)
-        query_embeds, pred_boxes, pred_classes, n_boxes = self.assemble_queries(targets)
+    def assemble_queries_backbone(self, pred_objects, image_hw):
+        """pose_estimation_transformer.py:240-305 ('backbone' mode, the inference path): per image the detector's
+        rows (x0, y0, x1, y1, score, class) in pixels -> cxcywh normalised by the batch's image size (util/box_ops.py:
+        24-40); more rows than queries: the top n_queries by score; fewer (or None): dummy padding as in 'gt' mode."""
+        ih, iw = image_hw
+        boxes_all, cls_all, emb_all, n_boxes = [], [], [], []
+        for pred in pred_objects:
+            if pred is None:
+                nb, boxes, cls = 0, torch.zeros((0, 4)), torch.zeros((0,), dtype=torch.int64)
+                emb = torch.zeros((0, 2 * self.hidden_dim))
+            else:
+                x0, y0, x1, y1 = pred[:, :4].unbind(-1)
+                boxes = torch.stack([(x0 + x1) / 2 / iw, (y0 + y1) / 2 / ih, (x1 - x0) / iw, (y1 - y0) / ih], -1)
+                scores, cls = pred[:, 4], pred[:, 5].to(torch.int64)
+                emb = self.bbox_embedding(boxes).repeat(1, 2)
+                nb = len(boxes)
+                if nb > self.n_queries:
+                    order = torch.sort(scores, dim=0, descending=True)[1][: self.n_queries]
+                    boxes, cls, emb, nb = boxes[order], cls[order], emb[order], self.n_queries
+            pad = self.n_queries - nb
+            if pad > 0:
+                boxes = torch.vstack((boxes, torch.full((pad, 4), -1.0)))
+                emb = torch.cat([emb, torch.full((pad, 2 * self.hidden_dim), -10.0)], 0)
+                cls = torch.cat((cls, torch.full((pad,), -1, dtype=torch.int64)))
+            n_boxes.append(nb)
+            boxes_all.append(boxes)
+            emb_all.append(emb)
+            cls_all.append(cls)
+        return torch.stack(emb_all), torch.stack(boxes_all), torch.stack(cls_all), n_boxes
+
+    def forward(self, samples: NestedTensor, targets=None):
+        features, pos, pred_objects = self.backbone(samples)
+        if self.bbox_mode == "backbone":
+            query_embeds, pred_boxes, pred_classes, n_boxes = self.assemble_queries_backbone(pred_objects, samples.tensors.shape[-2:])
+        else:
+            query_embeds, pred_boxes, pred_classes, n_boxes = self.assemble_queries(targets)
         srcs, masks = [], []
         for lvl, feat in enumerate(features):
             src, mask = feat.decompose()
@@ -533,12 +568,12 @@ def param_groups(model, lr=2e-4, lr_backbone=2e-5, proj_names=("reference_points
     ]
 
 
-def build_poet(cfg, features):
+def build_poet(cfg, features, bbox_mode="gt", predictions=None):
     """cfg: dict(d_model, nheads, enc_layers, dec_layers, d_ffn, n_levels, n_points, num_queries,
     n_classes, dropout, strides, num_channels)."""
-    bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2)
+    bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions)
     tr = DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"],
                                cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"])
-    model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], "gt", "specific", True)
+    model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, "specific", True)
     crit = SetCriterion(PoseMatcher(), build_weight_dict(cfg["dec_layers"]))
     return model, crit

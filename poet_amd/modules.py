@@ -354,15 +354,16 @@ def _to_host_list(tensors, dtype):
 
 
 class PoET(nn.Module):
-    """pose_estimation_transformer.py:32-451 for bbox_mode in {'gt','jitter'}, rotation_mode '6d',
+    """pose_estimation_transformer.py:32-451 for bbox_mode in {'gt','jitter'} (training: queries from the targets) and
+    'backbone' (inference: queries from the detector rows the backbone returns), rotation_mode '6d',
     class_mode in {'specific','agnostic'}, query/ref-point mode 'bbox' (the reference's defaults)."""
 
     def __init__(self, backbone, transformer, num_queries, num_feature_levels, n_classes, bbox_mode="gt",
                  ref_points_mode="bbox", query_embedding_mode="bbox", rotation_mode="6d", class_mode="agnostic",
                  aleatoric=False, aux_loss=True, backbone_type="yolo"):
         super().__init__()
-        if bbox_mode not in ("gt", "jitter") or ref_points_mode != "bbox" or query_embedding_mode != "bbox":
-            raise NotImplementedError("only bbox_mode gt/jitter with bbox queries/reference points is implemented")
+        if bbox_mode not in ("gt", "jitter", "backbone") or ref_points_mode != "bbox" or query_embedding_mode != "bbox":
+            raise NotImplementedError("only bbox_mode gt/jitter/backbone with bbox queries/reference points is implemented")
         if rotation_mode != "6d" or aleatoric:
             raise NotImplementedError("only the 6d rotation representation without aleatoric heads is implemented")
         self.transformer = transformer
@@ -415,6 +416,36 @@ class PoET(nn.Module):
             boxes[i, :nb], classes[i, :nb], valid[i, :nb] = b, c, 1
         return boxes, classes, valid, n_boxes
 
+    def host_queries_backbone(self, pred_objects, image_hw):
+        """'backbone' mode (pose_estimation_transformer.py:240-305), on the host like host_queries: per image the detector
+        rows (x0, y0, x1, y1, score, class) in pixels -> cxcywh normalised by the batch image size (util/box_ops.py:24-40;
+        the reference uses image_sizes[0] for the whole batch); more rows than queries: the n_queries best scores, in
+        descending order; fewer, or None: dummy padding (box -1, class -1)."""
+        N, Q = len(pred_objects), self.n_queries
+        ih, iw = float(image_hw[0]), float(image_hw[1])
+        boxes = np.full((N, Q, 4), -1.0, np.float32)
+        classes = np.full((N, Q), -1, np.int64)
+        valid = np.zeros((N, Q), np.uint8)
+        n_boxes = []
+        have = [i for i, p in enumerate(pred_objects) if p is not None and len(p)]
+        rows = dict(zip(have, _to_host_list([pred_objects[i] for i in have], np.float32)))   # one device->host copy for the batch
+        for i in range(N):
+            r = rows.get(i)
+            if r is None:
+                n_boxes.append(0)
+                continue
+            if len(r) > Q:
+                r = r[np.argsort(-r[:, 4], kind="stable")[:Q]]
+            nb = len(r)
+            x0, y0, x1, y1 = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+            b = np.stack([(x0 + x1) / np.float32(2), (y0 + y1) / np.float32(2), x1 - x0, y1 - y0], -1)
+            boxes[i, :nb] = b / np.array([iw, ih, iw, ih], np.float32)
+            classes[i, :nb] = r[:, 5].astype(np.int64)
+            valid[i, :nb] = 1
+            n_boxes.append(nb)
+        self._tgt_boxes_host = None
+        return boxes, classes, valid, n_boxes
+
     def forward_core(self, feats, feat_masks, image_mask, boxes, valid, classes):
         """Device-only part of forward (capturable in a hipGraph: no host sync, no host-dependent shapes).
         feats: list of NCHW maps; feat_masks: list of (N,h,w) uint8; image_mask (N,H,W) uint8;
@@ -465,11 +496,17 @@ class PoET(nn.Module):
         return out
 
     def forward(self, samples, targets=None):
-        if targets is None:
-            raise NotImplementedError("bbox_mode gt/jitter needs targets")
-        features, _pos, _pred = self.backbone(samples)
+        features, _pos, pred_objects = self.backbone(samples)
         dev = features[0].tensors.device
-        boxes, classes, valid, n_boxes = self.host_queries(targets)
+        if self.bbox_mode == "backbone":
+            if pred_objects is None:
+                raise ValueError("bbox_mode 'backbone' needs the backbone's detections (third output of backbone(samples))")
+            hw = samples.tensors.shape[-2:] if getattr(samples, "tensors", None) is not None else samples.mask.shape[-2:]
+            boxes, classes, valid, n_boxes = self.host_queries_backbone(pred_objects, hw)
+        else:
+            if targets is None:
+                raise ValueError("bbox_mode gt/jitter needs targets")
+            boxes, classes, valid, n_boxes = self.host_queries(targets)
         pred_boxes = torch.from_numpy(boxes).to(dev, non_blocking=True)
         pred_classes = torch.from_numpy(classes).to(dev, non_blocking=True)
         val = torch.from_numpy(valid).to(dev, non_blocking=True)

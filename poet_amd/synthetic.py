@@ -1,6 +1,7 @@
 """Synthetic stand-in at the backbone interface (models/backbone.py:26-50 `Joiner`): the reference's
 detector backbone is frozen, external and out of scope, so benchmarks and tests feed pre-made
-multi-scale feature maps here.  Returns (features: list[NestedTensor], pos: None, predictions: None);
+multi-scale feature maps here.  Returns (features: list[NestedTensor], pos: None, predictions) where `predictions` are the
+detector rows given at construction (None for training; inference: per image None or (n, 6) rows x0,y0,x1,y1,score,class);
 level masks are the nearest-neighbour resize of the image padding mask, as real backbones produce."""
 from __future__ import annotations
 
@@ -14,9 +15,11 @@ from .modules import NestedTensor, PositionEmbeddingSine
 
 
 class SyntheticBackbone(nn.Module):
-    def __init__(self, features: List[torch.Tensor], strides: Sequence[int], num_channels: Sequence[int], pos_feats: int = 128):
+    def __init__(self, features: List[torch.Tensor], strides: Sequence[int], num_channels: Sequence[int], pos_feats: int = 128,
+                 predictions=None):
         super().__init__()
         self.features = features
+        self.predictions = predictions
         self.strides, self.num_channels = list(strides), list(num_channels)
         self.position_embedding = PositionEmbeddingSine(pos_feats, normalize=True)
         self.train_backbone = False
@@ -34,7 +37,7 @@ class SyntheticBackbone(nn.Module):
             m = torch.empty((N, h, w), dtype=torch.uint8, device=f.device)
             ops.mask_nearest(im8, m, N, H, W, h, w)
             out.append(NestedTensor(f, m))
-        return out, None, None
+        return out, None, self.predictions
 
 
 def image_mask(sizes, device):

@@ -31,3 +31,18 @@ def run_oracle(name, batch, pad, seed=1234, backward=True, train=False, default_
         total.backward()
     return dict(cfg=cfg, model=model, crit=crit, out=out, n_boxes=n_boxes, losses=losses, total=total,
                 memory=cap["memory"], hs=cap["hs"], feats=feats, sizes=sizes, targets=targets, samples=samples)
+
+
+def run_oracle_inference(name, batch=3):
+    """The inference path (bbox_mode='backbone', eval(), no targets) on the seeded detector rows of formula.make_predictions."""
+    from oracle.formula import make_predictions
+    cfg = CONFIGS[name]
+    feats, sizes, _ = make_inputs(cfg, seed=1234, batch=batch, pad=False)
+    preds = make_predictions(cfg, seed=77, batch=batch)
+    model, _ = poet_ref.build_poet(cfg, feats, bbox_mode="backbone", predictions=preds)
+    formula_fill(model)
+    model.eval()
+    samples = poet_ref.nested_from_list(make_samples(cfg, sizes))
+    with torch.no_grad():
+        out, n_boxes = model(samples, None)
+    return dict(cfg=cfg, model=model, out=out, n_boxes=n_boxes, feats=feats, sizes=sizes, preds=preds, samples=samples)

@@ -6,14 +6,15 @@ from poet_amd.synthetic import SyntheticBackbone, image_mask
 from oracle.formula import CONFIGS, formula_fill, make_inputs
 
 
-def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False):
+def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False,
+                  bbox_mode="gt", predictions=None):
     if not isinstance(precision, str):
         precision = "fp32" if precision == torch.float32 else "bf16"
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
     fd = feat_dtype or torch.float32
     gfeats = [f.cuda().to(fd) for f in feats]
-    bb = SyntheticBackbone(gfeats, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2)
+    bb = SyntheticBackbone(gfeats, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions)
     p = cfg["dropout"] if dropout is None else dropout
     if default_init:
         torch.manual_seed(4321)          # oracle/gen_golden.py INIT_SEED: the reference's own init order
@@ -24,7 +25,7 @@ def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, f
                                         enc_n_points=cfg["n_points"])
     tr.set_precision(precision)
     model = poet_amd.PoET(bb, tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
-                          n_classes=cfg["n_classes"], bbox_mode="gt", class_mode="specific", aux_loss=True)
+                          n_classes=cfg["n_classes"], bbox_mode=bbox_mode, class_mode="specific", aux_loss=True)
     if not default_init:
         formula_fill(model)
     model = model.cuda()

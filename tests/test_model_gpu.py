@@ -385,6 +385,28 @@ def test_data_parallel_two_ranks_one_gpu(gpu, tmp_path, mode):
     assert not np.array_equal(a["losses"], b["losses"])          # the ranks really saw different data
 
 
+@pytest.mark.parametrize("name", ["tiny", "cfg0"])
+@pytest.mark.parametrize("precision,tol_t,tol_r", [("fp32", 1e-3, 1e-3), ("bf16", 1e-2, 1e-2)])
+def test_inference_path_vs_reference_golden(gpu, golden_dir, name, precision, tol_t, tol_r):
+    """Inference (bbox_mode='backbone', eval(), no targets; pose_estimation_transformer.py:240-305): queries assembled
+    from detector rows that live on the GPU -- top-k by score, dummy padding, an image without detections -- must give
+    the real reference's boxes / classes exactly and its poses within the north-star tolerances."""
+    from oracle.formula import CONFIGS, make_predictions
+    g = np.load(os.path.join(golden_dir, f"poet_{name}_b3_infer.npz"))
+    preds = [None if p is None else p.cuda() for p in make_predictions(CONFIGS[name], seed=77, batch=3)]
+    r = gpu(name, 3, False, precision, bbox_mode="backbone", predictions=preds)
+    r["model"].eval()
+    with torch.no_grad():
+        out, n_boxes = r["model"](r["samples"])
+    assert list(n_boxes) == list(g["n_boxes"])
+    np.testing.assert_array_equal(out["pred_classes"].cpu().numpy(), g["pred_classes"])
+    np.testing.assert_allclose(out["pred_boxes"].cpu().numpy(), g["pred_boxes"], rtol=0, atol=1e-7)
+    real = _real_query_mask(n_boxes, r["cfg"]["num_queries"])
+    dt = (out["pred_translation"].float().cpu() - torch.from_numpy(g["pred_translation"]))[real].abs().max().item()
+    dr = (out["pred_rotation"].float().cpu() - torch.from_numpy(g["pred_rotation"]))[real].abs().max().item()
+    assert dt < tol_t and dr < tol_r, (dt, dr)
+
+
 def test_images_without_objects(gpu):
     """Ragged and empty targets (the reference pads the query set per image and clamps the box count to >= 1,
     pose_estimation_transformer.py:604-606): one image without objects == the oracle's loss; a batch with no objects at all

@@ -99,3 +99,20 @@ def test_state_dict_keys_match_reference(golden_dir):
     g = _load(golden_dir, "poet_tiny_b2.npz")
     r = run_oracle("tiny", 2, False, backward=False)
     assert [str(x) for x in g["grad_names"]] == [n for n, _ in r["model"].named_parameters()]
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg0"])
+def test_oracle_inference_path_matches_reference(golden_dir, name):
+    """bbox_mode='backbone' (pose_estimation_transformer.py:240-305): more detections than queries (top-k by score), fewer
+    (dummy padding) and none at all (None) -- the oracle's query assembly and outputs equal the real reference's."""
+    from tests.oracle_runner import run_oracle_inference
+    g = np.load(os.path.join(golden_dir, f"poet_{name}_b3_infer.npz"))
+    o = run_oracle_inference(name)
+    assert list(o["n_boxes"]) == list(g["n_boxes"])
+    assert o["n_boxes"][0] == o["cfg"]["num_queries"] and o["n_boxes"][2] == 0
+    np.testing.assert_array_equal(o["out"]["pred_classes"].numpy(), g["pred_classes"])
+    np.testing.assert_allclose(o["out"]["pred_boxes"].numpy(), g["pred_boxes"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(o["out"]["pred_translation"].numpy(), g["pred_translation"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o["out"]["pred_rotation"].numpy(), g["pred_rotation"], rtol=1e-5, atol=1e-6)
+    if o["out"]["aux_outputs"]:                         # (cfg0 has a single decoder layer: no auxiliary outputs)
+        np.testing.assert_allclose(np.stack([a["pred_rotation"].numpy() for a in o["out"]["aux_outputs"]]), g["aux_rotation"], rtol=1e-5, atol=1e-6)
