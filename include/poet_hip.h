@@ -134,6 +134,8 @@ int poet_msda_bwd(const void* value, const int64_t* spatial_shapes_host, const i
  * ref (Nref,Lq,L,2) fp32 are the reference points already multiplied by valid ratios; Nref is 1
  * (ref_batch_stride = 0) or N.  value is addressed by element strides (vs_n, vs_s, vs_m), so both
  * the upstream (N,S,M,D) and the head-major (N,M,S,D) layouts are accepted.  out (N,Lq,M*D) q_dtype.
+ * Limit (all msda entry points): the gather kernels use 32-bit byte offsets and 24-bit pixel arithmetic, so a value map
+ * must span < 4 GiB, S < 2^24 and vs_s * sizeof(element) < 2^24; larger calls return POET_ERR_UNSUPPORTED.
  * Backward: grad_value fp32, same strides as value, accumulated atomically (caller zero-fills);
  * grad_offattn (N,Lq,ldq) q_dtype receives d/d(offsets) and d/d(logits) (softmax backward folded). */
 int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m,
