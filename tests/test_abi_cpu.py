@@ -66,6 +66,18 @@ def test_argument_errors_are_reported_not_thrown(lib):
     assert lib.poet_add(None, None, None, 0, 0, 0, 0, None) < 0
 
 
+def test_msda_rejects_value_maps_beyond_32bit_offsets(lib):
+    """The gather kernels address value maps with 32-bit byte offsets (include/poet_hip.h): a 4 GiB map must be refused
+    with an error code before anything is launched (the pointers are never dereferenced on the host)."""
+    shapes = (ctypes.c_int64 * 2)(2048, 2048)
+    starts = (ctypes.c_int64 * 1)(0)
+    fake = ctypes.c_void_p(0x1000)
+    N, S, M, D = 2, 2048 * 2048, 16, 16                           # 2 * 4M * 256 * 4 B = 8 GiB in fp32
+    rc = lib.poet_msda_fwd(fake, shapes, starts, fake, fake, fake, N, S, M, D, 1, 4, 10, 0, None)
+    assert rc < 0 and b"4 GiB" in lib.poet_hip_last_error()
+    assert lib.poet_msda_fwd(fake, shapes, starts, fake, fake, fake, N, S, M, 12, 1, 4, 10, 0, None) < 0      # head dim not a multiple of 8
+
+
 def test_product_has_no_cpu_path_and_never_imports_the_oracle(lib):
     import poet_amd
     from poet_amd import ops
