@@ -95,6 +95,7 @@ def gemm_flops_per_image(cfg):
 _PMC_NAMES = {"msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_kernel<", "msda_fused_fwd": "msda_fwd_kernel",
               "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws_kernel<", "gemm_stream_fwd": "gemm_ws_kernel<",
               "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
+              "gemm_small_fwd": "gemm_small_kernel<false", "gemm_small_dX": "gemm_small_kernel<true", "gemm_small_dW": "gemm_small_dw_kernel",
               "ln_fwd": "ln_fwd_kernel<bf16", "ln_bwd": "ln_bwd_kernel<bf16"}
 _PMC_FILTER = {"gemm_stream_dX": ", true,", "gemm_stream_fwd": ", false,"}     # ws kernels: W stored [K][N] (dX) or not
 
@@ -288,7 +289,7 @@ def main():
             out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"])
             if out["roofline"]["kernel"].startswith("msda_bwd_dvalue_scatter"):
                 # the contract's two bounds do not name this kernel's real limiter; say so next to the HBM fraction
-                out["roofline"]["limiter"] = "LDS integer atomics (ds_add_u32) + per-query setup, not HBM: DESIGN.md section 5/9"
+                out["roofline"]["limiter"] = "the LDS atomic unit (26 M ds_add_u32 wave-instructions per launch at ~8 clk each), not HBM: DESIGN.md section 5/9"
             out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
                                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         if world == 1 and not args.no_cpu_baseline:

@@ -229,7 +229,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         for extra in (add_src, gate_ref):                     # epilogue operands the kernel also streams
             if extra is not None:
                 nb += batch * M * N * _esz(extra)
-        PROFILE.end("gemm_small" if path == "small" else f"gemm_{path}_{role}", e0, 2.0 * M * N * K * batch, nb)
+        PROFILE.end(f"gemm_{path}_{role}", e0, 2.0 * M * N * K * batch, nb)
         return Cout
     _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
     return Cout
