@@ -114,6 +114,12 @@ def make_inputs(cfg: dict, seed: int = 1234, batch: int | None = None, pad: bool
         rot = np.stack([_rand_rotation(rng) for _ in range(k)]).astype(np.float32)
         targets.append({"boxes": torch.from_numpy(boxes), "labels": torch.from_numpy(labels),
                         "relative_position": torch.from_numpy(pos), "relative_rotation": torch.from_numpy(rot)})
+    # 'jitter' mode (pose_estimation_transformer.py:208-209): the data loader's perturbed copies of the boxes.  Drawn from a
+    # SEPARATE generator after everything else, so the streams of the fields above are what they were before this existed.
+    jr = np.random.default_rng(seed + 7919)
+    for t in targets:
+        b = t["boxes"].numpy()
+        t["jitter_boxes"] = torch.from_numpy(np.clip(b + jr.normal(0.0, 0.02, b.shape), 0.01, 0.99).astype(np.float32))
     return feats, sizes, targets
 
 

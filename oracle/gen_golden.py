@@ -60,7 +60,7 @@ def _install_shims():
     sys.path.insert(0, REF)
 
 
-def _ref_model(cfg, feats, bbox_mode="gt", predictions=None):
+def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specific"):
     """Build the reference's own PoET around a Joiner-like synthetic backbone."""
     import torch.nn as nn
     import torch.nn.functional as F
@@ -96,8 +96,8 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None):
                                enc_n_points=cfg["n_points"])
     model = PoET(Joinerish(), tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
                  n_classes=cfg["n_classes"], bbox_mode=bbox_mode, ref_points_mode="bbox", query_embedding_mode="bbox",
-                 rotation_mode="6d", class_mode="specific", aleatoric=False, aux_loss=True, backbone_type="yolo")
-    crit = SetCriterion(PoseMatcher(bbox_mode="gt", class_mode="specific"), build_weight_dict(cfg["dec_layers"]),
+                 rotation_mode="6d", class_mode=class_mode, aleatoric=False, aux_loss=True, backbone_type="yolo")
+    crit = SetCriterion(PoseMatcher(bbox_mode=bbox_mode, class_mode=class_mode), build_weight_dict(cfg["dec_layers"]),
                         ["translation", "rotation"])
     return model, crit
 
@@ -105,7 +105,7 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None):
 INIT_SEED = 4321
 
 
-def _run_model(name, batch, pad, full, default_init=False):
+def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class_mode="specific"):
     from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples, checksum
     from util.misc import nested_tensor_from_tensor_list
 
@@ -123,7 +123,7 @@ def _run_model(name, batch, pad, full, default_init=False):
         for k, v in model.state_dict().items():
             assert torch.equal(v, osd[k]), f"default init differs at {k}"
     else:
-        model, crit = _ref_model(cfg, feats)
+        model, crit = _ref_model(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode)
         formula_fill(model)
     model.eval()
     crit.eval()
@@ -167,6 +167,8 @@ def _run_model(name, batch, pad, full, default_init=False):
         rec["param_names"] = np.asarray([n for n, _ in model.named_parameters()])
         rec["param_checksums"] = np.stack([checksum(p) for _, p in model.named_parameters()])
     tag = f"{name}_b{batch}{'_pad' if pad else ''}{'_init' if default_init else ''}"
+    if (bbox_mode, class_mode) != ("gt", "specific"):
+        tag += f"_{bbox_mode}_{class_mode}"
     np.savez_compressed(os.path.join(GOLD, f"poet_{tag}.npz"), **rec)
     print("wrote", tag, "loss", float(total))
 
@@ -254,6 +256,10 @@ def main():
         _run_inference("tiny")
         _run_inference("cfg0")
         return
+    if "--modes" in sys.argv:                 # only the jitter / class-agnostic goldens
+        _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
+        _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
+        return
     _small_units()
     _run_model("tiny", 2, True, True)
     _run_model("tiny", 2, False, True)
@@ -264,6 +270,8 @@ def main():
     _run_model("tiny", 2, True, True, default_init=True)
     _run_inference("tiny")
     _run_inference("cfg0")
+    _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
+    _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
     subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", "--hf"], cwd=ROOT)
 
 

@@ -403,7 +403,7 @@ class PoET(nn.Module):
         """pose_estimation_transformer.py:203-239,309-311 ('gt' mode)."""
         boxes_all, cls_all, emb_all, n_boxes = [], [], [], []
         for t in targets:
-            boxes = t["boxes"]
+            boxes = t["jitter_boxes"] if self.bbox_mode == "jitter" else t["boxes"]      # :206-209
             nb = len(boxes)
             n_boxes.append(nb)
             cls = t["labels"]
@@ -496,8 +496,8 @@ class PoET(nn.Module):
 class PoseMatcher(nn.Module):
     def __init__(self, cost_bbox=1.0, cost_class=1.0, bbox_mode="gt"):
         super().__init__()
-        assert bbox_mode == "gt"
-        self.cost_bbox, self.cost_class = cost_bbox, cost_class
+        assert bbox_mode in ("gt", "jitter")
+        self.cost_bbox, self.cost_class, self.bbox_mode = cost_bbox, cost_class, bbox_mode
 
     @torch.no_grad()
     def forward(self, outputs, targets, n_boxes):
@@ -505,7 +505,12 @@ class PoseMatcher(nn.Module):
         bs, nq = outputs["pred_boxes"].shape[:2]
         out_bbox = outputs["pred_boxes"].flatten(0, 1)
         tgt_bbox = torch.cat([t["boxes"] for t in targets])
-        cost = (self.cost_bbox * torch.cdist(out_bbox, tgt_bbox, p=1)).view(bs, nq, -1).cpu()
+        if self.bbox_mode == "gt":          # matcher.py:169-173: L1 between the (identical) boxes
+            cost = (self.cost_bbox * torch.cdist(out_bbox, tgt_bbox, p=1)).view(bs, nq, -1).cpu()
+        else:                               # matcher.py:175-181 ('jitter'): class equality only, 0 = same class
+            out_class = outputs["pred_classes"].flatten(0, 1)
+            tgt_class = torch.cat([t["labels"].type(torch.float32) for t in targets])
+            cost = (self.cost_class * torch.where(out_class[:, None] == tgt_class[None, :], 0.0, 1.0)).view(bs, nq, -1).cpu()
         sizes = [len(t["boxes"]) for t in targets]
         res = []
         for i, c in enumerate(cost.split(sizes, -1)):
@@ -568,12 +573,12 @@ def param_groups(model, lr=2e-4, lr_backbone=2e-5, proj_names=("reference_points
     ]
 
 
-def build_poet(cfg, features, bbox_mode="gt", predictions=None):
+def build_poet(cfg, features, bbox_mode="gt", predictions=None, class_mode="specific"):
     """cfg: dict(d_model, nheads, enc_layers, dec_layers, d_ffn, n_levels, n_points, num_queries,
     n_classes, dropout, strides, num_channels)."""
     bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions)
     tr = DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"],
                                cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"])
-    model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, "specific", True)
-    crit = SetCriterion(PoseMatcher(), build_weight_dict(cfg["dec_layers"]))
+    model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, class_mode, True)
+    crit = SetCriterion(PoseMatcher(bbox_mode="jitter" if bbox_mode == "jitter" else "gt"), build_weight_dict(cfg["dec_layers"]))
     return model, crit

@@ -202,9 +202,9 @@ def announce(tag: str):
 class PoseMatcher(nn.Module):
     def __init__(self, cost_bbox: float = 1, cost_class: float = 1, bbox_mode: str = "gt", class_mode: str = "specific"):
         super().__init__()
-        if bbox_mode != "gt":
-            raise NotImplementedError("PoseMatcher: only bbox_mode='gt' is implemented")
-        self.cost_bbox, self.cost_class = cost_bbox, cost_class
+        if bbox_mode not in ("gt", "jitter"):
+            raise NotImplementedError("PoseMatcher: bbox_mode 'gt' and 'jitter' are implemented ('backbone' matching is evaluation-side)")
+        self.cost_bbox, self.cost_class, self.bbox_mode = cost_bbox, cost_class, bbox_mode
         self._cache = (None, None)
 
     @torch.no_grad()
@@ -220,6 +220,22 @@ class PoseMatcher(nn.Module):
         if tgt_host is None:                             # standalone use: copy now (one transfer; blocks like matcher.py:139 does)
             from .modules import _to_host_list
             tgt_host = _to_host_list([t["boxes"] for t in targets], np.float32)
+        if self.bbox_mode == "jitter":
+            # matcher.py:175-181: the queries carry perturbed boxes, so the match is by class only (cost 0 = same class, 1 =
+            # different); same cost matrix + same SciPy solver as the reference => the same tie-breaking
+            pc, tl = outputs.get("_pred_classes_host"), outputs.get("_tgt_labels_host")
+            if pc is None:
+                pc = outputs["pred_classes"].detach().cpu().numpy()
+            if tl is None:
+                from .modules import _to_host_list
+                tl = _to_host_list([t["labels"] for t in targets], np.int64)
+            res = []
+            for i in range(bs):
+                c = self.cost_class * (np.asarray(pc[i][: n_boxes[i], None]) != np.asarray(tl[i])[None, :]).astype(np.float32)
+                r, cidx = linear_sum_assignment(c)
+                res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
+            self._cache = (pb, res)
+            return res
         res = []
         for i, t in enumerate(targets):
             # L1 cost matrix of matcher.py:60-75 in numpy: the matrices are <= 20 x 20, and a torch CPU op here would wake
@@ -302,7 +318,7 @@ class SetCriterion(nn.Module):
             self.matcher._cache = (None, None)      # the per-call cache must not outlive the call (static buffers are reused)
         aux_list = outputs.get("aux_outputs", [])
         for aux in aux_list:
-            for k in ("_pred_boxes_host", "_tgt_boxes_host"):
+            for k in ("_pred_boxes_host", "_tgt_boxes_host", "_pred_classes_host", "_tgt_labels_host"):
                 if k in outputs:
                     aux[k] = outputs[k]
         dev = outputs["pred_translation"].device

@@ -408,6 +408,7 @@ class PoET(nn.Module):
         cl = _to_host_list([t["labels"] for t in targets], np.int64)
         # the matcher works on the ground-truth boxes: hand it this host copy instead of letting it sync again
         self._tgt_boxes_host = bl if key == "boxes" else _to_host_list([t["boxes"] for t in targets], np.float32)
+        self._tgt_labels_host, self._pred_classes_host = cl, classes       # ('jitter' matching is by class)
         for i, (b, c) in enumerate(zip(bl, cl)):
             nb = len(b)
             if nb > Q:
@@ -443,7 +444,8 @@ class PoET(nn.Module):
             classes[i, :nb] = r[:, 5].astype(np.int64)
             valid[i, :nb] = 1
             n_boxes.append(nb)
-        self._tgt_boxes_host = None
+        self._tgt_boxes_host = self._tgt_labels_host = None
+        self._pred_classes_host = classes
         return boxes, classes, valid, n_boxes
 
     def forward_core(self, feats, feat_masks, image_mask, boxes, valid, classes):
@@ -492,6 +494,8 @@ class PoET(nn.Module):
                                    "pred_classes": pred_classes} for t, r in zip(trans[:-1], rot[:-1])]
         out["_pred_boxes_host"] = boxes_host          # lets the matcher run without a device->host sync
         out["_tgt_boxes_host"] = getattr(self, "_tgt_boxes_host", None)
+        out["_tgt_labels_host"] = getattr(self, "_tgt_labels_host", None)
+        out["_pred_classes_host"] = getattr(self, "_pred_classes_host", None)
         out["_stacked"] = (trans, rot)                # (L, N, Q, 3) / (L, N, Q, 3, 3): lets the criterion take all layers at once
         return out
 

@@ -109,6 +109,38 @@ def test_loss_and_grads_fp32_vs_reference_golden(gpu, golden_dir, name, batch, p
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("bbox_mode,class_mode", [("jitter", "specific"), ("gt", "agnostic")])
+def test_modes_fp32_vs_reference_golden(gpu, golden_dir, bbox_mode, class_mode):
+    """bbox_mode='jitter' (perturbed query boxes, matching by class: matcher.py:175-181) and class_mode='agnostic' (3 / 6-wide
+    heads): poses, losses and gradient checksums of the HIP path against the real reference run in those modes."""
+    g = np.load(os.path.join(golden_dir, f"poet_tiny_b2_pad_{bbox_mode}_{class_mode}.npz"))
+    r = gpu("tiny", 2, True, torch.float32, bbox_mode=bbox_mode, class_mode=class_mode)
+    model, crit = r["model"], r["crit"]
+    model.eval()
+    out, n_boxes = model(r["samples"], r["targets"])
+    real = _real_query_mask(n_boxes, r["cfg"]["num_queries"])
+    dt = (out["pred_translation"].float().cpu() - torch.from_numpy(g["pred_translation"]))[real].abs().max().item()
+    dr = (out["pred_rotation"].float().cpu() - torch.from_numpy(g["pred_rotation"]))[real].abs().max().item()
+    assert dt < 1e-3 and dr < 1e-3, (dt, dr)
+    losses = crit(out, r["targets"], n_boxes)
+    names = sorted(losses)
+    assert names == [str(x) for x in g["loss_names"]]
+    np.testing.assert_allclose([float(losses[k]) for k in names], g["loss_values"], rtol=2e-4, atol=2e-5)
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    model.zero_grad()
+    total.backward()
+    params = dict(model.named_parameters())
+    bad = []
+    for n, ref in zip(g["grad_names"], g["grad_checksums"]):
+        p = params[str(n)]
+        if np.isnan(ref).all():
+            continue
+        got = checksum(p.grad.cpu())
+        if not np.allclose(got, ref, atol=3e-3 * max(1.0, abs(ref[0]))):
+            bad.append((str(n), float(np.abs(got - ref).max()), float(ref[0])))
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("init", [False, True])
 def test_full_size_ycbv_checksums(gpu, golden_dir, init):
     """BASELINE configs[1] geometry (5/5/16h, 4 levels, 640x480, Q=20) at bs=1 against the reference's golden:

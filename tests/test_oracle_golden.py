@@ -116,3 +116,24 @@ def test_oracle_inference_path_matches_reference(golden_dir, name):
     np.testing.assert_allclose(o["out"]["pred_rotation"].numpy(), g["pred_rotation"], rtol=1e-5, atol=1e-6)
     if o["out"]["aux_outputs"]:                         # (cfg0 has a single decoder layer: no auxiliary outputs)
         np.testing.assert_allclose(np.stack([a["pred_rotation"].numpy() for a in o["out"]["aux_outputs"]]), g["aux_rotation"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("bbox_mode,class_mode", [("jitter", "specific"), ("gt", "agnostic")])
+def test_poet_modes_vs_reference(golden_dir, bbox_mode, class_mode):
+    """bbox_mode='jitter' (queries from the perturbed boxes, matching by class equality: pose_estimation_transformer.py:
+    208-209, matcher.py:175-181) and class_mode='agnostic' (3 / 6-wide heads, no per-class gather: :85-96,365): outputs,
+    losses and gradient checksums of the oracle equal the real reference's."""
+    g = _load(golden_dir, f"poet_tiny_b2_pad_{bbox_mode}_{class_mode}.npz")
+    r = run_oracle("tiny", 2, True, bbox_mode=bbox_mode, class_mode=class_mode)
+    np.testing.assert_allclose(r["out"]["pred_translation"].detach().numpy(), g["pred_translation"], rtol=1e-5, atol=ATOL)
+    np.testing.assert_allclose(r["out"]["pred_rotation"].detach().numpy(), g["pred_rotation"], rtol=1e-5, atol=ATOL)
+    names = sorted(r["losses"])
+    assert names == list(g["loss_names"])
+    np.testing.assert_allclose([float(r["losses"][k]) for k in names], g["loss_values"], rtol=1e-5, atol=1e-6)
+    grads = dict(r["model"].named_parameters())
+    for n, cs in zip(g["grad_names"], g["grad_checksums"]):
+        p = grads[str(n)]
+        if np.isnan(cs[0]):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+        else:
+            np.testing.assert_allclose(checksum(p.grad), cs, rtol=2e-4, atol=2e-6, err_msg=str(n))
