@@ -132,6 +132,48 @@ def build_model(cfg, feats, precision, device):
     return model, crit
 
 
+def synth_detections(cfg, batch, seed):
+    """Detector rows (x0, y0, x1, y1, score, class) in pixels for the inference mode: 3..Q per image, as synth_batch's boxes."""
+    rng = np.random.default_rng(seed)
+    ih, iw = cfg["image_hw"]
+    preds = []
+    for _ in range(batch):
+        k = int(rng.integers(3, cfg["num_queries"] + 1))
+        cx, cy = rng.uniform(0.2, 0.8, k) * iw, rng.uniform(0.2, 0.8, k) * ih
+        w, h = rng.uniform(0.05, 0.25, k) * iw, rng.uniform(0.05, 0.25, k) * ih
+        rows = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, rng.uniform(0.1, 1.0, k), rng.integers(1, cfg["n_classes"] + 1, k)], 1)
+        preds.append(torch.from_numpy(rows.astype(np.float32)))
+    return preds
+
+
+def run_inference(args, cfg, device):
+    """`--infer`: forward-only rate of the inference path (bbox_mode='backbone', eval, HIP-graph replay).  A secondary
+    number; the default run and the driver's contract are the training metric."""
+    import poet_amd
+    batch = args.batch or 1
+    feats, _ = synth_batch(cfg, batch, 1234, device)
+    model, _ = build_model(cfg, feats, args.precision, device)
+    model.bbox_mode = "backbone"
+    model.backbone.predictions = synth_detections(cfg, batch, 99)
+    runner = model.eval() if args.no_graphs else poet_amd.GraphedInference(model, warm=1)
+    ih, iw = cfg["image_hw"]
+    samples = poet_amd.NestedTensor(None, torch.zeros((batch, ih, iw), dtype=torch.bool, device=device))
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 3)):
+            runner(samples)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, _ = runner(samples)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"metric": "images/sec inference (forward only, queries from detector rows)", "value": round(batch / dt, 1),
+                      "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(dt * 1e3, 3),
+                      "higher_is_better": True, "dtype": args.precision, "data": "synthetic",
+                      "config": {"workload": f"{args.config}: inference, bs={batch}, {'eager' if args.no_graphs else 'HIP graph'}"},
+                      "finite": bool(torch.isfinite(out["pred_translation"]).all())}), flush=True)
+
+
 def usable_cores():
     """Cores this process may actually use: the cgroup CPU quota when there is one (threads beyond it only get the whole
     process descheduled for the rest of each 100 ms period), else the visible CPU count."""
@@ -197,6 +239,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel from Python instead of replaying HIP graphs")
+    ap.add_argument("--infer", action="store_true", help="secondary number: forward-only rate of the inference path (1 GPU; --batch, default 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,6 +257,8 @@ def main():
     import poet_amd
     from poet_amd import ops
     cfg = CONFIGS[args.config]
+    if args.infer:
+        return run_inference(args, cfg, device)
     batch = args.batch or cfg["batch"]
     torch.manual_seed(1234)                                      # identical init on every rank (then broadcast anyway)
     poet_amd.manual_seed(1234 + rank)

@@ -439,6 +439,26 @@ def test_inference_path_vs_reference_golden(gpu, golden_dir, name, precision, to
     assert dt < tol_t and dr < tol_r, (dt, dr)
 
 
+def test_graphed_inference_matches_eager(gpu):
+    """HIP-graph replay of the inference forward == the eager launch sequence, across calls whose detections change."""
+    import poet_amd
+    from oracle.formula import CONFIGS, make_predictions
+    cfg = CONFIGS["tiny"]
+    r = gpu("tiny", 3, False, "bf16", bbox_mode="backbone", predictions=make_predictions(cfg, seed=77, batch=3))
+    model = r["model"].eval()
+    runner = poet_amd.GraphedInference(model, warm=1)
+    for seed in (77, 78, 79, 80):
+        model.backbone.predictions = [None if p is None else p.cuda() for p in make_predictions(cfg, seed=seed, batch=3)]
+        with torch.no_grad():
+            ref, nb_ref = model(r["samples"])
+            ref_t, ref_r = ref["pred_translation"].clone(), ref["pred_rotation"].clone()
+            out, nb = runner(r["samples"])
+        assert list(nb) == list(nb_ref)
+        assert torch.equal(out["pred_boxes"], ref["pred_boxes"]) and torch.equal(out["pred_classes"], ref["pred_classes"])
+        assert torch.equal(out["pred_translation"], ref_t) and torch.equal(out["pred_rotation"], ref_r)
+    assert runner.ready
+
+
 def test_images_without_objects(gpu):
     """Ragged and empty targets (the reference pads the query set per image and clamps the box count to >= 1,
     pose_estimation_transformer.py:604-606): one image without objects == the oracle's loss; a batch with no objects at all
