@@ -118,9 +118,33 @@ def make_inputs(cfg: dict, seed: int = 1234, batch: int | None = None, pad: bool
     # SEPARATE generator after everything else, so the streams of the fields above are what they were before this existed.
     jr = np.random.default_rng(seed + 7919)
     for t in targets:
+        t["relative_quaternions"] = torch.from_numpy(_quat_wxyz(t["relative_rotation"].numpy()))
         b = t["boxes"].numpy()
         t["jitter_boxes"] = torch.from_numpy(np.clip(b + jr.normal(0.0, 0.02, b.shape), 0.01, 0.99).astype(np.float32))
     return feats, sizes, targets
+
+
+def _quat_wxyz(R: np.ndarray) -> np.ndarray:
+    """Unit quaternions [w, x, y, z] of rotation matrices (n,3,3): the data loader's `relative_quaternions`.  Branch on
+    the largest of (trace, R00, R11, R22) for numerical safety; sign fixed to w >= 0."""
+    out = np.zeros((len(R), 4), np.float64)
+    for i, m in enumerate(R.astype(np.float64)):
+        tr = m[0, 0] + m[1, 1] + m[2, 2]
+        if tr > 0:
+            s = np.sqrt(tr + 1.0) * 2
+            q = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
+        elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+            s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+            q = [(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s]
+        elif m[1, 1] > m[2, 2]:
+            s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+            q = [(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s]
+        else:
+            s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+            q = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
+        q = np.asarray(q)
+        out[i] = q if q[0] >= 0 else -q
+    return out.astype(np.float32)
 
 
 def make_predictions(cfg: dict, seed: int = 77, batch: int = 3):

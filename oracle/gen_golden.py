@@ -60,7 +60,7 @@ def _install_shims():
     sys.path.insert(0, REF)
 
 
-def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specific"):
+def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False):
     """Build the reference's own PoET around a Joiner-like synthetic backbone."""
     import torch.nn as nn
     import torch.nn.functional as F
@@ -69,7 +69,7 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specifi
     from models.matcher import PoseMatcher
     from models.position_encoding import PositionEmbeddingSine
     from util.misc import NestedTensor
-    from oracle.poet_ref import build_weight_dict
+    from oracle.poet_ref import build_weight_dict, losses_for
 
     class Joinerish(nn.Module):
         def __init__(self):
@@ -96,16 +96,16 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specifi
                                enc_n_points=cfg["n_points"])
     model = PoET(Joinerish(), tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
                  n_classes=cfg["n_classes"], bbox_mode=bbox_mode, ref_points_mode="bbox", query_embedding_mode="bbox",
-                 rotation_mode="6d", class_mode=class_mode, aleatoric=False, aux_loss=True, backbone_type="yolo")
+                 rotation_mode=rotation_mode, class_mode=class_mode, aleatoric=aleatoric, aux_loss=True, backbone_type="yolo")
     crit = SetCriterion(PoseMatcher(bbox_mode=bbox_mode, class_mode=class_mode), build_weight_dict(cfg["dec_layers"]),
-                        ["translation", "rotation"])
+                        list(losses_for(rotation_mode, aleatoric)))
     return model, crit
 
 
 INIT_SEED = 4321
 
 
-def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class_mode="specific"):
+def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class_mode="specific", rotation_mode="6d", aleatoric=False):
     from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples, checksum
     from util.misc import nested_tensor_from_tensor_list
 
@@ -123,7 +123,7 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
         for k, v in model.state_dict().items():
             assert torch.equal(v, osd[k]), f"default init differs at {k}"
     else:
-        model, crit = _ref_model(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode)
+        model, crit = _ref_model(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode, rotation_mode=rotation_mode, aleatoric=aleatoric)
         formula_fill(model)
     model.eval()
     crit.eval()
@@ -169,6 +169,12 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
     tag = f"{name}_b{batch}{'_pad' if pad else ''}{'_init' if default_init else ''}"
     if (bbox_mode, class_mode) != ("gt", "specific"):
         tag += f"_{bbox_mode}_{class_mode}"
+    if rotation_mode != "6d" or aleatoric:
+        tag += f"_{rotation_mode}{'_aleatoric' if aleatoric else ''}"
+        if aleatoric:
+            rec["aux_translation_aleatoric"] = np.stack([a["pred_translation_aleatoric"].detach().numpy() for a in out["aux_outputs"]])
+            rec["pred_translation_aleatoric"] = out["pred_translation_aleatoric"].detach().numpy()
+            rec["pred_rotation_aleatoric"] = out["pred_rotation_aleatoric"].detach().numpy()
     np.savez_compressed(os.path.join(GOLD, f"poet_{tag}.npz"), **rec)
     print("wrote", tag, "loss", float(total))
 
@@ -256,6 +262,10 @@ def main():
         _run_inference("tiny")
         _run_inference("cfg0")
         return
+    if "--rot" in sys.argv:                   # only the quaternion / aleatoric goldens
+        for rm, al in (("quat", False), ("silho_quat", False), ("6d", True)):
+            _run_model("tiny", 2, True, True, rotation_mode=rm, aleatoric=al)
+        return
     if "--modes" in sys.argv:                 # only the jitter / class-agnostic goldens
         _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
         _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
@@ -272,6 +282,8 @@ def main():
     _run_inference("cfg0")
     _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
     _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
+    for rm, al in (("quat", False), ("silho_quat", False), ("6d", True)):
+        _run_model("tiny", 2, True, True, rotation_mode=rm, aleatoric=al)
     subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", "--hf"], cwd=ROOT)
 
 

@@ -370,18 +370,24 @@ class SyntheticBackbone(nn.Module):
 
 class PoET(nn.Module):
     def __init__(self, backbone, transformer, num_queries, num_feature_levels, n_classes,
-                 bbox_mode="gt", class_mode="specific", aux_loss=True):
+                 bbox_mode="gt", class_mode="specific", aux_loss=True, rotation_mode="6d", aleatoric=False):
         super().__init__()
         self.transformer, self.backbone = transformer, backbone
         d = transformer.d_model
         self.hidden_dim, self.n_queries, self.n_classes = d, num_queries, n_classes + 1
         self.bbox_mode, self.class_mode, self.aux_loss = bbox_mode, class_mode, aux_loss
+        self.rotation_mode, self.aleatoric = rotation_mode, aleatoric
+        assert rotation_mode in ("6d", "quat", "silho_quat") and not (aleatoric and rotation_mode != "6d")      # :72-82
+        rot_dim = 6 if rotation_mode == "6d" else 4
         self.num_feature_levels = num_feature_levels
         mult = self.n_classes if class_mode == "specific" else 1
         n_pred = transformer.decoder.num_layers
         # construction order (and hence RNG consumption) as pose_estimation_transformer.py:85-144
         self.translation_head = t_head = MLP(d, d, 3 * mult, 3)    # registered first, replaced by the ModuleList below
-        self.rotation_head = r_head = MLP(d, d, 6 * mult, 3)       # (keeps the reference's parameter order)
+        self.rotation_head = r_head = MLP(d, d, rot_dim * mult, 3) # (keeps the reference's parameter order)
+        if aleatoric:                                              # :88-90,95-96: log-variances, 3 per head
+            self.translation_head_aleatoric = ta_head = MLP(d, d, 3 * mult, 3)
+            self.rotation_head_aleatoric = ra_head = MLP(d, d, 3 * mult, 3)
         projs = []
         n_bb = len(backbone.strides)
         cin = None
@@ -397,6 +403,9 @@ class PoET(nn.Module):
             nn.init.constant_(proj[0].bias, 0)
         self.translation_head = nn.ModuleList([copy.deepcopy(t_head) for _ in range(n_pred)])
         self.rotation_head = nn.ModuleList([copy.deepcopy(r_head) for _ in range(n_pred)])
+        if aleatoric:
+            self.translation_head_aleatoric = nn.ModuleList([copy.deepcopy(ta_head) for _ in range(n_pred)])
+            self.rotation_head_aleatoric = nn.ModuleList([copy.deepcopy(ra_head) for _ in range(n_pred)])
         self.bbox_embedding = BoundingBoxEmbeddingSine(num_pos_feats=d / 8)
 
     def assemble_queries(self, targets):
@@ -472,21 +481,28 @@ class PoET(nn.Module):
         bs = pred_classes.shape[0]
         idx = torch.where(pred_classes > 0, pred_classes, 0).view(-1).long()
         rows = torch.arange(bs * self.n_queries)
-        rots, trans = [], []
+        def pick(x):                                    # :365-374: per query the slice of its class
+            return x.view(bs * self.n_queries, self.n_classes, -1)[rows, idx].view(bs, self.n_queries, -1) if self.class_mode == "specific" else x
+
+        rots, trans, rots_a, trans_a = [], [], [], []
         for lvl in range(hs.shape[0]):
-            r = self.rotation_head[lvl](hs[lvl])
-            t = self.translation_head[lvl](hs[lvl])
-            if self.class_mode == "specific":
-                r = r.view(bs * self.n_queries, self.n_classes, -1)[rows, idx].view(bs, self.n_queries, -1)
-                t = t.view(bs * self.n_queries, self.n_classes, -1)[rows, idx].view(bs, self.n_queries, -1)
-            rots.append(rotation_6d_to_matrix(r))
-            trans.append(t)
+            r = pick(self.rotation_head[lvl](hs[lvl]))
+            trans.append(pick(self.translation_head[lvl](hs[lvl])))
+            rots.append(rotation_6d_to_matrix(r) if self.rotation_mode == "6d" else F.normalize(r, p=2, dim=2))      # :420-432
+            if self.aleatoric:
+                rots_a.append(pick(self.rotation_head_aleatoric[lvl](hs[lvl])))
+                trans_a.append(pick(self.translation_head_aleatoric[lvl](hs[lvl])))
         rots, trans = torch.stack(rots), torch.stack(trans)
         out = {"pred_translation": trans[-1], "pred_rotation": rots[-1],
                "pred_boxes": pred_boxes, "pred_classes": pred_classes}
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_translation": t, "pred_rotation": r, "pred_boxes": pred_boxes,
                                    "pred_classes": pred_classes} for t, r in zip(trans[:-1], rots[:-1])]
+        if self.aleatoric:                              # :402-411
+            out["pred_translation_aleatoric"], out["pred_rotation_aleatoric"] = trans_a[-1], rots_a[-1]
+            if self.aux_loss:
+                for a, aux in enumerate(out["aux_outputs"]):
+                    aux["pred_translation_aleatoric"], aux["pred_rotation_aleatoric"] = trans_a[a], rots_a[a]
         return out, n_boxes
 
 
@@ -519,10 +535,36 @@ class PoseMatcher(nn.Module):
         return res
 
 
+def acos_linear_extrapolation(x, lo, hi):
+    """util/rotation_utils.py:13-67: acos inside (lo, hi), first-order Taylor continuation outside."""
+    out = torch.empty_like(x)
+    up, low = x >= hi, x <= lo
+    mid = ~up & ~low
+    out[mid] = torch.acos(x[mid])
+    for m, b in ((up, hi), (low, lo)):
+        out[m] = math.acos(b) - (x[m] - b) / math.sqrt(1.0 - b * b)
+    return out
+
+
+def so3_log_map(R, eps=1e-4, cos_bound=1e-4):
+    """util/rotation_utils.py:150-192,244-316: rotation matrices (n,3,3) -> rotation vectors (n,3)."""
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    if ((tr < -1.0 - eps) | (tr > 3.0 + eps)).any():
+        raise ValueError("A matrix has trace outside valid range [-1-eps,3+eps].")
+    phi = acos_linear_extrapolation((tr - 1.0) * 0.5, -(1.0 - cos_bound), 1.0 - cos_bound)
+    sin = torch.sin(phi)
+    fac = torch.empty_like(phi)
+    ok = sin.abs() > 0.5 * eps
+    fac[~ok] = 0.5 + (phi[~ok] ** 2) * (1.0 / 12)
+    fac[ok] = phi[ok] / (2.0 * sin[ok])
+    A = fac[:, None, None] * (R - R.permute(0, 2, 1))
+    return torch.stack((A[:, 2, 1], A[:, 0, 2], A[:, 1, 0]), dim=1)
+
+
 class SetCriterion(nn.Module):
-    def __init__(self, matcher, weight_dict):
+    def __init__(self, matcher, weight_dict, losses=("translation", "rotation")):
         super().__init__()
-        self.matcher, self.weight_dict = matcher, weight_dict
+        self.matcher, self.weight_dict, self.losses = matcher, weight_dict, tuple(losses)
 
     @staticmethod
     def _src_idx(indices):
@@ -531,18 +573,35 @@ class SetCriterion(nn.Module):
         return b, s
 
     def _losses(self, outputs, targets, indices):
+        """pose_estimation_transformer.py:472-609, one entry of `self.losses` per term."""
         idx = self._src_idx(indices)
-        st = outputs["pred_translation"][idx]
-        tt = torch.cat([t["relative_position"][j] for t, (_, j) in zip(targets, indices)], 0)
+        gather = lambda key: torch.cat([t[key][j] for t, (_, j) in zip(targets, indices)], 0)
+        st, tt = outputs["pred_translation"][idx], gather("relative_position")
         n_obj = len(tt)
-        loss_t = torch.sqrt(((st - tt) ** 2).sum(1)).sum() / n_obj
-        sr = outputs["pred_rotation"][idx]
-        tr = torch.cat([t["relative_rotation"][j] for t, (_, j) in zip(targets, indices)], 0)
-        prod = torch.bmm(sr, tr.transpose(1, 2))
-        trace = prod[:, torch.eye(3).bool()].sum(1)
-        theta = torch.clamp(0.5 * (trace - 1), -1 + 1e-6, 1 - 1e-6)
-        loss_r = torch.acos(theta).sum() / n_obj
-        return {"loss_trans": loss_t, "loss_rot": loss_r}
+        res = {}
+        for name in self.losses:
+            if name == "translation":
+                res["loss_trans"] = torch.sqrt(((st - tt) ** 2).sum(1)).sum() / n_obj
+            elif name == "aleatoric_translation":        # s = log(sigma^2) per axis
+                sa = outputs["pred_translation_aleatoric"][idx]
+                res["loss_trans"] = ((torch.exp(-sa) * torch.square(tt - st)).sum(1) + sa.sum(1)).sum() / (2 * n_obj)
+            elif name in ("rotation", "aleatoric_rotation"):
+                sr, tr = outputs["pred_rotation"][idx], gather("relative_rotation")
+                prod = torch.bmm(sr, tr.transpose(1, 2))
+                if name == "rotation":
+                    trace = prod[:, torch.eye(3).bool()].sum(1)
+                    theta = torch.clamp(0.5 * (trace - 1), -1 + 1e-6, 1 - 1e-6)
+                    res["loss_rot"] = torch.acos(theta).sum() / n_obj
+                else:
+                    sa = outputs["pred_rotation_aleatoric"][idx]
+                    res["loss_rot"] = ((torch.exp(-sa) * torch.square(so3_log_map(prod))).sum(1) + sa.sum(1)).sum() / (2 * n_obj)
+            elif name in ("quaternion", "silho_quaternion"):   # [w, x, y, z]; eps 1e-4
+                dp = (outputs["pred_rotation"][idx] * gather("relative_quaternions")).sum(1)
+                lq = -torch.log(torch.square(dp) + 1e-4) if name == "quaternion" else torch.log(1 - torch.abs(dp) + 1e-4)
+                res["loss_rot"] = lq.sum() / n_obj
+            else:
+                raise ValueError(name)
+        return res
 
     def forward(self, outputs, targets, n_boxes):
         main = {k: v for k, v in outputs.items() if k != "aux_outputs"}
@@ -551,6 +610,13 @@ class SetCriterion(nn.Module):
             part = self._losses(aux, targets, self.matcher(aux, targets, n_boxes))
             losses.update({f"{k}_{i}": v for k, v in part.items()})
         return losses
+
+
+def losses_for(rotation_mode="6d", aleatoric=False):
+    """main.py's choice of loss terms for a rotation representation / the aleatoric extension."""
+    if aleatoric:
+        return ("aleatoric_translation", "aleatoric_rotation")
+    return ("translation", {"6d": "rotation", "quat": "quaternion", "silho_quat": "silho_quaternion"}[rotation_mode])
 
 
 def build_weight_dict(dec_layers, t_coef=1.0, r_coef=1.0, aux=True):
@@ -573,12 +639,14 @@ def param_groups(model, lr=2e-4, lr_backbone=2e-5, proj_names=("reference_points
     ]
 
 
-def build_poet(cfg, features, bbox_mode="gt", predictions=None, class_mode="specific"):
+def build_poet(cfg, features, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False):
     """cfg: dict(d_model, nheads, enc_layers, dec_layers, d_ffn, n_levels, n_points, num_queries,
     n_classes, dropout, strides, num_channels)."""
     bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions)
     tr = DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"],
                                cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"])
-    model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, class_mode, True)
-    crit = SetCriterion(PoseMatcher(bbox_mode="jitter" if bbox_mode == "jitter" else "gt"), build_weight_dict(cfg["dec_layers"]))
+    model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, class_mode, True,
+                 rotation_mode=rotation_mode, aleatoric=aleatoric)
+    crit = SetCriterion(PoseMatcher(bbox_mode="jitter" if bbox_mode == "jitter" else "gt"), build_weight_dict(cfg["dec_layers"]),
+                        losses_for(rotation_mode, aleatoric))
     return model, crit

@@ -9,12 +9,13 @@ from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples
 INIT_SEED = 4321      # oracle/gen_golden.py: seed of the reference's own default initialisation
 
 
-def run_oracle(name, batch, pad, seed=1234, backward=True, train=False, default_init=False, bbox_mode="gt", class_mode="specific"):
+def run_oracle(name, batch, pad, seed=1234, backward=True, train=False, default_init=False, bbox_mode="gt", class_mode="specific",
+               rotation_mode="6d", aleatoric=False):
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
     if default_init:
         torch.manual_seed(INIT_SEED)
-    model, crit = poet_ref.build_poet(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode)
+    model, crit = poet_ref.build_poet(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode, rotation_mode=rotation_mode, aleatoric=aleatoric)
     if not default_init:
         formula_fill(model)
     model.train(train)

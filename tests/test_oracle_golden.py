@@ -137,3 +137,29 @@ def test_poet_modes_vs_reference(golden_dir, bbox_mode, class_mode):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0
         else:
             np.testing.assert_allclose(checksum(p.grad), cs, rtol=2e-4, atol=2e-6, err_msg=str(n))
+
+
+@pytest.mark.parametrize("rotation_mode,aleatoric", [("quat", False), ("silho_quat", False), ("6d", True)])
+def test_poet_rotation_modes_vs_reference(golden_dir, rotation_mode, aleatoric):
+    """Quaternion representations (4-wide rotation heads, L2-normalised; losses -log(<q,q*>^2 + eps) and log(1 - |<q,q*>| + eps),
+    pose_estimation_transformer.py:420-432,564-609) and the aleatoric extension (two more heads predicting log-variances, Gaussian
+    losses with the so(3) log map, :490-513,536-562): outputs, losses and gradient checksums equal the real reference's."""
+    g = _load(golden_dir, f"poet_tiny_b2_pad_{rotation_mode}{'_aleatoric' if aleatoric else ''}.npz")
+    r = run_oracle("tiny", 2, True, rotation_mode=rotation_mode, aleatoric=aleatoric)
+    np.testing.assert_allclose(r["out"]["pred_translation"].detach().numpy(), g["pred_translation"], rtol=1e-5, atol=ATOL)
+    np.testing.assert_allclose(r["out"]["pred_rotation"].detach().numpy(), g["pred_rotation"], rtol=1e-5, atol=ATOL)
+    assert r["out"]["pred_rotation"].shape[-1] == (3 if rotation_mode == "6d" else 4)
+    if aleatoric:
+        np.testing.assert_allclose(r["out"]["pred_rotation_aleatoric"].detach().numpy(), g["pred_rotation_aleatoric"], rtol=1e-5, atol=ATOL)
+        np.testing.assert_allclose(r["out"]["pred_translation_aleatoric"].detach().numpy(), g["pred_translation_aleatoric"], rtol=1e-5, atol=ATOL)
+    names = sorted(r["losses"])
+    assert names == list(g["loss_names"])
+    np.testing.assert_allclose([float(r["losses"][k]) for k in names], g["loss_values"], rtol=1e-5, atol=1e-6)
+    grads = dict(r["model"].named_parameters())
+    assert sorted(grads) == sorted(str(n) for n in g["grad_names"])
+    for n, cs in zip(g["grad_names"], g["grad_checksums"]):
+        p = grads[str(n)]
+        if np.isnan(cs[0]):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+        else:
+            np.testing.assert_allclose(checksum(p.grad), cs, rtol=2e-4, atol=2e-6 * max(1.0, abs(cs[0])), err_msg=str(n))
