@@ -10,7 +10,7 @@ from .modules import (BoundingBoxEmbeddingSine, DeformableTransformer, Deformabl
                       DeformableTransformerDecoderLayer, DeformableTransformerEncoder,
                       DeformableTransformerEncoderLayer, MLP, MSDeformAttn, NestedTensor, PoET,
                       PositionEmbeddingSine)
-from .engine import (BucketReducer, GraphedTrainer, GraphedInference, ParamArena, PoseMatcher, SetCriterion, Trainer,  # noqa: F401
+from .engine import (BucketReducer, losses_for, GraphedTrainer, GraphedInference, ParamArena, PoseMatcher, SetCriterion, Trainer,  # noqa: F401
                      build_weight_dict, reduce_dict)
 from .blocks import manual_seed  # noqa: F401
 

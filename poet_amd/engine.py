@@ -272,12 +272,51 @@ class _PinnedRing:
         return out
 
 
+def acos_linear_extrapolation(x, lo, hi):
+    """util/rotation_utils.py:13-67: acos inside (lo, hi), first-order Taylor continuation outside."""
+    out = torch.empty_like(x)
+    up, low = x >= hi, x <= lo
+    mid = ~up & ~low
+    out[mid] = torch.acos(x[mid])
+    for m, b in ((up, hi), (low, lo)):
+        out[m] = math.acos(b) - (x[m] - b) / math.sqrt(1.0 - b * b)
+    return out
+
+
+def so3_log_map(R, eps=1e-4, cos_bound=1e-4):
+    """util/rotation_utils.py:150-192,244-316: rotation matrices (n,3,3) -> rotation vectors (n,3).  Used by the aleatoric
+    rotation loss only (a few hundred matrices; the masked assignments synchronise with the host, as the reference's do)."""
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    if bool(((tr < -1.0 - eps) | (tr > 3.0 + eps)).any()):
+        raise ValueError("A matrix has trace outside valid range [-1-eps,3+eps].")
+    phi = acos_linear_extrapolation((tr - 1.0) * 0.5, -(1.0 - cos_bound), 1.0 - cos_bound)
+    sin = torch.sin(phi)
+    fac = torch.empty_like(phi)
+    ok = sin.abs() > 0.5 * eps
+    fac[~ok] = 0.5 + (phi[~ok] ** 2) * (1.0 / 12)
+    fac[ok] = phi[ok] / (2.0 * sin[ok])
+    A = fac[:, None, None] * (R - R.permute(0, 2, 1))
+    return torch.stack((A[:, 2, 1], A[:, 0, 2], A[:, 1, 0]), dim=1)
+
+
+LOSS_TERMS = ("translation", "rotation", "quaternion", "silho_quaternion", "aleatoric_translation", "aleatoric_rotation")
+
+
+def losses_for(rotation_mode="6d", aleatoric=False):
+    """The reference's loss terms for a rotation representation / the aleatoric extension (main.py's --translation_loss /
+    --rotation_loss choices)."""
+    if aleatoric:
+        return ("aleatoric_translation", "aleatoric_rotation")
+    return ("translation", {"6d": "rotation", "quat": "quaternion", "silho_quat": "silho_quaternion"}[rotation_mode])
+
+
 class SetCriterion(nn.Module):
     def __init__(self, matcher, weight_dict, losses=("translation", "rotation")):
         super().__init__()
-        if tuple(losses) != ("translation", "rotation"):
-            raise NotImplementedError("only the translation + rotation (6d) losses are implemented")
+        if any(l not in LOSS_TERMS for l in losses):
+            raise NotImplementedError(f"losses {tuple(losses)}: known terms are {LOSS_TERMS}")
         self.matcher, self.weight_dict, self.losses = matcher, weight_dict, list(losses)
+        self.default_terms = tuple(losses) == ("translation", "rotation")       # the pair the fused loss kernel computes
 
     def _gather_targets(self, targets, indices, device):
         """(batch idx, query idx, matched target translation, matched target rotation) for pose_estimation_transformer.py:
@@ -299,18 +338,36 @@ class SetCriterion(nn.Module):
                 self._ring = _PinnedRing()
             idx = self._ring.stage(packed, device)
         gi = idx[2].to(pos.device) if pos.device != idx.device else idx[2]
-        return idx[0], idx[1], pos[gi].to(device), rot[gi].to(device)
+        return idx[0], idx[1], pos[gi].to(device), rot[gi].to(device), idx[2], targets
 
     def _losses(self, outputs, gathered):
-        b, s, tt, tr = gathered
+        """pose_estimation_transformer.py:472-609, one entry of self.losses per term (the default pair normally takes the
+        fused kernel in forward(); this is the general form)."""
+        b, s, tt, tr, gi, targets = gathered
         n_obj = len(tt)
         st = outputs["pred_translation"][b, s]
-        loss_t = torch.sqrt(((st - tt) ** 2).sum(1)).sum() / n_obj
-        sr = outputs["pred_rotation"][b, s]
-        prod = torch.bmm(sr, tr.transpose(1, 2))
-        trace = prod.diagonal(dim1=1, dim2=2).sum(1)
-        theta = torch.clamp(0.5 * (trace - 1), -1 + 1e-6, 1 - 1e-6)
-        return {"loss_trans": loss_t, "loss_rot": torch.acos(theta).sum() / n_obj}
+        res = {}
+        for name in self.losses:
+            if name == "translation":
+                res["loss_trans"] = torch.sqrt(((st - tt) ** 2).sum(1)).sum() / n_obj
+            elif name == "aleatoric_translation":
+                sa = outputs["pred_translation_aleatoric"][b, s]
+                res["loss_trans"] = ((torch.exp(-sa) * torch.square(tt - st)).sum(1) + sa.sum(1)).sum() / (2 * n_obj)
+            elif name in ("rotation", "aleatoric_rotation"):
+                prod = torch.bmm(outputs["pred_rotation"][b, s], tr.transpose(1, 2))
+                if name == "rotation":
+                    trace = prod.diagonal(dim1=1, dim2=2).sum(1)
+                    res["loss_rot"] = torch.acos(torch.clamp(0.5 * (trace - 1), -1 + 1e-6, 1 - 1e-6)).sum() / n_obj
+                else:
+                    sa = outputs["pred_rotation_aleatoric"][b, s]
+                    res["loss_rot"] = ((torch.exp(-sa) * torch.square(so3_log_map(prod))).sum(1) + sa.sum(1)).sum() / (2 * n_obj)
+            else:                                   # quaternion terms, [w, x, y, z], eps 1e-4
+                tq = torch.cat([t["relative_quaternions"] for t in targets], 0)
+                tq = tq[gi.to(tq.device)].to(st.device)
+                dp = (outputs["pred_rotation"][b, s] * tq).sum(1)
+                lq = -torch.log(torch.square(dp) + 1e-4) if name == "quaternion" else torch.log(1 - torch.abs(dp) + 1e-4)
+                res["loss_rot"] = lq.sum() / n_obj
+        return res
 
     def forward(self, outputs, targets, n_boxes):
         main = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
@@ -324,10 +381,10 @@ class SetCriterion(nn.Module):
         dev = outputs["pred_translation"].device
         indices = self.matcher(main, targets, n_boxes)
         all_idx = [indices] + [self.matcher(aux, targets, n_boxes) for aux in aux_list]
-        if all(ix is indices for ix in all_idx[1:]):
+        if self.default_terms and all(ix is indices for ix in all_idx[1:]):
             # 'gt' mode: every decoder layer gets the same assignment (same boxes), so the per-layer losses of
             # pose_estimation_transformer.py:635-674 are evaluated in ONE batched pass -- same values, ~10x fewer launches
-            b, s, tt, tr = self._gather_targets(targets, indices, dev)
+            b, s, tt, tr = self._gather_targets(targets, indices, dev)[:4]
             n_obj = len(tt)
             stacked = outputs.get("_stacked")
             if stacked is not None and dev.type == "cuda" and stacked[0].shape[0] == len(aux_list) + 1:
@@ -509,6 +566,9 @@ class GraphedTrainer(Trainer):
         # the base class broadcasts the parameters and owns the bucket reducer used by the EAGER warm-up steps (without it
         # the ranks would drift apart before the graphs are captured); the captured steps all-reduce the whole arena
         # themselves (see _Replay.backward) and run with the reducer detached
+        if getattr(model, "rotation_mode", "6d") != "6d" or getattr(model, "aleatoric", False) or not getattr(criterion, "default_terms", True):
+            raise NotImplementedError("GraphedTrainer captures the default heads / loss terms (6d rotations, no aleatoric heads); "
+                                      "use Trainer for the other representations")
         super().__init__(model, criterion, lr=lr, weight_decay=weight_decay, max_norm=max_norm, distributed=None)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena.world = self.world

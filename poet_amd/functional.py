@@ -168,6 +168,7 @@ class HeadsFn(torch.autograd.Function):
             ops.pose_finish_fwd(r_all, t_all, cls, rot[i], trans[i], R, ncls)
             saved.append((r_all, rs, ts))
         ctx.saved, ctx.hs, ctx.cls, ctx.ncls, ctx.names, ctx.params = saved, hs, cls, ncls, names, params
+        ctx.do_announce = True
         return rot, trans
 
     @staticmethod
@@ -192,8 +193,63 @@ class HeadsFn(torch.autograd.Function):
             B.mlp3_bwd(dt_all, h, [Pt[f"{k}.weight"] for k in range(3)], ts, [G(pt + f"{k}.weight") for k in range(3)],
                        [G(pt + f"{k}.bias") for k in range(3)], dh, True)
         ops.SIDE.join()
-        announce("0_heads")
+        if ctx.do_announce:
+            announce("0_heads")
         return (dhs, None, None, None, *G.ret)
+
+
+class HeadsQuietFn(HeadsFn):
+    """HeadsFn that leaves the bucket announcement to another head function of the same step (HeadsRawFn, applied BEFORE it
+    in forward and therefore run AFTER it in backward: autograd orders independent nodes by descending sequence number)."""
+
+    @staticmethod
+    def forward(ctx, hs, cls, ncls, names, *params):
+        out = HeadsFn.forward(ctx, hs, cls, ncls, names, *params)
+        ctx.do_announce = False
+        return out
+
+
+class HeadsRawFn(torch.autograd.Function):
+    """The 3-layer MLP heads named by `prefixes` (e.g. "rotation_head.", "translation_head_aleatoric.") of every decoder
+    layer, WITHOUT the per-class slice / rotation post-processing: returns one (L, N*Q, out_dim) tensor per prefix.  Serves
+    the representations the fused head kernel does not cover (pose_estimation_transformer.py:85-96,357-384: quaternion
+    heads, aleatoric log-variance heads); the slice / normalisation are a handful of elementwise ops on 320 rows."""
+
+    @staticmethod
+    def forward(ctx, hs, prefixes, names, *params):
+        nl, N, Q, d = hs.shape
+        R = N * Q
+        hs = hs.contiguous()
+        outs, saved = [], []
+        for pre in prefixes:
+            per_layer, sv = [], []
+            for i in range(nl):
+                P = _pdict(names, params, f"{pre}{i}.layers.")
+                o, st = B.mlp3_fwd(hs[i].view(R, d), [P[f"{k}.weight"] for k in range(3)], [P[f"{k}.bias"] for k in range(3)])
+                per_layer.append(o)
+                sv.append(st)
+            outs.append(torch.stack(per_layer))
+            saved.append(sv)
+        ctx.saved, ctx.hs, ctx.prefixes, ctx.names, ctx.params = saved, hs, prefixes, names, params
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        hs, names, params = ctx.hs, ctx.names, ctx.params
+        nl, N, Q, d = hs.shape
+        R = N * Q
+        G = B.GradSink(names, params)
+        dhs = torch.empty_like(hs)
+        for j, pre in enumerate(ctx.prefixes):
+            dout = douts[j].contiguous()
+            for i in range(nl):
+                P = _pdict(names, params, f"{pre}{i}.layers.")
+                pl = f"{pre}{i}.layers."
+                B.mlp3_bwd(dout[i], hs[i].view(R, d), [P[f"{k}.weight"] for k in range(3)], ctx.saved[j][i],
+                           [G(pl + f"{k}.weight") for k in range(3)], [G(pl + f"{k}.bias") for k in range(3)], dhs[i].view(R, d), j > 0)
+        ops.SIDE.join()
+        announce("0_heads")
+        return (dhs, None, None, *G.ret)
 
 
 # ====================================================================================================

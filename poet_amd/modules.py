@@ -18,6 +18,7 @@ from typing import List, Optional
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import functional as Fn
@@ -364,19 +365,24 @@ class PoET(nn.Module):
         super().__init__()
         if bbox_mode not in ("gt", "jitter", "backbone") or ref_points_mode != "bbox" or query_embedding_mode != "bbox":
             raise NotImplementedError("only bbox_mode gt/jitter/backbone with bbox queries/reference points is implemented")
-        if rotation_mode != "6d" or aleatoric:
-            raise NotImplementedError("only the 6d rotation representation without aleatoric heads is implemented")
+        if rotation_mode not in ("6d", "quat", "silho_quat"):
+            raise NotImplementedError("Rotational representation is not supported.")
+        if aleatoric and rotation_mode != "6d":        # pose_estimation_transformer.py:72-73
+            raise NotImplementedError("Aleatoric uncertainty estimation not implemented for quaternion rotation representation.")
         self.transformer = transformer
         d = transformer.d_model
         self.hidden_dim, self.backbone, self.backbone_type = d, backbone, backbone_type
         self.aux_loss, self.n_queries, self.n_classes = aux_loss, num_queries, n_classes + 1
-        self.bbox_mode, self.class_mode, self.rotation_mode = bbox_mode, class_mode, rotation_mode
-        self.t_dim, self.rot_dim = 3, 6
+        self.bbox_mode, self.class_mode, self.rotation_mode, self.aleatoric = bbox_mode, class_mode, rotation_mode, aleatoric
+        self.t_dim, self.rot_dim, self.aleatoric_dim = 3, (6 if rotation_mode == "6d" else 4), 3
         mult = self.n_classes if class_mode == "specific" else 1
         self.num_feature_levels = num_feature_levels
         # construction order == RNG consumption order of pose_estimation_transformer.py:85-144
         self.translation_head = th = MLP(d, d, self.t_dim * mult, 3)    # registered first, replaced by ModuleLists
         self.rotation_head = rh = MLP(d, d, self.rot_dim * mult, 3)      # below: keeps the reference's parameter order
+        if aleatoric:                                                    # :88-90,95-96: log-variance heads
+            self.translation_head_aleatoric = tah = MLP(d, d, self.aleatoric_dim * mult, 3)
+            self.rotation_head_aleatoric = rah = MLP(d, d, self.aleatoric_dim * mult, 3)
         n_bb = len(backbone.strides)
         projs, cin = [], None
         for n in range(n_bb):
@@ -392,6 +398,9 @@ class PoET(nn.Module):
         n_pred = transformer.decoder.num_layers
         self.translation_head = nn.ModuleList([copy.deepcopy(th) for _ in range(n_pred)])
         self.rotation_head = nn.ModuleList([copy.deepcopy(rh) for _ in range(n_pred)])
+        if aleatoric:
+            self.translation_head_aleatoric = nn.ModuleList([copy.deepcopy(tah) for _ in range(n_pred)])
+            self.rotation_head_aleatoric = nn.ModuleList([copy.deepcopy(rah) for _ in range(n_pred)])
         self.bbox_embedding = BoundingBoxEmbeddingSine(num_pos_feats=d / 8)
 
     # ---- query assembly (pose_estimation_transformer.py:203-239,309-311,337-338), batched on the host ----
@@ -484,6 +493,25 @@ class PoET(nn.Module):
             cls32, ncls = torch.zeros(N * Q, dtype=torch.int32, device=dev), 1
         names, params = _named(self.translation_head, "translation_head.")
         n2, p2 = _named(self.rotation_head, "rotation_head.")
+
+        def pick(raw):                                 # (L, N*Q, ncls*k) -> (L, N, Q, k): per query the slice of its class (:365-374)
+            L = raw.shape[0]
+            if ncls == 1:
+                return raw.view(L, N, Q, -1)
+            idx = cls32.clamp(min=0).long().view(1, N * Q, 1, 1).expand(L, N * Q, 1, raw.shape[-1] // ncls)
+            return raw.view(L, N * Q, ncls, -1).gather(2, idx).view(L, N, Q, -1)
+
+        self._last_aleatoric = None
+        if self.rotation_mode != "6d":                 # quaternion heads: MLPs on the HIP path, slice + L2 normalisation elementwise (:429)
+            r_raw, t_raw = Fn.HeadsRawFn.apply(hs, ("rotation_head.", "translation_head."), names + n2, *(params + p2))
+            return F.normalize(pick(r_raw), p=2, dim=3), pick(t_raw), hs
+        if self.aleatoric:                             # applied BEFORE HeadsQuietFn: it runs last in backward and announces the bucket
+            n3, p3 = _named(self.translation_head_aleatoric, "translation_head_aleatoric.")
+            n4, p4 = _named(self.rotation_head_aleatoric, "rotation_head_aleatoric.")
+            ra_raw, ta_raw = Fn.HeadsRawFn.apply(hs, ("rotation_head_aleatoric.", "translation_head_aleatoric."), n3 + n4, *(p3 + p4))
+            self._last_aleatoric = (pick(ra_raw), pick(ta_raw))
+            rot, trans = Fn.HeadsQuietFn.apply(hs, cls32, ncls, names + n2, *(params + p2))
+            return rot, trans, hs
         rot, trans = Fn.HeadsFn.apply(hs, cls32, ncls, names + n2, *(params + p2))
         return rot, trans, hs
 
@@ -497,6 +525,12 @@ class PoET(nn.Module):
         out["_tgt_labels_host"] = getattr(self, "_tgt_labels_host", None)
         out["_pred_classes_host"] = getattr(self, "_pred_classes_host", None)
         out["_stacked"] = (trans, rot)                # (L, N, Q, 3) / (L, N, Q, 3, 3): lets the criterion take all layers at once
+        al = getattr(self, "_last_aleatoric", None)
+        if al is not None:                            # :402-411
+            ra, ta = al
+            out["pred_translation_aleatoric"], out["pred_rotation_aleatoric"] = ta[-1], ra[-1]
+            for a, aux in enumerate(out.get("aux_outputs", [])):
+                aux["pred_translation_aleatoric"], aux["pred_rotation_aleatoric"] = ta[a], ra[a]
         return out
 
     def forward(self, samples, targets=None):

@@ -7,7 +7,7 @@ from oracle.formula import CONFIGS, formula_fill, make_inputs
 
 
 def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False,
-                  bbox_mode="gt", predictions=None, class_mode="specific"):
+                  bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False):
     if not isinstance(precision, str):
         precision = "fp32" if precision == torch.float32 else "bf16"
     cfg = CONFIGS[name]
@@ -25,12 +25,13 @@ def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, f
                                         enc_n_points=cfg["n_points"])
     tr.set_precision(precision)
     model = poet_amd.PoET(bb, tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
-                          n_classes=cfg["n_classes"], bbox_mode=bbox_mode, class_mode=class_mode, aux_loss=True)
+                          n_classes=cfg["n_classes"], bbox_mode=bbox_mode, class_mode=class_mode, aux_loss=True,
+                          rotation_mode=rotation_mode, aleatoric=aleatoric)
     if not default_init:
         formula_fill(model)
     model = model.cuda()
     crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(bbox_mode="jitter" if bbox_mode == "jitter" else "gt"),
-                                 poet_amd.build_weight_dict(cfg["dec_layers"]))
+                                 poet_amd.build_weight_dict(cfg["dec_layers"]), poet_amd.losses_for(rotation_mode, aleatoric))
     samples = poet_amd.NestedTensor(None, image_mask(sizes, "cuda"))
     gt = [{k: v.cuda() for k, v in t.items()} for t in targets]
     return dict(cfg=cfg, model=model, crit=crit, samples=samples, targets=gt, cpu_targets=targets, feats=feats, sizes=sizes)

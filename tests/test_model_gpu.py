@@ -141,6 +141,51 @@ def test_modes_fp32_vs_reference_golden(gpu, golden_dir, bbox_mode, class_mode):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("rotation_mode,aleatoric", [("quat", False), ("silho_quat", False), ("6d", True)])
+def test_rotation_modes_fp32_vs_reference_golden(gpu, golden_dir, rotation_mode, aleatoric):
+    """Quaternion heads / losses and the aleatoric extension (pose_estimation_transformer.py:85-96,420-432,490-609) on the HIP
+    path: outputs, losses and gradient checksums against the real reference run in those modes; then one optimisation
+    step with the eager trainer (the graphed trainer declines these modes)."""
+    import poet_amd
+    g = np.load(os.path.join(golden_dir, f"poet_tiny_b2_pad_{rotation_mode}{'_aleatoric' if aleatoric else ''}.npz"))
+    r = gpu("tiny", 2, True, torch.float32, rotation_mode=rotation_mode, aleatoric=aleatoric)
+    model, crit = r["model"], r["crit"]
+    model.eval()
+    out, n_boxes = model(r["samples"], r["targets"])
+    real = _real_query_mask(n_boxes, r["cfg"]["num_queries"])
+    for key in ["pred_translation", "pred_rotation"] + (["pred_translation_aleatoric", "pred_rotation_aleatoric"] if aleatoric else []):
+        err = (out[key].float().cpu() - torch.from_numpy(g[key]))[real].abs().max().item()
+        assert err < 1e-3, (key, err)
+    losses = crit(out, r["targets"], n_boxes)
+    names = sorted(losses)
+    assert names == [str(x) for x in g["loss_names"]]
+    np.testing.assert_allclose([float(losses[k]) for k in names], g["loss_values"], rtol=2e-4, atol=2e-5)
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    model.zero_grad()
+    total.backward()
+    params = dict(model.named_parameters())
+    assert sorted(params) == sorted(str(n) for n in g["grad_names"])          # same parameter set (state_dict keys) as the reference
+    # the so(3) log map of the aleatoric rotation loss has the factor phi / (2 sin phi): for the random rotation pairs of the
+    # fixture (angles up to pi - 0.014) it amplifies the ~1e-6 fp32 differences of the predicted rotations ~1e3-fold
+    gtol = 2e-2 if aleatoric else 3e-3
+    bad = []
+    for n, ref in zip(g["grad_names"], g["grad_checksums"]):
+        p = params[str(n)]
+        if np.isnan(ref).all():
+            continue
+        got = checksum(p.grad.cpu())
+        if not np.allclose(got, ref, atol=gtol * max(1.0, abs(ref[0]))):
+            bad.append((str(n), float(np.abs(got - ref).max()), float(ref[0])))
+    assert not bad, bad[:10]
+    with pytest.raises(NotImplementedError):
+        poet_amd.GraphedTrainer(model, crit)
+    model.train()
+    tr = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, distributed=False)
+    t1, _ = tr.step(r["samples"], r["targets"])
+    t2, _ = tr.step(r["samples"], r["targets"])
+    assert np.isfinite(float(t1)) and np.isfinite(float(t2))
+
+
 @pytest.mark.parametrize("init", [False, True])
 def test_full_size_ycbv_checksums(gpu, golden_dir, init):
     """BASELINE configs[1] geometry (5/5/16h, 4 levels, 640x480, Q=20) at bs=1 against the reference's golden:
