@@ -15,3 +15,4 @@ from .engine import (BucketReducer, losses_for, GraphedTrainer, GraphedInference
 from .blocks import manual_seed  # noqa: F401
 
 __version__ = "0.1.0"
+from .data import DataPrefetcher, nested_tensor_from_tensor_list  # noqa: F401,E402

@@ -116,3 +116,25 @@ def test_bucket_reducer_gloo_world2():
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_input_side_batching_and_prefetch_protocol():
+    """util/misc.py:326-343 (zero padding + mask) against the oracle's restatement, and the prefetcher's iteration protocol
+    (data_utils/data_prefetcher.py: batches in order, (None, None) at the end) on the CPU."""
+    import poet_amd
+    from oracle import poet_ref
+    g = torch.Generator().manual_seed(0)
+    ims = [torch.randn(3, 5, 7, generator=g), torch.randn(3, 4, 9, generator=g), torch.randn(3, 6, 2, generator=g)]
+    a, b = poet_amd.nested_tensor_from_tensor_list(ims), poet_ref.nested_from_list(ims)
+    assert torch.equal(a.tensors, b.tensors) and torch.equal(a.mask, b.mask)
+    assert a.tensors.shape == (3, 3, 6, 9) and bool(a.mask[0, 5:, :].all()) and not bool(a.mask[0, :5, :7].any())
+    batches = [(poet_amd.nested_tensor_from_tensor_list([im]), [{"boxes": torch.full((2, 4), float(i))}]) for i, im in enumerate(ims)]
+    for prefetch in (True, False):
+        pf = poet_amd.DataPrefetcher(batches, "cpu", prefetch=prefetch)
+        seen = []
+        while True:
+            s, t = pf.next()
+            if s is None:
+                break
+            seen.append(float(t[0]["boxes"][0, 0]))
+        assert seen == [0.0, 1.0, 2.0] and pf.next() == (None, None)

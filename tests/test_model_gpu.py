@@ -504,6 +504,30 @@ def test_graphed_inference_matches_eager(gpu):
     assert runner.ready
 
 
+def test_prefetcher_feeds_the_trainer(gpu):
+    """DataPrefetcher (data_utils/data_prefetcher.py's role): batches arrive on the GPU in order, with boxes / labels kept on
+    the host as asked, bit-identical to a direct copy, and the trainer consumes them."""
+    import poet_amd
+    from oracle.formula import CONFIGS, make_inputs
+    cfg = CONFIGS["tiny"]
+    r = gpu("tiny", 2, True, "bf16", dropout=0.0)
+    host_batches = []
+    for step in range(4):
+        _, _, targets = make_inputs(cfg, seed=500 + step, batch=2, pad=True)
+        host_batches.append((poet_amd.NestedTensor(None, r["samples"].mask.cpu()), targets))
+    pf = poet_amd.DataPrefetcher(host_batches, "cuda", keep_on_host=("boxes", "labels", "jitter_boxes"))
+    r["model"].train()
+    tr = poet_amd.Trainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+    n = 0
+    for (samples, targets), (_, ref_t) in zip(pf, host_batches):
+        assert samples.mask.is_cuda and not targets[0]["boxes"].is_cuda and targets[0]["relative_rotation"].is_cuda
+        assert torch.equal(targets[1]["relative_position"].cpu(), ref_t[1]["relative_position"])
+        total, _ = tr.step(samples, targets)
+        assert np.isfinite(float(total))
+        n += 1
+    assert n == 4 and pf.next() == (None, None)
+
+
 def test_images_without_objects(gpu):
     """Ragged and empty targets (the reference pads the query set per image and clamps the box count to >= 1,
     pose_estimation_transformer.py:604-606): one image without objects == the oracle's loss; a batch with no objects at all
