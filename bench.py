@@ -289,19 +289,22 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof, prof_steps = None, 3
-    if not args.no_roofline and rank == 0 and world == 1:
+    if not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, over 3 EXTRA steps of the same workload right after the
-        # timed region (kept out of it so the events do not perturb `value`)
+        # timed region (kept out of it so the events do not perturb `value`).  At N > 1 every rank runs the extra steps
+        # (they contain the gradient all-reduces); rank 0 alone records events.
         eager = trainer if args.no_graphs else super(poet_amd.GraphedTrainer, trainer)     # per-launch events need eager launches
         ops.SEED_DEV[0] = None
-        ops.PROFILE.start()
+        if rank == 0:
+            ops.PROFILE.start()
         for _ in range(prof_steps):
             # keep the GPU busy while the host enqueues the eager step: with an idle queue the begin-event of a launch
             # is stamped when it is recorded and the pair would time host latency, not the kernel
             torch.cuda._sleep(int(0.25 * 2.4e9))
             eager.step(samples, targets)
             sync()
-        prof = ops.PROFILE.stop()
+        if rank == 0:
+            prof = ops.PROFILE.stop()
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
