@@ -141,7 +141,8 @@ def _msda_inputs(seed, shapes, n=2, m=4, d=16, lq=37, p=4):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shapes,m,d", [([(6, 8), (3, 4)], 4, 16), ([(12, 16), (6, 8), (3, 4), (2, 2)], 8, 32), ([(5, 7)], 2, 64),
-                                        ([(9, 11), (5, 6), (3, 3)], 4, 16)])
+                                        ([(9, 11), (5, 6), (3, 3)], 4, 16), ([(7, 5), (4, 3)], 3, 8), ([(1, 1), (2, 3)], 5, 8),
+                                        ([(13, 17), (7, 9), (4, 5), (2, 3)], 1, 128)])
 def test_msda_boundary(ops, dtype, shapes, m, d):
     value, loc, attn, gout = _msda_inputs(3, shapes, m=m, d=d)
     geom = ops.LevelGeom(shapes)
