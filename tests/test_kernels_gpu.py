@@ -161,6 +161,24 @@ def test_msda_boundary(ops, dtype, shapes, m, d):
     _close(gl, torch.from_numpy(rl), dtype, scale=30, msg="msda dloc")
 
 
+@pytest.mark.parametrize("npts", [1, 2])
+def test_msda_fewer_points(ops, npts):
+    """n_points 1 and 2 (the other instantiations of the gather / scatter kernels) against the float64 closed form."""
+    shapes = [(9, 11), (5, 6), (3, 3)]
+    value, loc, attn, gout = _msda_inputs(11, shapes, m=4, d=16, p=npts)
+    geom = ops.LevelGeom(shapes)
+    tv, tl, ta, tg = (torch.from_numpy(a) for a in (value, loc, attn, gout))
+    out = torch.empty(tg.shape, device="cuda")
+    ops.msda_fwd(dev(tv), geom, dev(tl), dev(ta), out)
+    _close(out, torch.from_numpy(msda_explicit.msda_forward(value, shapes, loc, attn)), torch.float32, msg="msda fwd")
+    gv = torch.empty(tv.shape, device="cuda"); gl = torch.empty(tl.shape, device="cuda"); ga = torch.empty(ta.shape, device="cuda")
+    ops.msda_bwd(dev(tv), geom, dev(tl), dev(ta), dev(tg), gv, gl, ga)
+    rv, rl, ra = msda_explicit.msda_backward(value, shapes, loc, attn, gout)
+    _close(gv, torch.from_numpy(rv), torch.float32, scale=3, msg="msda dvalue")
+    _close(ga, torch.from_numpy(ra), torch.float32, scale=3, msg="msda dattn")
+    _close(gl, torch.from_numpy(rl), torch.float32, scale=30, msg="msda dloc")
+
+
 @pytest.mark.parametrize("vdt,qdt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
 @pytest.mark.parametrize("head_major", [False, True])
 def test_msda_fused(ops, vdt, qdt, head_major):
