@@ -306,6 +306,63 @@ def mlp3_fwd(h, Ws, bs):
     return c, (a, b)
 
 
+def uniform_stride(ts):
+    """Element stride between consecutive tensors of a list when they are fp32, contiguous, equally shaped and equally
+    spaced in memory (the per-decoder-layer copies of one head parameter inside the flat arena); None otherwise."""
+    if len(ts) < 2:
+        return None
+    t0 = ts[0]
+    step = ts[1].data_ptr() - t0.data_ptr()
+    if step <= 0 or step % 4:
+        return None
+    for i, t in enumerate(ts):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != t0.shape or t.data_ptr() - t0.data_ptr() != i * step:
+            return None
+    return step // 4
+
+
+def mlp3_fwd_batched(h, Ws, bs, sW, sb):
+    """mlp3_fwd for `nb` INDEPENDENT heads of one shape in three launches: h (nb, rows, d); Ws[k] / bs[k] = layer k's weight
+    / bias of head 0, head j's copy sW[k] / sb[k] elements further (pose_estimation_transformer.py:357-363 applies
+    head l to decoder output l: nothing couples them)."""
+    nb, rows, d = h.shape
+    outs, x = [], h
+    for k in range(3):
+        n_out, k_in = Ws[k].shape
+        y = empty((nb, rows, n_out), torch.float32, h)
+        ops.gemm(x, Ws[k], y, rows, n_out, k_in, lda=k_in, ldb=k_in, ldc=n_out, bias=bs[k], act=1 if k < 2 else 0, batch=nb,
+                 strideA=rows * k_in, strideB=sW[k], strideC=rows * n_out, stride_bias=sb[k])
+        outs.append(y)
+        x = y
+    return outs[2], (outs[0], outs[1])
+
+
+def mlp3_bwd_batched(dc, h, Ws, saved, gWs, gbs, sW, sgW, sgb, dh, accumulate, Ws_all):
+    """Backward of mlp3_fwd_batched: per MLP layer one launch for all dW + db and one for all dX.  sW: head-to-head stride of
+    the weights, sgW / sgb: of the gradient buffers (the arena packs parameters and gradients differently)."""
+    a, b = saved
+    nb, rows, d = h.shape
+    acts = (h, a, b)
+    dy = dc
+    for k in (2, 1, 0):
+        n_out, k_in = Ws[k].shape
+        x = acts[k]
+        ops.gemm(dy, x, gWs[k], n_out, k_in, rows, lda=n_out, ldb=k_in, ldc=k_in, a_kmajor=True, b_kmajor=True, atomic=True,
+                 bias=gbs[k], batch=nb, strideA=rows * n_out, strideB=rows * k_in, strideC=sgW[k], stride_bias=sgb[k])
+        if k > 0:
+            dx = torch.empty_like(x)
+            if n_out % 16 == 0:
+                ops.gemm(dy, Ws[k], dx, rows, k_in, n_out, lda=n_out, ldb=k_in, ldc=k_in, b_kmajor=True, gate_ref=x, batch=nb,
+                         strideA=rows * n_out, strideB=sW[k], strideC=rows * k_in)
+            else:                                   # (n_classes+1) * 6 or * 3 wide outputs: outside the batched kernel's K % 16 == 0
+                for j in range(nb):
+                    ops.linear_dx(dy[j], Ws_all[k][j], dx[j], rows=rows, gate_ref=x[j])
+            dy = dx
+        else:
+            ops.gemm(dy, Ws[0], dh, rows, k_in, n_out, lda=n_out, ldb=k_in, ldc=k_in, b_kmajor=True,
+                     add_src=dh if accumulate else None, ld_add=k_in, batch=nb, strideA=rows * n_out, strideB=sW[0], strideC=rows * k_in)
+
+
 def mlp3_bwd(dc, h, Ws, saved, gWs, gbs, dh, accumulate):
     a, b = saved
     rows = h.shape[0]

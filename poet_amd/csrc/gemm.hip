@@ -404,7 +404,6 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         POET_CHECK(d.c_dtype == POET_F32, POET_ERR_ARG, "poet_gemm: atomic/split-K needs fp32 C");
         POET_CHECK((!d.bias || dw_form) && !d.act && !d.gate_ref && !d.add_src && d.drop_p == 0.f && !d.row_mask, POET_ERR_ARG,
                    "poet_gemm: atomic/split-K allows no epilogue");
-        POET_CHECK(!ysum || d.batch == 1, POET_ERR_UNSUPPORTED, "poet_gemm: bias-gradient output needs batch == 1");
     }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.out_mode == 1) POET_CHECK(d.hm_M > 0 && d.hm_S > 0 && d.hm_D > 0 && d.hm_M * d.hm_D == d.N, POET_ERR_ARG, "poet_gemm: head-major dims");
@@ -432,10 +431,13 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         return POET_OK;
     }
     if (ysum) {                            // generic path: the column sums are a separate launch
+        POET_CHECK(d.batch == 1, POET_ERR_UNSUPPORTED, "poet_gemm: batched bias-gradient output only in the <= 1024-row kernels");
         const int rc = poet_colsum(d.A, d.lda, ysum, 1, d.K, d.M, nullptr, 1, d.a_dtype, stream);
         if (rc) return rc;
         d.bias = nullptr;
     }
+    POET_CHECK(d.batch == 1 || (!d.add_src && !d.gate_ref), POET_ERR_UNSUPPORTED,
+               "poet_gemm: batched add_src / gate_ref only in the <= 1024-row kernels");
     if (gemm_ws_try(p, st)) {
         g_last_path = POET_GEMM_PATH_STREAM;
         POET_LAUNCH_CHECK();

@@ -43,9 +43,10 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmK p) {
     const int kw = SPLIT ? d.K >> 2 : d.K, kbase = SPLIT ? wid * kw : 0; // this wave's K range
     const int kq = kw >> 2;                                             // floats per lane group, multiple of 4
     const int ncol = min(n0 + r, d.N - 1);                              // ragged N: clamp the operand, mask the store
-    const float* ap = reinterpret_cast<const float*>(d.A) + (int64_t)min(m0 + r, d.M - 1) * d.lda + kbase + g * kq;
-    const float* wp = BKM ? reinterpret_cast<const float*>(d.B) + (int64_t)(kbase + g * kq) * d.ldb + ncol
-                          : reinterpret_cast<const float*>(d.B) + (int64_t)ncol * d.ldb + kbase + g * kq;
+    const int64_t zb = blockIdx.y;                                      // batch entry (independent problems of one shape)
+    const float* ap = reinterpret_cast<const float*>(d.A) + zb * d.strideA + (int64_t)min(m0 + r, d.M - 1) * d.lda + kbase + g * kq;
+    const float* wb = reinterpret_cast<const float*>(d.B) + zb * d.strideB;
+    const float* wp = BKM ? wb + (int64_t)(kbase + g * kq) * d.ldb + ncol : wb + (int64_t)ncol * d.ldb + kbase + g * kq;
     f32x4_t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int k0 = 0; k0 < kq; k0 += 64) {                               // 64 floats per operand per trip
         float4 a[16], w[16];
@@ -76,11 +77,12 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmK p) {
     // lane holds C[m0 + 4g + t][n0 + r], t = 0..3: 16 lanes of a row are 64 contiguous bytes
     const int col = n0 + r;
     if (col >= d.N) return;
-    const float b = d.bias ? d.bias[col] : 0.f;
+    const float b = d.bias ? d.bias[zb * d.stride_bias + col] : 0.f;
     const uint32_t sd = d.seed ^ (d.seed_dev ? *d.seed_dev * 0x9E3779B1u : 0u);
-    const float* addp = reinterpret_cast<const float*>(d.add_src);
-    const float* gate = reinterpret_cast<const float*>(d.gate_ref);
-    float* C = reinterpret_cast<float*>(d.C);
+    // (gate_ref and add_src are laid out like C: they take C's batch stride)
+    const float* addp = d.add_src ? reinterpret_cast<const float*>(d.add_src) + zb * d.strideC : nullptr;
+    const float* gate = d.gate_ref ? reinterpret_cast<const float*>(d.gate_ref) + zb * d.strideC : nullptr;
+    float* C = reinterpret_cast<float*>(d.C) + zb * d.strideC;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int row = m0 + g * 4 + t;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmK p) {
         float v = c4[t] * d.alpha + b;
         if (d.act == 1) v = fmaxf(v, 0.f);
         if (gate) v = gate[(int64_t)row * d.ldc + col] > 0.f ? v * d.gate_scale : 0.f;
-        if (p.drop_thresh) v = drop_keep(sd, (uint32_t)row * (uint32_t)d.N + (uint32_t)col, p.drop_thresh) ? v * p.drop_scale : 0.f;
+        if (p.drop_thresh) v = drop_keep(sd, ((uint32_t)zb * (uint32_t)d.M + (uint32_t)row) * (uint32_t)d.N + (uint32_t)col, p.drop_thresh) ? v * p.drop_scale : 0.f;
         if (addp) v += addp[(int64_t)row * d.ld_add + col];
         C[(int64_t)row * d.ldc + col] = v;
     }
@@ -109,8 +111,9 @@ __global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
     const int kq = (d.K + 15) >> 4;                                     // rows per (wave, lane group)
     const int rbase = (wid * 4 + g) * kq;
     const int ycol = min(m0 + r, d.M - 1), xcol = min(n0 + r, d.N - 1);
-    const float* yp = reinterpret_cast<const float*>(d.A) + ycol;
-    const float* xp = reinterpret_cast<const float*>(d.B) + xcol;
+    const int64_t zb = blockIdx.y;                                      // batch entry
+    const float* yp = reinterpret_cast<const float*>(d.A) + zb * d.strideA + ycol;
+    const float* xp = reinterpret_cast<const float*>(d.B) + zb * d.strideB + xcol;
     f32x4_t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float ysum = 0.f;
     for (int k0 = 0; k0 < kq; k0 += 32) {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
     }
     f32x4_t c4 = fold_waves(acc[0] + acc[1] + acc[2] + acc[3], red, lane, wid);     // (barrier inside)
     if (wid) return;
-    float* C = reinterpret_cast<float*>(d.C);
+    float* C = reinterpret_cast<float*>(d.C) + zb * d.strideC;
     const int col = n0 + r;
     if (col < d.N) {
 #pragma unroll
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
             if (row < d.M) C[(int64_t)row * d.ldc + col] += c4[t];
         }
     }
-    if (do_sum && g == 0 && m0 + r < d.M) const_cast<float*>(d.bias)[m0 + r] += reds[0][r] + reds[1][r] + reds[2][r] + reds[3][r];
+    if (do_sum && g == 0 && m0 + r < d.M) const_cast<float*>(d.bias)[zb * d.stride_bias + m0 + r] += reds[0][r] + reds[1][r] + reds[2][r] + reds[3][r];
 }
 
 }  // namespace
@@ -155,12 +158,12 @@ bool gemm_small_try(const GemmK& p, hipStream_t st) {
     static const int disabled = [] { const char* e = getenv("POET_GEMM_NO_SMALL"); return e && atoi(e) ? 1 : 0; }();
     if (disabled) return false;
     if (d.compute != POET_F32 || d.a_dtype != POET_F32 || d.b_dtype != POET_F32 || d.c_dtype != POET_F32) return false;
-    if (d.batch != 1 || d.A2 || d.row_mask || d.out_mode) return false;
+    if (d.batch < 1 || d.batch > 65535 || d.A2 || d.row_mask || d.out_mode) return false;
     const bool dw_form = d.a_kmajor && d.b_kmajor && (d.atomic || d.splitk > 1);
     if (dw_form) {                                                      // M = n_out, N = k_in, K = rows
         if (d.K > 1024 || d.alpha != 1.f) return false;
         const int tiles = ((d.M + 15) >> 4) * ((d.N + 15) >> 4);
-        hipLaunchKernelGGL(gemm_small_dw_kernel, dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_small_dw_kernel, dim3(tiles, d.batch), dim3(256), 0, st, p);
         return true;
     }
     if (d.a_kmajor || d.splitk != 1 || d.atomic) return false;
@@ -168,7 +171,7 @@ bool gemm_small_try(const GemmK& p, hipStream_t st) {
     if (!d.b_kmajor && !p.b_vec) return false;
     const int tiles = ((d.M + 15) >> 4) * ((d.N + 15) >> 4);
     const bool split = d.K >= 512 && d.K % 64 == 0;                      // long reductions: 4 waves share one tile
-    const dim3 grid(split ? tiles : (tiles + 3) / 4);
+    const dim3 grid(split ? tiles : (tiles + 3) / 4, d.batch);
     if (d.b_kmajor) {
         if (split) hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, dim3(256), 0, st, p);

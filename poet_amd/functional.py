@@ -5,6 +5,8 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+import os
+
 import torch
 
 from . import blocks as B
@@ -149,24 +151,58 @@ class DecoderFn(torch.autograd.Function):
 # ====================================================================================================
 # Pose heads: per decoder layer two 3-layer MLPs + class-slot gather + 6D->R
 # ====================================================================================================
+def _head_stack(names, params, prefix, nl, grads=None):
+    """Layer-0 tensors and uniform per-decoder-layer strides of one head family's 3 weights and 3 biases (None when the
+    copies are not equally spaced, e.g. outside the flat arena).  grads: a GradSink -> the same for the gradient buffers."""
+    Ws, bs, sW, sb = [], [], [], []
+    for k in range(3):
+        for kind, lst, strides in (("weight", Ws, sW), ("bias", bs, sb)):
+            ts = [(_pdict(names, params, f"{prefix}{i}.layers.")[f"{k}.{kind}"] if grads is None else grads(f"{prefix}{i}.layers.{k}.{kind}"))
+                  for i in range(nl)]
+            st = B.uniform_stride(ts)
+            if st is None:
+                return None
+            lst.append(ts[0])
+            strides.append(st)
+    return Ws, bs, sW, sb
+
+
+_BATCH_HEADS = os.environ.get("POET_GEMM_NO_SMALL", "0") in ("", "0") and os.environ.get("POET_NO_BATCHED_HEADS", "0") in ("", "0")
+
+
 class HeadsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hs, cls, ncls, names, *params):
-        """hs (L,N,Q,d) fp32; cls (N*Q) int32.  Returns rot (L,N,Q,3,3), trans (L,N,Q,3)."""
+        """hs (L,N,Q,d) fp32; cls (N*Q) int32.  Returns rot (L,N,Q,3,3), trans (L,N,Q,3).
+        The heads of different decoder layers are independent (pose_estimation_transformer.py:357-363): when their
+        parameters sit equally spaced in the flat arena, every MLP layer of all L heads is ONE batched launch (7 launches
+        instead of 7 L forward, 13 instead of 13 L backward)."""
         nl, N, Q, d = hs.shape
         R = N * Q
         hs = hs.contiguous()
         rot = torch.empty((nl, N, Q, 3, 3), dtype=torch.float32, device=hs.device)
         trans = torch.empty((nl, N, Q, 3), dtype=torch.float32, device=hs.device)
-        saved = []
-        for i in range(nl):
-            h = hs[i].view(R, d)
-            Pr = _pdict(names, params, f"rotation_head.{i}.layers.")
-            Pt = _pdict(names, params, f"translation_head.{i}.layers.")
-            r_all, rs = B.mlp3_fwd(h, [Pr[f"{k}.weight"] for k in range(3)], [Pr[f"{k}.bias"] for k in range(3)])
-            t_all, ts = B.mlp3_fwd(h, [Pt[f"{k}.weight"] for k in range(3)], [Pt[f"{k}.bias"] for k in range(3)])
-            ops.pose_finish_fwd(r_all, t_all, cls, rot[i], trans[i], R, ncls)
-            saved.append((r_all, rs, ts))
+        ctx.batched = None
+        st_r = _head_stack(names, params, "rotation_head.", nl) if (_BATCH_HEADS and nl > 1) else None
+        st_t = _head_stack(names, params, "translation_head.", nl) if st_r is not None else None
+        if st_t is not None:
+            h = hs.view(nl, R, d)
+            r_all, rs = B.mlp3_fwd_batched(h, st_r[0], st_r[1], st_r[2], st_r[3])
+            t_all, ts = B.mlp3_fwd_batched(h, st_t[0], st_t[1], st_t[2], st_t[3])
+            cls_rep = cls.repeat(nl)
+            ops.pose_finish_fwd(r_all, t_all, cls_rep, rot, trans, nl * R, ncls)
+            ctx.batched = (r_all, rs, ts, cls_rep, st_r, st_t)
+            saved = None
+        else:
+            saved = []
+            for i in range(nl):
+                h = hs[i].view(R, d)
+                Pr = _pdict(names, params, f"rotation_head.{i}.layers.")
+                Pt = _pdict(names, params, f"translation_head.{i}.layers.")
+                r_all, rs = B.mlp3_fwd(h, [Pr[f"{k}.weight"] for k in range(3)], [Pr[f"{k}.bias"] for k in range(3)])
+                t_all, ts = B.mlp3_fwd(h, [Pt[f"{k}.weight"] for k in range(3)], [Pt[f"{k}.bias"] for k in range(3)])
+                ops.pose_finish_fwd(r_all, t_all, cls, rot[i], trans[i], R, ncls)
+                saved.append((r_all, rs, ts))
         ctx.saved, ctx.hs, ctx.cls, ctx.ncls, ctx.names, ctx.params = saved, hs, cls, ncls, names, params
         ctx.do_announce = True
         return rot, trans
@@ -179,19 +215,38 @@ class HeadsFn(torch.autograd.Function):
         G = B.GradSink(names, params)
         drot, dtrans = drot.contiguous(), dtrans.contiguous()
         dhs = torch.empty_like(hs)
-        for i in range(nl):
-            h = hs[i].view(R, d)
-            r_all, rs, ts = ctx.saved[i]
-            pr, pt = f"rotation_head.{i}.layers.", f"translation_head.{i}.layers."
-            Pr, Pt = _pdict(names, params, pr), _pdict(names, params, pt)
+        gst_r = gst_t = None
+        if ctx.batched is not None:
+            gst_r = _head_stack(names, params, "rotation_head.", nl, grads=G)
+            gst_t = _head_stack(names, params, "translation_head.", nl, grads=G) if gst_r is not None else None
+        if gst_t is not None:
+            r_all, rs, ts, cls_rep, st_r, st_t = ctx.batched
             dr_all = torch.empty_like(r_all)
-            dt_all = torch.empty((R, ncls * 3), dtype=torch.float32, device=hs.device)
-            ops.pose_finish_bwd(r_all, cls, drot[i], dtrans[i], dr_all, dt_all, R, ncls)
-            dh = dhs[i].view(R, d)
-            B.mlp3_bwd(dr_all, h, [Pr[f"{k}.weight"] for k in range(3)], rs, [G(pr + f"{k}.weight") for k in range(3)],
-                       [G(pr + f"{k}.bias") for k in range(3)], dh, False)
-            B.mlp3_bwd(dt_all, h, [Pt[f"{k}.weight"] for k in range(3)], ts, [G(pt + f"{k}.weight") for k in range(3)],
-                       [G(pt + f"{k}.bias") for k in range(3)], dh, True)
+            dt_all = torch.empty((nl, R, ncls * 3), dtype=torch.float32, device=hs.device)
+            ops.pose_finish_bwd(r_all, cls_rep, drot, dtrans, dr_all, dt_all, nl * R, ncls)
+            h = hs.view(nl, R, d)
+            dh = dhs.view(nl, R, d)
+            allw = lambda pre: [[_pdict(names, params, f"{pre}{i}.layers.")[f"{k}.weight"] for i in range(nl)] for k in range(3)]
+            B.mlp3_bwd_batched(dr_all, h, st_r[0], rs, gst_r[0], gst_r[1], st_r[2], gst_r[2], gst_r[3], dh, False, allw("rotation_head."))
+            B.mlp3_bwd_batched(dt_all, h, st_t[0], ts, gst_t[0], gst_t[1], st_t[2], gst_t[2], gst_t[3], dh, True, allw("translation_head."))
+        else:
+            for i in range(nl):
+                h = hs[i].view(R, d)
+                if ctx.batched is not None:          # forward ran batched but the gradient buffers are not equally spaced
+                    r_all, (ra, rb), (ta, tb) = ctx.batched[0][i], ctx.batched[1], ctx.batched[2]
+                    rs, ts = (ra[i], rb[i]), (ta[i], tb[i])
+                else:
+                    r_all, rs, ts = ctx.saved[i]
+                pr, pt = f"rotation_head.{i}.layers.", f"translation_head.{i}.layers."
+                Pr, Pt = _pdict(names, params, pr), _pdict(names, params, pt)
+                dr_all = torch.empty_like(r_all)
+                dt_all = torch.empty((R, ncls * 3), dtype=torch.float32, device=hs.device)
+                ops.pose_finish_bwd(r_all, cls, drot[i], dtrans[i], dr_all, dt_all, R, ncls)
+                dh = dhs[i].view(R, d)
+                B.mlp3_bwd(dr_all, h, [Pr[f"{k}.weight"] for k in range(3)], rs, [G(pr + f"{k}.weight") for k in range(3)],
+                           [G(pr + f"{k}.bias") for k in range(3)], dh, False)
+                B.mlp3_bwd(dt_all, h, [Pt[f"{k}.weight"] for k in range(3)], ts, [G(pt + f"{k}.weight") for k in range(3)],
+                           [G(pt + f"{k}.bias") for k in range(3)], dh, True)
         ops.SIDE.join()
         if ctx.do_announce:
             announce("0_heads")

@@ -669,3 +669,43 @@ def test_gemm_small_dw_db(ops, rows, n_out, k_in):
     ops.linear_dw(dev(dy), dev(x), dw, rows=rows, db=db)          # accumulates onto what is there
     _close(dw, 2 * (dy.t() @ x) + w0, torch.float32, scale=math.sqrt(rows), msg="small dW")
     _close(db, 2 * dy.sum(0) + b0, torch.float32, scale=math.sqrt(rows), msg="small db")
+
+
+def test_gemm_small_batched_matches_loop(ops):
+    """batch > 1 in the 320-row kernels (independent problems of one shape at a constant stride: the pose heads of the
+    L decoder layers inside the flat parameter arena): forward with bias + ReLU, gated dX accumulated onto a tensor, and
+    dW + db must equal the same calls issued one problem at a time, bit for bit."""
+    nb, rows, n_out, k_in = 5, 320, 256, 256
+    pad = 1000                                                    # the copies are NOT back to back
+    Wbuf = dev(_rand(nb * (n_out * k_in + pad), seed=1, scale=0.06))
+    bbuf = dev(_rand(nb * (n_out + 24), seed=2))
+    sW, sb = n_out * k_in + pad, n_out + 24
+    Ws = [Wbuf[j * sW: j * sW + n_out * k_in].view(n_out, k_in) for j in range(nb)]
+    bs = [bbuf[j * sb: j * sb + n_out] for j in range(nb)]
+    x = dev(_rand(nb, rows, k_in, seed=3))
+    dy = dev(_rand(nb, rows, n_out, seed=4))
+    # forward
+    y1, y2 = torch.empty(nb, rows, n_out, device="cuda"), torch.empty(nb, rows, n_out, device="cuda")
+    ops.gemm(x, Ws[0], y1, rows, n_out, k_in, lda=k_in, ldb=k_in, ldc=n_out, bias=bs[0], act=1, batch=nb,
+             strideA=rows * k_in, strideB=sW, strideC=rows * n_out, stride_bias=sb)
+    for j in range(nb):
+        ops.linear_fwd(x[j], Ws[j], bs[j], y2[j], act=1)
+    assert torch.equal(y1, y2)
+    ref = torch.relu(x[3].cpu() @ Ws[3].cpu().t() + bs[3].cpu())
+    assert (y1[3].cpu() - ref).abs().max().item() < 2e-3
+    # dX with gate and accumulation
+    acc1 = dev(_rand(nb, rows, k_in, seed=5)); acc2 = acc1.clone()
+    ops.gemm(dy, Ws[0], acc1, rows, k_in, n_out, lda=n_out, ldb=k_in, ldc=k_in, b_kmajor=True, gate_ref=x, add_src=acc1, ld_add=k_in,
+             batch=nb, strideA=rows * n_out, strideB=sW, strideC=rows * k_in)
+    for j in range(nb):
+        ops.linear_dx(dy[j], Ws[j], acc2[j], rows=rows, gate_ref=x[j], add_src=acc2[j])
+    assert torch.equal(acc1, acc2)
+    # dW + db
+    g1, g2 = torch.zeros_like(Wbuf), torch.zeros_like(Wbuf)
+    d1, d2 = torch.zeros_like(bbuf), torch.zeros_like(bbuf)
+    ops.gemm(dy, x, g1, n_out, k_in, rows, lda=n_out, ldb=k_in, ldc=k_in, a_kmajor=True, b_kmajor=True, atomic=True, bias=d1, batch=nb,
+             strideA=rows * n_out, strideB=rows * k_in, strideC=sW, stride_bias=sb)
+    for j in range(nb):
+        ops.linear_dw(dy[j], x[j], g2[j * sW: j * sW + n_out * k_in].view(n_out, k_in), rows=rows, db=d2[j * sb: j * sb + n_out])
+    assert torch.equal(g1, g2) and torch.equal(d1, d2)
+    assert float(g1[n_out * k_in: sW].abs().max()) == 0.0        # the gaps between the copies stay untouched
