@@ -183,7 +183,8 @@ class HeadsFn(torch.autograd.Function):
         rot = torch.empty((nl, N, Q, 3, 3), dtype=torch.float32, device=hs.device)
         trans = torch.empty((nl, N, Q, 3), dtype=torch.float32, device=hs.device)
         ctx.batched = None
-        st_r = _head_stack(names, params, "rotation_head.", nl) if (_BATCH_HEADS and nl > 1) else None
+        # (the batch-capable kernels are the <= 1024-row fp32 ones: larger per-GPU batches take the per-layer loop)
+        st_r = _head_stack(names, params, "rotation_head.", nl) if (_BATCH_HEADS and nl > 1 and R <= 1024 and d % 16 == 0) else None
         st_t = _head_stack(names, params, "translation_head.", nl) if st_r is not None else None
         if st_t is not None:
             h = hs.view(nl, R, d)

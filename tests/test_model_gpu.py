@@ -595,3 +595,19 @@ def test_rccl_code_path_one_rank(gpu, tmp_path, mode):
     assert np.isfinite(a["flat"]).all()
     assert a["losses"] == pytest.approx(np.array(losses), rel=2e-3, abs=2e-3)
     assert np.abs(a["flat"] - flat).max() < 1e-3                # (fp32 atomics in the dW kernels: runs differ at ~1e-4 after AdamW)
+
+
+def test_heads_beyond_the_batched_kernels(gpu):
+    """N * Q > 1024 rows (a large per-GPU batch): the pose heads leave the batch-5 launches of the 320-row kernels for the
+    per-layer loop; one training step must run and give a finite loss (regression: bs 128 x 20 queries)."""
+    import poet_amd
+    from oracle.formula import CONFIGS
+    cfg = CONFIGS["tiny"]
+    batch = 1024 // cfg["num_queries"] + 2
+    r = gpu("tiny", batch, False, "bf16", dropout=0.0)
+    assert batch * cfg["num_queries"] > 1024
+    r["model"].train()
+    tr = poet_amd.Trainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+    for _ in range(2):
+        total, _ = tr.step(r["samples"], r["targets"])
+    assert np.isfinite(float(total))
