@@ -566,9 +566,9 @@ class GraphedTrainer(Trainer):
         # the base class broadcasts the parameters and owns the bucket reducer used by the EAGER warm-up steps (without it
         # the ranks would drift apart before the graphs are captured); the captured steps all-reduce the whole arena
         # themselves (see _Replay.backward) and run with the reducer detached
-        if getattr(model, "rotation_mode", "6d") != "6d" or getattr(model, "aleatoric", False) or not getattr(criterion, "default_terms", True):
-            raise NotImplementedError("GraphedTrainer captures the default heads / loss terms (6d rotations, no aleatoric heads); "
-                                      "use Trainer for the other representations")
+        if getattr(model, "aleatoric", False):
+            raise NotImplementedError("GraphedTrainer does not capture the aleatoric heads (their outputs are not part of the captured "
+                                      "forward's interface); use Trainer")
         super().__init__(model, criterion, lr=lr, weight_decay=weight_decay, max_norm=max_norm, distributed=None)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena.world = self.world

@@ -177,13 +177,28 @@ def test_rotation_modes_fp32_vs_reference_golden(gpu, golden_dir, rotation_mode,
         if not np.allclose(got, ref, atol=gtol * max(1.0, abs(ref[0]))):
             bad.append((str(n), float(np.abs(got - ref).max()), float(ref[0])))
     assert not bad, bad[:10]
-    with pytest.raises(NotImplementedError):
-        poet_amd.GraphedTrainer(model, crit)
     model.train()
-    tr = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, distributed=False)
-    t1, _ = tr.step(r["samples"], r["targets"])
-    t2, _ = tr.step(r["samples"], r["targets"])
-    assert np.isfinite(float(t1)) and np.isfinite(float(t2))
+    if aleatoric:
+        with pytest.raises(NotImplementedError):
+            poet_amd.GraphedTrainer(model, crit)
+        tr = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, distributed=False)
+        t1, _ = tr.step(r["samples"], r["targets"])
+        t2, _ = tr.step(r["samples"], r["targets"])
+        assert np.isfinite(float(t1)) and np.isfinite(float(t2))
+        return
+    # quaternion modes: HIP-graph replay (single and segmented backward) == eager, dropout off
+    runs = {}
+    for mode in ("eager", "graph", "segmented"):
+        rr = gpu("tiny", 2, True, "bf16", dropout=0.0, rotation_mode=rotation_mode)
+        rr["model"].train()
+        if mode == "eager":
+            tr = poet_amd.Trainer(rr["model"], rr["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+        else:
+            tr = poet_amd.GraphedTrainer(rr["model"], rr["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1,
+                                         segment_backward=(mode == "segmented"))
+        runs[mode] = [float(tr.step(rr["samples"], rr["targets"])[0]) for _ in range(4)]
+    assert runs["graph"] == pytest.approx(runs["eager"], rel=2e-3, abs=2e-3), runs
+    assert runs["segmented"] == pytest.approx(runs["eager"], rel=2e-3, abs=2e-3), runs
 
 
 @pytest.mark.parametrize("init", [False, True])
