@@ -694,6 +694,30 @@ class GraphedInference:
 
     def __init__(self, model: nn.Module, warm: int = 1):
         self.model, self.warm, self.calls, self.ready = model.eval(), warm, 0, False
+        self._pack_heads()
+
+    def _pack_heads(self):
+        """Re-home the pose-head parameters of every decoder layer in one buffer per head family, equally spaced: the heads
+        then run as batched launches (functional.HeadsFn) exactly as they do on the trainer's flat arena.  Values, names and
+        state_dict are untouched; only `.data` moves."""
+        for fam in ("translation_head", "rotation_head"):
+            heads = getattr(self.model, fam, None)
+            if heads is None or len(heads) < 2:
+                continue
+            per = [[p for _, p in h.named_parameters()] for h in heads]
+            if any(p.dtype != torch.float32 or not p.is_cuda for ps in per for p in ps):
+                continue
+            sizes = [(p.numel() + 63) // 64 * 64 for p in per[0]]           # 256-byte aligned slots
+            T = sum(sizes)
+            buf = torch.empty(len(per) * T, dtype=torch.float32, device=per[0][0].device)
+            with torch.no_grad():
+                for i, ps in enumerate(per):
+                    off = i * T
+                    for p, sz in zip(ps, sizes):
+                        view = buf[off: off + p.numel()].view(p.shape)
+                        view.copy_(p.data)
+                        p.data = view
+                        off += sz
 
     def _inputs(self, samples, targets):
         m = self.model
