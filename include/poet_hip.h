@@ -20,7 +20,7 @@
  *   poet_msda_fused_fwd / _bwd
  *       the same sampling with MSDeformAttn.forward's softmax over L*P logits and the
  *       loc = ref + offset/(W,H) arithmetic folded in (models/deformable_transformer.py:201,283).
- *   poet_gemm, poet_gemm_last_path
+ *   poet_gemm, poet_gemm_dw_list, poet_gemm_last_path
  *       every nn.Linear / 1x1 nn.Conv2d on the path (deformable_transformer.py:182,185,258,261,
  *       the 4 Linears of MSDeformAttn, nn.MultiheadAttention's in/out projections :253,
  *       pose_estimation_transformer.py:106-122,684-688) and their backward contractions.
@@ -112,6 +112,11 @@ typedef struct PoetGemmDesc {
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
 /* Which kernel family the calling thread's last successful poet_gemm launched (profiling aid: lets a caller attribute a
  * launch time to the kernel symbol a rocprofv3 trace shows). */
+/* dw[i][n_out, k_in] += dy[i][rows, n_out]^T x[i][rows, k_in] and (db != NULL, db[i] != NULL) db[i][n_out] += column sums of
+ * dy[i], for n <= 8 fp32 problems of ONE shape (rows <= 1024) whose operands live at unrelated addresses, in one launch:
+ * the weight / bias gradient of the same nn.Linear of every decoder layer (models/deformable_transformer.py:253-292). */
+int poet_gemm_dw_list(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n,
+                      int n_out, int k_in, int rows, int64_t ldy, int64_t ldx, int64_t ldw, void* stream);
 enum { POET_GEMM_PATH_NONE = 0, POET_GEMM_PATH_TILED = 1, POET_GEMM_PATH_STREAM = 2, POET_GEMM_PATH_DW = 3, POET_GEMM_PATH_SMALL = 4 };
 int poet_gemm_last_path(void);
 

@@ -133,7 +133,9 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
     z, mean, rstd = saved
     rows, d = z.shape
     dz = torch.empty_like(dy)
-    separate = p > 0 or z.dtype != dy.dtype
+    # (a deferred weight gradient reads dxo after this function returned: it must not alias dz, which the callers go on
+    # accumulating into)
+    separate = p > 0 or z.dtype != dy.dtype or ops.defer_small_dw.active is not None
     dxo = torch.empty_like(z) if separate else dz
     ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dxo if separate else None, ggamma, gbeta, rows, d, p, seed)
     ops.linear_dw(dxo, x_in, gW, rows=rows, db=gb)

@@ -465,3 +465,15 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     POET_LAUNCH_CHECK();
     return POET_OK;
 }
+
+extern "C" int poet_gemm_dw_list(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n,
+                                 int n_out, int k_in, int rows, int64_t ldy, int64_t ldx, int64_t ldw, void* stream) {
+    using namespace poet;
+    POET_CHECK(dy && x && dw && n >= 1 && n <= 8, POET_ERR_ARG, "poet_gemm_dw_list: 1..8 problems");
+    POET_CHECK(n_out > 0 && k_in > 0 && rows > 0 && rows <= 1024, POET_ERR_UNSUPPORTED, "poet_gemm_dw_list: rows %d not in 1..1024", rows);
+    for (int i = 0; i < n; ++i) POET_CHECK(dy[i] && x[i] && dw[i], POET_ERR_ARG, "poet_gemm_dw_list: null operand %d", i);
+    POET_CHECK(gemm_small_dw_list(dy, x, dw, db, n, n_out, k_in, rows, ldy, ldx, ldw, reinterpret_cast<hipStream_t>(stream)),
+               POET_ERR_UNSUPPORTED, "poet_gemm_dw_list: unsupported problem");
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}

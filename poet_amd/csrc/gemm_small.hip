@@ -100,10 +100,11 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmK p) {
 // One 16x16 tile per workgroup; wave w reduces rows [w K/4, (w+1) K/4), lane group g a quarter of those: at 320 rows a lane
 // issues 2 x 20 independent 4-byte loads (one memory round trip), 20 MFMAs, and the partial tiles are folded through
 // LDS.  The tile has one owner, so the accumulation onto the existing gradient is a plain read-modify-write.
-__global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
-    __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
-    __shared__ float reds[4][16];
-    const PoetGemmDesc& d = p.d;                                        // M = n1, N = n2, K = rows
+// P: anything with the PoetGemmDesc field names the body reads (`p.d`): the launch record itself, or the list kernel's
+// per-problem stand-in below
+template <typename P>
+__device__ __forceinline__ void small_dw_body(const P& p, float* red, float (*reds)[16]) {
+    const auto& d = p.d;                                                // M = n1, N = n2, K = rows
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int tn = (d.N + 15) >> 4, tile = blockIdx.x;
     const int m0 = (tile / tn) << 4, n0 = (tile % tn) << 4;
@@ -151,7 +152,62 @@ __global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
     if (do_sum && g == 0 && m0 + r < d.M) const_cast<float*>(d.bias)[zb * d.stride_bias + m0 + r] += reds[0][r] + reds[1][r] + reds[2][r] + reds[3][r];
 }
 
+__global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
+    __shared__ float reds[4][16];
+    small_dw_body(p, red, reds);
+}
+
+// ---- the same weight gradient for up to 8 problems of ONE shape whose operands live at unrelated addresses ----
+// (the dW + db of one Linear of every decoder layer: dY_l and X_l are separate allocations, so there is no batch
+// stride).  grid.y = problem; its pointers come out of the kernel-argument segment through a constant-address-space
+// pointer at a uniform offset (scalar loads; a run-time subscript into the by-value struct would go through scratch).
+constexpr int DW_LIST_MAX = 8;
+struct DwList {
+    const float* Y[DW_LIST_MAX];
+    const float* X[DW_LIST_MAX];
+    float* C[DW_LIST_MAX];
+    float* ysum[DW_LIST_MAX];
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+};
+struct DwOne {                                                          // the fields small_dw_body reads
+    struct {
+        const void *A, *B;
+        void* C;
+        const float* bias;
+        int M, N, K;
+        int64_t lda, ldb, ldc, strideA, strideB, strideC, stride_bias;
+    } d;
+};
+
+__global__ __launch_bounds__(256) void gemm_small_dw_list_kernel(const DwList l) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
+    __shared__ float reds[4][16];
+    typedef const __attribute__((address_space(4))) DwList* kernarg_t;
+    kernarg_t ka = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const int z = blockIdx.y;
+    DwOne one;
+    one.d.A = ka->Y[z]; one.d.B = ka->X[z]; one.d.C = ka->C[z]; one.d.bias = ka->ysum[z];
+    one.d.M = ka->M; one.d.N = ka->N; one.d.K = ka->K;
+    one.d.lda = ka->lda; one.d.ldb = ka->ldb; one.d.ldc = ka->ldc;
+    one.d.strideA = one.d.strideB = one.d.strideC = one.d.stride_bias = 0;      // (the body offsets by blockIdx.y * stride)
+    (void)l;
+    small_dw_body(one, red, reds);
+}
+
 }  // namespace
+
+bool gemm_small_dw_list(const float* const* Y, const float* const* X, float* const* C, float* const* ysum, int n, int n_out, int k_in,
+                        int rows, int64_t ldy, int64_t ldx, int64_t ldc, hipStream_t st) {
+    if (n < 1 || n > DW_LIST_MAX || rows > 1024) return false;
+    DwList l{};
+    for (int i = 0; i < n; ++i) { l.Y[i] = Y[i]; l.X[i] = X[i]; l.C[i] = C[i]; l.ysum[i] = ysum ? ysum[i] : nullptr; }
+    l.M = n_out; l.N = k_in; l.K = rows; l.lda = ldy; l.ldb = ldx; l.ldc = ldc;
+    const int tiles = ((n_out + 15) >> 4) * ((k_in + 15) >> 4);
+    hipLaunchKernelGGL(gemm_small_dw_list_kernel, dim3(tiles, n), dim3(256), 0, st, l);
+    return true;
+}
 
 bool gemm_small_try(const GemmK& p, hipStream_t st) {
     const PoetGemmDesc& d = p.d;

@@ -126,21 +126,23 @@ class DecoderFn(torch.autograd.Function):
         dmem = torch.empty((N * S, d), dtype=ctx.mem_dtype, device=dhs.device) if ctx.need_mem else None
         dx = None
         first = True
-        for i in reversed(range(cfg["n_layers"])):
-            pre = f"layers.{i}."
-            P_ = _pdict(names, params, pre)
-            dcur = dhs[i].view(N * Q, d)
-            if dx is not None:
-                ops.add(dx, dcur, dx)
-            else:
-                dx = dcur.clone()
-            dV = torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
-            dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV)
-            B.value_proj_bwd(dV, ctx.mem2, P_["cross_attn.value_proj.weight"], ctx.mask, N, S, M, D,
-                             G(pre + "cross_attn.value_proj.weight"), G(pre + "cross_attn.value_proj.bias"), dmem, not first,
-                             cfg.get("act"))
-            first = False
-            ctx.saved[i] = None
+        with ops.defer_small_dw() as deferred:           # the 320-row dW + db of all layers: one launch per Linear, at the end
+            for i in reversed(range(cfg["n_layers"])):
+                deferred.next_layer()
+                pre = f"layers.{i}."
+                P_ = _pdict(names, params, pre)
+                dcur = dhs[i].view(N * Q, d)
+                if dx is not None:
+                    ops.add(dx, dcur, dx)
+                else:
+                    dx = dcur.clone()
+                dV = torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
+                dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV)
+                B.value_proj_bwd(dV, ctx.mem2, P_["cross_attn.value_proj.weight"], ctx.mask, N, S, M, D,
+                                 G(pre + "cross_attn.value_proj.weight"), G(pre + "cross_attn.value_proj.bias"), dmem, not first,
+                                 cfg.get("act"))
+                first = False
+                ctx.saved[i] = None
         ops.SIDE.join()
         announce("1_decoder")
         dmemory = dmem.view(N, S, d) if ctx.need_mem else None

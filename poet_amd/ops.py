@@ -259,9 +259,70 @@ def _splitk_for(M, N, K):
     return max(1, min(-(-1024 // tiles), -(-K // (512 if big else 128))))
 
 
+class defer_small_dw:
+    """`with ops.defer_small_dw() as D:` around the backward of a STACK of identical layers (the decoder): the weight / bias
+    gradients of <= 1024-row fp32 Linears are recorded instead of launched (`D.next_layer()` before each layer), and
+    `flush()` issues ONE launch per Linear for all layers (poet_gemm_dw_list) -- nothing reads a weight gradient before the
+    optimiser, and the launches of these kernels cost more than their work.  Falls back to one launch per record when the
+    layers did not record the same sequence of shapes.  Off while the per-kernel profiler runs."""
+    active = None
+
+    def __enter__(self):
+        self.layers = []
+        if not PROFILE.on and os.environ.get("POET_NO_DEFERRED_DW", "0") in ("", "0"):
+            defer_small_dw.active = self
+        return self
+
+    def next_layer(self):
+        self.layers.append([])
+
+    def record(self, dy, x, dW, db, rows, ldy, ldx):
+        self.layers[-1].append((dy, x, dW, db, rows, ldy, ldx))
+
+    def flush(self):
+        layers, self.layers = self.layers, []
+        if not layers:
+            return
+        sig = lambda r: (tuple(r[2].shape), r[3] is None, r[4], r[5], r[6])
+        uniform = len(layers) <= 8 and all(len(l) == len(layers[0]) and [sig(r) for r in l] == [sig(r) for r in layers[0]] for l in layers)
+        if not uniform:
+            for l in layers:
+                for dy, x, dW, db, rows, ldy, ldx in l:
+                    _linear_dw_now(dy, x, dW, rows, ldy, ldx, db)
+            return
+        lib = _lib.load()
+        n = len(layers)
+        arr = C.c_void_p * n
+        for j in range(len(layers[0])):
+            recs = [l[j] for l in layers]
+            dy0, x0, dW0, db0, rows, ldy, ldx = recs[0]
+            n_out, k_in = dW0.shape
+            _lib.check(lib.poet_gemm_dw_list(arr(*[r[0].data_ptr() for r in recs]), arr(*[r[1].data_ptr() for r in recs]),
+                                             arr(*[r[2].data_ptr() for r in recs]),
+                                             None if db0 is None else arr(*[r[3].data_ptr() for r in recs]), n, n_out, k_in, rows,
+                                             ldy or n_out, ldx or k_in, k_in, _stream()), "poet_gemm_dw_list")
+
+    def __exit__(self, et, ev, tb):
+        defer_small_dw.active = None
+        if et is None:
+            self.flush()
+        return False
+
+
+def _linear_dw_now(dy, x, dW, rows, ldy, ldx, db):
+    n_out, k_in = dW.shape
+    SIDE.run(lambda: gemm(dy, x, dW, n_out, k_in, rows, lda=ldy or n_out, ldb=ldx or k_in, ldc=k_in, a_kmajor=True,
+                          b_kmajor=True, splitk=_splitk_for(n_out, k_in, rows), atomic=True, bias=db), dy, x)
+
+
 def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None, db=None):
     """dW[N_out, K_in] += dy[rows, N_out]^T @ x[rows, K_in]   (fp32 atomics, split-K over rows);
     db[N_out] += column sums of dy (optional: the bias gradient, fused into the same pass where possible)."""
+    D = defer_small_dw.active
+    if (D is not None and D.layers and rows <= 1024 and dy.dtype == torch.float32 and x.dtype == torch.float32
+            and dW.dtype == torch.float32 and dW.is_contiguous()):
+        D.record(dy, x, dW, db, rows, ldy, ldx)
+        return dW
     n_out, k_in = dW.shape
     SIDE.run(lambda: gemm(dy, x, dW, n_out, k_in, rows, lda=ldy or n_out, ldb=ldx or k_in, ldc=k_in, a_kmajor=True,
                           b_kmajor=True, splitk=_splitk_for(n_out, k_in, rows), atomic=True, bias=db), dy, x)

@@ -1,5 +1,6 @@
 """Kernel-level parity: every C-ABI kernel vs the CPU oracle / an fp32 torch statement of the
 same arithmetic, on seeded inputs.  -m gpu only."""
+import contextlib
 import math
 
 import numpy as np
@@ -709,3 +710,36 @@ def test_gemm_small_batched_matches_loop(ops):
         ops.linear_dw(dy[j], x[j], g2[j * sW: j * sW + n_out * k_in].view(n_out, k_in), rows=rows, db=d2[j * sb: j * sb + n_out])
     assert torch.equal(g1, g2) and torch.equal(d1, d2)
     assert float(g1[n_out * k_in: sW].abs().max()) == 0.0        # the gaps between the copies stay untouched
+
+
+def test_gemm_dw_list_matches_loop(ops):
+    """poet_gemm_dw_list (the dW + db of one Linear of every decoder layer in one launch, operands at unrelated addresses)
+    through `ops.defer_small_dw`: identical to one launch per layer, also with strided dY (a column slice) and without a
+    bias gradient; a record sequence that differs between layers falls back to single launches."""
+    rows, n_out, k_in, nl = 320, 256, 256, 5
+    res = {}
+    for mode in ("loop", "deferred"):
+        dys = [dev(_rand(rows, 3 * n_out, seed=10 + i)) for i in range(nl)]
+        xs = [dev(_rand(rows, k_in, seed=20 + i)) for i in range(nl)]
+        gW = [torch.ones(n_out, k_in, device="cuda") for _ in range(nl)]
+        gb = [torch.ones(n_out, device="cuda") for _ in range(nl)]
+        gW2 = [torch.zeros(n_out, k_in, device="cuda") for _ in range(nl)]
+        ctx = ops.defer_small_dw() if mode == "deferred" else contextlib.nullcontext()
+        with ctx as D:
+            for i in range(nl):
+                if D is not None:
+                    D.next_layer()
+                ops.linear_dw(dys[i][:, n_out: 2 * n_out], xs[i], gW[i], rows=rows, ldy=3 * n_out, db=gb[i])
+                ops.linear_dw(dys[i], xs[i], gW2[i], rows=rows, ldy=3 * n_out)
+        res[mode] = [t.cpu() for t in gW + gb + gW2]
+    for a, b in zip(res["loop"], res["deferred"]):
+        assert torch.equal(a, b)
+    dy3, x3 = _rand(rows, 3 * n_out, seed=13), _rand(rows, k_in, seed=23)
+    assert (res["deferred"][3] - (1 + dy3[:, n_out: 2 * n_out].t() @ x3)).abs().max().item() < 2e-3
+    # ragged record sequences -> fallback
+    g1, g2 = torch.zeros(n_out, k_in, device="cuda"), torch.zeros(64, k_in, device="cuda")
+    dy_a, dy_b, x_a = dev(_rand(rows, n_out, seed=31)), dev(_rand(rows, 64, seed=32)), dev(_rand(rows, k_in, seed=33))
+    with ops.defer_small_dw() as D:
+        D.next_layer(); ops.linear_dw(dy_a, x_a, g1, rows=rows)
+        D.next_layer(); ops.linear_dw(dy_b, x_a, g2, rows=rows)
+    assert (g1.cpu() - dy_a.cpu().t() @ x_a.cpu()).abs().max().item() < 2e-3 and (g2.cpu() - dy_b.cpu().t() @ x_a.cpu()).abs().max().item() < 2e-3
