@@ -292,8 +292,9 @@ def dec_layer_bwd(dt3, sv, P_, G, pre, ref_in, geom, N, Q, M, npts, dV):
     gWin, gbin = g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias")
     ops.linear_dw(dpk, sv["qk"], gWin[: 2 * d], rows=rows, ldy=3 * d, db=gbin[: 2 * d])
     ops.linear_dw(dpk[:, 2 * d:], sv["tgt"], gWin[2 * d:], rows=rows, ldy=3 * d, db=gbin[2 * d:])
-    ops.linear_dx(dpk, Win[: 2 * d], dtgt, rows=rows, ldy=3 * d, add_src=dtgt)
-    ops.linear_dx(dpk[:, 2 * d:], Win[2 * d:], dtgt, rows=rows, ldy=3 * d, add_src=dtgt)
+    # d(tgt) += d(q|k) W_qk + d(v) W_v: q = k = tgt + query_pos and v = tgt (deformable_transformer.py:277-278), and query_pos
+    # has no gradient consumer, so the two products collapse into ONE GEMM over the packed in_proj_weight (K = 3d)
+    ops.linear_dx(dpk, Win, dtgt, rows=rows, add_src=dtgt)
     return dtgt
 
 
