@@ -293,6 +293,8 @@ int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, i
                float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                const float* sqnorm, float max_norm, float grad_scale,
                const uint32_t* step_dev /* optional: the step count is read from this device word instead of `step` */,
+               const float* lr_scale /* optional: lr multiplier per block of 64 elements, ceil(n/64) floats (the 0.1x group of
+                                        main.py:41,253-271 inside one contiguous range) */,
                void* stream);
 /* *word += delta (single-thread kernel): advances the device-side dropout seed / Adam step between graph replays. */
 int poet_counter_add(uint32_t* word, uint32_t delta, void* stream);

@@ -83,12 +83,25 @@ def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate,
 
 
 # ---- (b) offsets/logits projection + fused deformable sampling ----------------------------------
+def _pair(so_w, like):
+    """(weight, bias, grad weight, grad bias) of the stacked [sampling_offsets | attention_weights] Linear when the arena
+    keeps the two adjacent (engine.ParamArena._link_projection_pairs); None otherwise (plain modules outside an arena)."""
+    pr = getattr(so_w, "_pair", None)
+    if pr is None:
+        return None
+    return (pr["w16"] if like.dtype == torch.bfloat16 else pr["w"]), pr["b"], pr["gw"], pr["gb"]
+
+
 def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P, act=None):
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
     OA = empty((rows, ldq), act or q2d.dtype, q2d)
-    ops.linear_fwd(q2d, Wb(so_w, q2d), so_b, OA, ldc=ldq)
-    ops.linear_fwd(q2d, Wb(aw_w, q2d), aw_b, OA[:, 2 * mlp:], ldc=ldq)
+    pr = _pair(so_w, q2d)
+    if pr is not None:                        # offsets | logits = ONE Linear over the adjacent parameters
+        ops.linear_fwd(q2d, pr[0], pr[1], OA)
+    else:
+        ops.linear_fwd(q2d, Wb(so_w, q2d), so_b, OA, ldc=ldq)
+        ops.linear_fwd(q2d, Wb(aw_w, q2d), aw_b, OA[:, 2 * mlp:], ldc=ldq)
     out = empty((rows, M * D), OA.dtype, q2d)
     ops.msda_fused_fwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq)
     return out, OA
@@ -102,15 +115,22 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
     ops.msda_fused_bwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
                        grid_queries=grid_queries)
     plain = seg_sums is None
-    ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldq, db=g_so_b if plain else None)
-    ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldq, db=g_aw_b if plain else None)
+    pr = _pair(so_w, dOA)
+    if pr is not None and pr[2].data_ptr() == g_so_w.data_ptr():      # (the gradient sink is the arena: stacked dW + db)
+        ops.linear_dw(dOA, q2d, pr[2], rows=rows, db=pr[3] if plain else None)
+    else:
+        ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldq, db=g_so_b if plain else None)
+        ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldq, db=g_aw_b if plain else None)
     if seg_sums is not None:      # per-level column sums (encoder): feeds both the biases and level_embed
         ops.colsum(dOA, ldq, seg_sums, N, Lq, ldq, geom.c_segs, geom.L)
         ops.colsum(seg_sums, ldq, g_so_b, 1, geom.L, 2 * mlp)
         ops.colsum(seg_sums[:, 2 * mlp:], ldq, g_aw_b, 1, geom.L, mlp)
     if dq is not None:
-        ops.linear_dx(dOA, Wb(so_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq if dq_accumulate else None)
-        ops.linear_dx(dOA[:, 2 * mlp:], Wb(aw_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq)
+        if pr is not None:                    # d(query) (+)= dOA [W_so ; W_aw]: one product with K = 3 M L P
+            ops.linear_dx(dOA, pr[0], dq, rows=rows, add_src=dq if dq_accumulate else None)
+        else:
+            ops.linear_dx(dOA, Wb(so_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq if dq_accumulate else None)
+            ops.linear_dx(dOA[:, 2 * mlp:], Wb(aw_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq)
 
 
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------

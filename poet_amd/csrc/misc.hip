@@ -436,9 +436,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, uint16_t* __restrict__ pb, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2s,
                                                     const float* __restrict__ sqnorm, float max_norm, float gscale,
-                                                    const uint32_t* __restrict__ step_dev) {
+                                                    const uint32_t* __restrict__ step_dev, const float* __restrict__ lr_scale) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (lr_scale) lr *= lr_scale[i >> 6];                    // per-64-element learning-rate multiplier (LR groups inside one range)
     if (step_dev) {                                          // graph replay: bias corrections from the device-side step
         const float t = (float)(*step_dev);
         bc1 = 1.f - powf(b1, t);
@@ -648,12 +649,12 @@ extern "C" int poet_sqnorm(const float* g, int64_t n, float* out, void* stream) 
 
 extern "C" int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, float lr, float beta1,
                           float beta2, float eps, float weight_decay, int step, const float* sqnorm, float max_norm,
-                          float grad_scale, const uint32_t* step_dev, void* stream) {
+                          float grad_scale, const uint32_t* step_dev, const float* lr_scale, void* stream) {
     POET_CHECK(p && g && m && v && n > 0 && (step >= 1 || step_dev), POET_ERR_ARG, "adamw: bad args");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2s, sqnorm, max_norm, grad_scale, step_dev);
+                       weight_decay, bc1, bc2s, sqnorm, max_norm, grad_scale, step_dev, lr_scale);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -47,27 +47,44 @@ class ParamArena:
                  weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, exclude=("transformer.reference_points",)):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not any(e in n for e in exclude)]
         is_proj = lambda n: any(k in n for k in proj_names)
-        main = sorted([(n, p) for n, p in named if not is_proj(n)], key=lambda t: _bucket_of(t[0]))
-        proj = [(n, p) for n, p in named if is_proj(n)]
+        # Order: by bucket (backward-completion order), named_parameters order inside a bucket -- except that the two
+        # query-side projections of every MSDeformAttn are laid out as [sampling_offsets.weight | attention_weights.weight]
+        # and [sampling_offsets.bias | attention_weights.bias]: their outputs are the two column blocks of ONE activation
+        # (offsets | logits), so with the parameters adjacent the pair is one (2+1)*M*L*P-wide Linear -- one GEMM forward,
+        # one for dX, one for dW -- while state_dict still sees two nn.Linear modules.  The 0.1x learning rate of
+        # sampling_offsets (main.py:41,253-271) is a per-64-element multiplier table instead of a separate arena range.
+        byname = dict(named)
+        order, taken = [], set()
+        for n, p in sorted(named, key=lambda t: _bucket_of(t[0])):
+            if n in taken:
+                continue
+            if n.endswith("sampling_offsets.weight"):
+                pre = n[: -len("sampling_offsets.weight")]
+                quad = [pre + "sampling_offsets.weight", pre + "attention_weights.weight", pre + "sampling_offsets.bias", pre + "attention_weights.bias"]
+                if all(q in byname for q in quad):
+                    for q in quad:
+                        order.append((q, byname[q]))
+                        taken.add(q)
+                    continue
+            order.append((n, p))
+            taken.add(n)
         dev = named[0][1].device
         self.entries, off = [], 0
         self.buckets: List[tuple] = []
         cur, start = None, 0
-        for n, p in main:
+        scale = []
+        for n, p in order:
             b = _bucket_of(n)
             if b != cur:
                 if cur is not None:
                     self.buckets.append((cur, start, off))
                 cur, start = b, off
             self.entries.append((n, p, off))
-            off += -(-p.numel() // ALIGN) * ALIGN
+            size = -(-p.numel() // ALIGN) * ALIGN
+            scale += [lr_proj_mult if is_proj(n) else 1.0] * (size // ALIGN)
+            off += size
         self.buckets.append((cur, start, off))
         self.n_main = off
-        for n, p in proj:
-            self.entries.append((n, p, off))
-            off += -(-p.numel() // ALIGN) * ALIGN
-        if off > self.n_main:
-            self.buckets.append(("4_proj", self.n_main, off))
         self.total = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -84,10 +101,30 @@ class ParamArena:
             p.grad = p._grad_view
             p._bf16 = self.flat_bf16[o:o + k].view(p.shape)
         self.refresh_shadow()
-        self.groups = [(0, self.n_main, lr), (self.n_main, self.total, lr * lr_proj_mult)]
+        self.lr_scale = torch.tensor(scale, dtype=torch.float32, device=dev)
+        self.groups = [(0, self.total, lr)]
+        self._link_projection_pairs()
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.step_count = 0
         self.world = 1
+
+    def _link_projection_pairs(self):
+        """Hang the stacked views of every adjacent [sampling_offsets | attention_weights] pair on the sampling_offsets
+        parameters (`_pair` = dict of fp32 / bf16 / gradient views of the (n_so + n_aw, d) weight and the bias)."""
+        pos = {n: (p, o) for n, p, o in self.entries}
+        for n, (w, o) in pos.items():
+            if not n.endswith("sampling_offsets.weight"):
+                continue
+            pre = n[: -len("sampling_offsets.weight")]
+            aw, sb, ab = (pos.get(pre + k) for k in ("attention_weights.weight", "sampling_offsets.bias", "attention_weights.bias"))
+            if aw is None or sb is None or ab is None:
+                continue
+            (aw_p, aw_o), (sb_p, sb_o), (ab_p, ab_o) = aw, sb, ab
+            if aw_o != o + w.numel() or ab_o != sb_o + sb_p.numel() or aw_p.shape[1] != w.shape[1]:
+                continue                                     # not adjacent (odd sizes): the two Linears stay separate launches
+            rows, d = w.shape[0] + aw_p.shape[0], w.shape[1]
+            w._pair = dict(w=self.flat[o:o + rows * d].view(rows, d), w16=self.flat_bf16[o:o + rows * d].view(rows, d),
+                           gw=self.grad[o:o + rows * d].view(rows, d), b=self.flat[sb_o:sb_o + rows], gb=self.grad[sb_o:sb_o + rows])
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow from the fp32 masters (after construction / load_state_dict)."""
@@ -113,7 +150,7 @@ class ParamArena:
             if b > a:
                 ops.adamw(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b], b - a, lr, self.betas[0], self.betas[1],
                           self.eps, self.weight_decay, self.step_count, sqnorm_buf=sq, max_norm=max_norm, grad_scale=gs,
-                          p_bf16=self.flat_bf16[a:b], step_dev=step_dev)
+                          p_bf16=self.flat_bf16[a:b], step_dev=step_dev, lr_scale=self.lr_scale[a // ALIGN:])
 
     def grad_norm(self) -> torch.Tensor:
         return torch.sqrt(self.sq[0]) / self.world

@@ -549,10 +549,11 @@ def sqnorm(g, out):
     _lib.check(lib.poet_sqnorm(_req(g, "g").data_ptr(), g.numel(), out.data_ptr(), _stream()), "poet_sqnorm")
 
 
-def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, sqnorm_buf=None, max_norm=0.0, grad_scale=1.0, p_bf16=None, step_dev=None):
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, sqnorm_buf=None, max_norm=0.0, grad_scale=1.0, p_bf16=None, step_dev=None,
+          lr_scale=None):
     lib = _lib.load()
     _lib.check(lib.poet_adamw(_req(p, "p").data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), n, lr, beta1, beta2,
-                              eps, wd, step, _ptr(sqnorm_buf), max_norm, grad_scale, _ptr(step_dev), _stream()), "poet_adamw")
+                              eps, wd, step, _ptr(sqnorm_buf), max_norm, grad_scale, _ptr(step_dev), _ptr(lr_scale), _stream()), "poet_adamw")
 
 
 def counter_add(word, delta=1):

@@ -50,14 +50,15 @@ def _worker(rank, world, port, q):
         tags = [b[0] for b in arena.buckets]
         from poet_amd.engine import SEGMENT_TAGS          # the graphed trainer announces exactly these after its backward segments
         assert list(SEGMENT_TAGS) == tags[: len(SEGMENT_TAGS)], (SEGMENT_TAGS, tags)
-        assert tags == ["0_heads", "1_decoder", "2_encoder", "3_input_proj", "4_proj"], tags
+        assert tags == ["0_heads", "1_decoder", "2_encoder", "3_input_proj"], tags
         assert arena.buckets[0][1] == 0 and arena.buckets[-1][2] == arena.total
         for (_, _, e), (_, s, _) in zip(arena.buckets[:-1], arena.buckets[1:]):
             assert e == s
-        # the 0.1x LR group is exactly the sampling_offsets tail
-        assert arena.groups[1][0] == arena.n_main and arena.groups[1][2] == pytest.approx(arena.groups[0][2] * 0.1)
-        proj = [n for n, _, o in arena.entries if o >= arena.n_main]
-        assert proj and all("sampling_offsets" in n for n in proj)
+        # the 0.1x LR group (main.py:41) is a per-64-element multiplier table over ONE range: 0.1 exactly on sampling_offsets
+        assert len(arena.groups) == 1 and arena.groups[0][:2] == (0, arena.total) and len(arena.lr_scale) == arena.total // 64
+        for n, p, o in arena.entries:
+            blk = arena.lr_scale[o // 64: (o + p.numel() + 63) // 64]
+            assert bool((blk == (0.1 if "sampling_offsets" in n else 1.0)).all()), n
         # parameters are views of the flat buffer
         p0 = model.input_proj.weight
         assert p0.data_ptr() >= arena.flat.data_ptr() and p0._grad_view.data_ptr() >= arena.grad.data_ptr()
