@@ -37,7 +37,7 @@ class ParamArena:
     * zero_grad is one memset, clip_grad_norm_ one reduction, AdamW one launch per LR group;
     * data parallel: buckets are contiguous arena ranges in backward-completion order, so each
       all-reduce is a single large RCCL call launched while the rest of backward still runs.
-    Layout: [default-LR params by bucket | 0.1x-LR params (sampling_offsets, main.py:41)].
+    Layout: parameters by bucket; the 0.1x learning rate of sampling_offsets (main.py:41) is a per-block multiplier table.
     Parameters that never receive a gradient in this configuration (transformer.reference_points.*
     in bbox mode; the reason the reference needs find_unused_parameters=True) stay outside, exactly as
     torch.optim.AdamW skips parameters whose .grad is None.
@@ -206,7 +206,7 @@ class BucketReducer:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
     def finish(self):
-        """Reduce whatever was not announced (e.g. the 0.1x-LR tail), then make the compute stream wait."""
+        """Reduce whatever was not announced, then make the compute stream wait."""
         if not self.active:
             return
         for name, a, b in self.arena.buckets:
@@ -583,7 +583,7 @@ class _Replay(torch.autograd.Function):
             if reduce:
                 t.reducer.bucket_done(tag)   # event on this stream -> all-reduce of the bucket on the comm stream
         if reduce:
-            t.reducer.finish()               # remaining ranges (0.1x-LR tail), then this stream waits for the comm stream
+            t.reducer.finish()               # any range not announced yet, then this stream waits for the comm stream
         t.g_opt.replay()
         return None, None
 

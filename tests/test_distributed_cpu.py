@@ -71,7 +71,7 @@ def _worker(rank, world, port, q):
             p._grad_view.fill_(float(rank + 1))
         for tag in ["0_heads", "1_decoder", "2_encoder", "3_input_proj"]:   # order of the autograd nodes' announce()
             announce(tag)
-        red.finish()                                       # reduces the un-announced 0.1x-LR tail too
+        red.finish()                                       # (nothing is left un-announced here; finish() also joins the comm stream)
         set_reducer(None)
         expect = float(sum(r + 1 for r in range(world)))
         for n, p, _ in arena.entries:
