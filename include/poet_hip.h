@@ -108,6 +108,12 @@ typedef struct PoetGemmDesc {
     int32_t out_mode, hm_M, hm_S, hm_D;
     const uint32_t* seed_dev; /* optional device word XOR-mixed into `seed` at run time: lets a captured hipGraph draw a
                                  fresh dropout mask on every replay (the host bumps the word between replays) */
+    int32_t b_split;       /* 1: B is an fp32 [N,K] weight used as bf16 hi + bf16 lo, lo = bf16(B - float(hi)): two
+                              v_mfma_f32_16x16x32_bf16 per fragment pair, so the WEIGHT enters with 16 mantissa bits while
+                              the activation operand stays plain bf16 (needs b_dtype f32, compute bf16, b_kmajor 0).  Weight
+                              rounding is the same perturbation for every token and does not average out downstream the way
+                              per-token activation rounding does: DESIGN.md section 3. */
+    int32_t reserved0;
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
 /* Which kernel family the calling thread's last successful poet_gemm launched (profiling aid: lets a caller attribute a

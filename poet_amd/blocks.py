@@ -61,15 +61,24 @@ def Wb(W, like):
     return W
 
 
+def Wf(W, like, split):
+    """Forward weight operand: (tensor, b_split).  bf16 policy with split weights: the fp32 master itself, which the GEMM
+    takes as bf16 hi + bf16 lo (PoetGemmDesc.b_split); otherwise whatever Wb gives."""
+    if split and like.dtype == torch.bfloat16 and W.dtype == torch.float32:
+        return W, True
+    return Wb(W, like), False
+
+
 def vstrides(M, S, D):
     """element strides (n, s, m) of a head-major (N,M,S,D) value map"""
     return (M * S * D, D, S * D)
 
 
 # ---- (a) value projection ------------------------------------------------------------------------
-def value_proj_fwd(inp2d, W, b, row_mask, N, S, M, D, act=None):
+def value_proj_fwd(inp2d, W, b, row_mask, N, S, M, D, act=None, split=False):
     V = empty((N, M, S, D), act or inp2d.dtype, inp2d)
-    ops.linear_fwd(inp2d, Wb(W, inp2d), b, V, row_mask=row_mask, head_major=(M, S, D))
+    Wt, sp = Wf(W, inp2d, split)
+    ops.linear_fwd(inp2d, Wt, b, V, row_mask=row_mask, head_major=(M, S, D), split=sp)
     return V
 
 
@@ -92,16 +101,21 @@ def _pair(so_w, like):
     return (pr["w16"] if like.dtype == torch.bfloat16 else pr["w"]), pr["b"], pr["gw"], pr["gb"]
 
 
-def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P, act=None):
+def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P, act=None, split=False):
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
     OA = empty((rows, ldq), act or q2d.dtype, q2d)
-    pr = _pair(so_w, q2d)
+    pr = getattr(so_w, "_pair", None)
     if pr is not None:                        # offsets | logits = ONE Linear over the adjacent parameters
-        ops.linear_fwd(q2d, pr[0], pr[1], OA)
+        Wt, sp = Wf(pr["w"], q2d, split)
+        if not sp:
+            Wt = pr["w16"] if q2d.dtype == torch.bfloat16 else pr["w"]
+        ops.linear_fwd(q2d, Wt, pr["b"], OA, split=sp)
     else:
-        ops.linear_fwd(q2d, Wb(so_w, q2d), so_b, OA, ldc=ldq)
-        ops.linear_fwd(q2d, Wb(aw_w, q2d), aw_b, OA[:, 2 * mlp:], ldc=ldq)
+        Wt, sp = Wf(so_w, q2d, split)
+        ops.linear_fwd(q2d, Wt, so_b, OA, ldc=ldq, split=sp)
+        Wt, sp = Wf(aw_w, q2d, split)
+        ops.linear_fwd(q2d, Wt, aw_b, OA[:, 2 * mlp:], ldc=ldq, split=sp)
     out = empty((rows, M * D), OA.dtype, q2d)
     ops.msda_fused_fwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq)
     return out, OA
@@ -134,12 +148,13 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
 
 
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
-def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed):
+def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False):
     """Returns (y, y16, saved): y in the residual-stream dtype; y16 = bf16 copy for the next GEMM when the stream is
     fp32 but the branch is bf16 (else y itself)."""
     rows, d = res.shape[0], W.shape[0]
     tmp = empty((rows, d), x_in.dtype, res)          # branch dtype
-    ops.linear_fwd(x_in, Wb(W, x_in), b, tmp)
+    Wt, sp = Wf(W, x_in, split)
+    ops.linear_fwd(x_in, Wt, b, tmp, split=sp)
     y = torch.empty_like(res)                        # residual-stream dtype
     z = torch.empty_like(tmp)
     mean = empty((rows,), torch.float32, res)
@@ -165,12 +180,13 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
 
 
 # ---- (d) FFN block -------------------------------------------------------------------------------
-def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None):
+def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False):
     """x: residual stream; x16: the GEMM operand copy of it (== x in the pure modes)."""
     rows = x.shape[0]
     Hd = empty((rows, W1.shape[0]), act or x.dtype, x)
-    ops.linear_fwd(x16, Wb(W1, x16), b1, Hd, act=1, drop_p=p_h, seed=seed_h)
-    y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o)
+    Wt, sp = Wf(W1, x16, split)
+    ops.linear_fwd(x16, Wt, b1, Hd, act=1, drop_p=p_h, seed=seed_h, split=sp)
+    y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split)
     return y, y16, (Hd, ln_saved)
 
 
@@ -193,7 +209,7 @@ ENC_PARAMS = ("self_attn.sampling_offsets.weight", "self_attn.sampling_offsets.b
               "linear2.weight", "linear2.bias", "norm2.weight", "norm2.bias")
 
 
-def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None):
+def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None, split=False):
     """src (N*S,d): residual stream; src16: its GEMM-operand copy (== src in the pure modes); pos (N*S,d).
     Returns (out, out16, saved)."""
     S, d = geom.S, src.shape[1]
@@ -203,14 +219,14 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
     q = empty(src.shape, src16.dtype, src)
     ops.add(src, pos, q)
     V = value_proj_fwd(src16, P_["self_attn.value_proj.weight"], P_["self_attn.value_proj.bias"], mask, N, S, M, D,
-                       act)
+                       act, split)
     out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
                            P_["self_attn.attention_weights.weight"], P_["self_attn.attention_weights.bias"],
-                           V, geom, ref, ref_bs, N, S, M, D, npts, act)
+                           V, geom, ref, ref_bs, N, S, M, D, npts, act, split)
     x1, x1_16, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
-                                 P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0])
+                                 P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0], split)
     x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                             P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act)
+                             P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split)
     saved = dict(src=src16, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1_16, ffn=ffn, seeds=seeds, pd=pd)
     return x2, x2_16, saved
 

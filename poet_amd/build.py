@@ -73,20 +73,27 @@ def _write_resources(reports, verbose):
     typically 2-3x slower and nothing else tells you: list them loudly and keep the full table next to the library."""
     rows = [k for rep in reports for k in rep]
     old = {}
+    rebuilt = {k["src"] for k in rows}
     if os.path.exists(RESOURCES):
         for line in open(RESOURCES):
             parts = line.rstrip("\n").split("\t")
-            if len(parts) == 6:
+            if len(parts) == 6 and parts[0] not in rebuilt:  # rows of a recompiled source are replaced wholesale (no stale kernels)
                 old[(parts[0], parts[1])] = line
     for k in rows:
         old[(k["src"], k["name"])] = f'{k["src"]}\t{k["name"]}\t{k["vgprs"]}\t{k["agprs"]}\t{k["scratch"]}\t{k["occ"]}\n'
     with open(RESOURCES, "w") as f:
         f.writelines(old[key] for key in sorted(old))
     bad = [k for k in rows if k["scratch"] > 0]
-    if bad and verbose:
-        print(f"[poet_amd.build] WARNING: {len(bad)} kernel(s) use scratch memory:", file=sys.stderr)
+    if bad:
+        print(f"[poet_amd.build] ERROR: {len(bad)} kernel(s) use scratch memory:", file=sys.stderr)
         for k in bad:
             print(f'    {k["src"]}: {k["name"]}  scratch={k["scratch"]} B/lane  vgprs={k["vgprs"]}', file=sys.stderr)
+        if os.environ.get("POET_ALLOW_SCRATCH", "0") in ("", "0"):
+            for k in bad:                                     # make the next build recompile (and re-check) the offender
+                obj = os.path.join(CSRC, k["src"].replace(".hip", ".o"))
+                if os.path.exists(obj):
+                    os.remove(obj)
+            raise RuntimeError("poet_amd.build: kernels with scratch memory (set POET_ALLOW_SCRATCH=1 to build anyway)")
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:

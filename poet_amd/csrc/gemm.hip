@@ -91,6 +91,22 @@ struct LoaderKC {
             }
         }
     }
+    // fp32 source used as bf16 hi + bf16 lo (PoetGemmDesc.b_split): two LDS images, `lo_off` bytes apart
+    __device__ __forceinline__ void store_split(char* __restrict__ lds, int lo_off, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * 256;
+            if (NCH % 256 == 0 || c < NCH) {
+                const int row = c / CPR, kc = c % CPR;
+                const float f0 = __uint_as_float(v[i].x), f1 = __uint_as_float(v[i].y), f2 = __uint_as_float(v[i].z), f3 = __uint_as_float(v[i].w);
+                const uint2 hi = make_uint2(pack_bf2(f0, f1), pack_bf2(f2, f3));
+                const uint2 lo = make_uint2(pack_bf2(f0 - __uint_as_float(hi.x << 16), f1 - __uint_as_float(hi.x & 0xffff0000u)),
+                                            pack_bf2(f2 - __uint_as_float(hi.y << 16), f3 - __uint_as_float(hi.y & 0xffff0000u)));
+                *reinterpret_cast<uint2*>(lds + row * PITCH + kc * 8) = hi;
+                *reinterpret_cast<uint2*>(lds + lo_off + row * PITCH + kc * 8) = lo;
+            }
+        }
+    }
 };
 
 // ---- K-major operand: src[k*ld + row]; an item = 4 consecutive k-rows x 8 rows, transposed at the LDS write ----
@@ -142,13 +158,19 @@ template <typename Src, typename CT, int R, int BKB, bool KM> struct LoaderSel;
 template <typename Src, typename CT, int R, int BKB> struct LoaderSel<Src, CT, R, BKB, false> { using type = LoaderKC<Src, CT, R, BKB>; };
 template <typename Src, typename CT, int R, int BKB> struct LoaderSel<Src, CT, R, BKB, true> { using type = LoaderKM<Src, CT, R, BKB>; };
 
-template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB, bool AKM, bool BKM>
+template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB, bool AKM, bool BKM, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
     constexpr int BK = BKB / sizeof(CT);
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int PITCH = BKB + 16;
     constexpr int KSTEPS = BKB / 64;
-    constexpr int STAGE = (BM + BN) * PITCH;
+    constexpr int STAGE = (BM + (SPLIT ? 2 : 1) * BN) * PITCH;     // SPLIT: B as two bf16 images (hi, lo) of the fp32 weight
+    static_assert(!SPLIT || (!BKM && sizeof(TB) == 4 && sizeof(CT) == 2), "b_split: fp32 [N,K] weight, bf16 MFMA");
+#define POET_STORE_B(dst)                                         \
+    do {                                                          \
+        if constexpr (SPLIT) lb.store_split((dst), BN * PITCH, tid); \
+        else lb.store((dst), tid);                                \
+    } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const PoetGemmDesc& d = p.d;
@@ -185,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
     la.load(A, d.lda, m0, d.M, kbeg, kend, p.a_vec, tid);
     lb.load(B, d.ldb, n0, d.N, kbeg, kend, p.b_vec, tid);
     la.store(smem, tid);
-    lb.store(smem + BM * PITCH, tid);
+    POET_STORE_B(smem + BM * PITCH);
     if (kbeg + BK < kend) {
         la.load(A, d.lda, m0, d.M, kbeg + BK, kend, p.a_vec, tid);
         lb.load(B, d.ldb, n0, d.N, kbeg + BK, kend, p.b_vec, tid);
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
         if (k0 + BK < kend) {
             char* nxt = smem + (buf ^ 1) * STAGE;
             la.store(nxt, tid);
-            lb.store(nxt + BM * PITCH, tid);
+            POET_STORE_B(nxt + BM * PITCH);
             if (k0 + 2 * BK < kend) {
                 la.load(A, d.lda, m0, d.M, k0 + 2 * BK, kend, p.a_vec, tid);
                 lb.load(B, d.ldb, n0, d.N, k0 + 2 * BK, kend, p.b_vec, tid);
@@ -224,6 +246,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
                     if constexpr (sizeof(CT) == 2) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                        if constexpr (SPLIT) {
+                            const uint4 blo = *reinterpret_cast<const uint4*>(Bs + (BN + wn * WN + j * 16 + frow) * PITCH + ks * 64 + fchunk * 16);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, blo), acc[i][j], 0, 0, 0);
+                        }
                     } else {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
@@ -329,10 +356,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
     }
 }
 
-template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB, bool AKM, bool BKM>
+template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB, bool AKM, bool BKM, bool SPLIT = false>
 static void launch_one(const GemmK& p, hipStream_t st) {
-    constexpr int LDS = 2 * (BM + BN) * (BKB + 16);
-    auto kern = gemm_kernel<TA, TB, TC, CT, BM, BN, BKB, AKM, BKM>;
+    constexpr int LDS = 2 * (BM + (SPLIT ? 2 : 1) * BN) * (BKB + 16);
+    auto kern = gemm_kernel<TA, TB, TC, CT, BM, BN, BKB, AKM, BKM, SPLIT>;
     static bool attr_set = false;          // per instantiation; idempotent, so a race between host threads is benign
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -346,6 +373,13 @@ static void launch_one(const GemmK& p, hipStream_t st) {
 template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB>
 static void launch_layout(const GemmK& p, hipStream_t st) {
     const int key = p.d.a_kmajor * 2 + p.d.b_kmajor;
+    if constexpr (sizeof(TB) == 4 && sizeof(CT) == 2 && BM >= 64) {
+        if (p.d.b_split) {                          // (validated by poet_gemm: b_kmajor == 0)
+            if (p.d.a_kmajor) launch_one<TA, TB, TC, CT, BM, BN, BKB, true, false, true>(p, st);
+            else launch_one<TA, TB, TC, CT, BM, BN, BKB, false, false, true>(p, st);
+            return;
+        }
+    }
     switch (key) {
         case 0: launch_one<TA, TB, TC, CT, BM, BN, BKB, false, false>(p, st); break;
         case 1: launch_one<TA, TB, TC, CT, BM, BN, BKB, false, true>(p, st); break;
@@ -407,6 +441,9 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.out_mode == 1) POET_CHECK(d.hm_M > 0 && d.hm_S > 0 && d.hm_D > 0 && d.hm_M * d.hm_D == d.N, POET_ERR_ARG, "poet_gemm: head-major dims");
+    if (d.b_split)
+        POET_CHECK(d.b_dtype == POET_F32 && d.compute == POET_BF16 && !d.b_kmajor && !atomic, POET_ERR_ARG,
+                   "poet_gemm: b_split needs an fp32 [N,K] weight, bf16 compute, no split-K");
     const int tcs = tile_choice(d);
     const int BKB = tcs == 0 ? 128 : (tcs == 3 ? 1024 : 256);
     const int BK = BKB / (d.compute == POET_BF16 ? 2 : 4);

@@ -63,13 +63,18 @@ template <> struct run8<float> {
     }
 };
 
-template <typename TC, int KIND, bool WKM, int FM, int NTH>
-__global__ __launch_bounds__(NTH, 2) void gemm_ws_kernel(const GemmK p) {
-    constexpr int BN = 128, KS = 8, NWV = NTH / 64;
+// SPLIT (PoetGemmDesc.b_split): W arrives as the fp32 master and lives in LDS as TWO bf16 images, hi = bf16(W) and
+// lo = bf16(W - hi); every activation fragment meets both (two MFMAs), so the weight carries 16 mantissa bits at no extra HBM
+// traffic -- the matrix pipe of these HBM-bound kernels is ~25 % busy without it.
+template <typename TC, int KIND, bool WKM, int FM, int NTH, bool SPLIT = false, int BN = 128>
+__global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(const GemmK p) {
+    constexpr int KS = 8, NWV = NTH / 64;
     constexpr int K = KS * 32, PITCH = K * 2 + 16, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
+    constexpr int LO = SPLIT ? BN * PITCH : 0;                           // byte offset of the lo image
     constexpr bool GATE = KIND & WS_GATE, ADD = KIND & WS_ADD, MASK = KIND & WS_MASK;
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [BN][PITCH] bf16 rows of W (permuted) | bias[BN] f32
-    float* sbias = reinterpret_cast<float*>(smem + BN * PITCH);
+    static_assert(!SPLIT || !WKM, "b_split is a forward ([N,K] weight) feature");
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [BN][PITCH] bf16 rows of W (permuted) (| lo image) | bias[BN] f32
+    float* sbias = reinterpret_cast<float*>(smem + (SPLIT ? 2 : 1) * BN * PITCH);
     const PoetGemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int frow = lane & 15, g = lane >> 4;
@@ -101,7 +106,29 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ws_kernel(const GemmK p) {
     // ---- stationary W slice -> LDS (once) ----
     const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B);
     // (all of a thread's requests are in flight before its first LDS store: one exposed latency, not one per chunk)
-    if constexpr (!WKM) {                                               // W[n][k], k contiguous
+    if constexpr (SPLIT) {                                              // fp32 W[n][k] -> hi | lo images
+        const float* Bf = reinterpret_cast<const float*>(d.B);
+        constexpr int CPR = K / 4, NCH = BN * CPR, GRP = 8;            // 16-B chunks of 4 floats, 8 in flight per thread
+        static_assert(NCH % (NTH * GRP) == 0, "split W staging");
+#pragma unroll 1
+        for (int base = 0; base < NCH; base += NTH * GRP) {
+            float4 wv[GRP];
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                wv[i] = *reinterpret_cast<const float4*>(Bf + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                const uint2 hi = make_uint2(pack_bf2(wv[i].x, wv[i].y), pack_bf2(wv[i].z, wv[i].w));
+                const uint2 lo = make_uint2(pack_bf2(wv[i].x - __uint_as_float(hi.x << 16), wv[i].y - __uint_as_float(hi.x & 0xffff0000u)),
+                                            pack_bf2(wv[i].z - __uint_as_float(hi.y << 16), wv[i].w - __uint_as_float(hi.y & 0xffff0000u)));
+                *reinterpret_cast<uint2*>(smem + rho * PITCH + kc * 8) = hi;
+                *reinterpret_cast<uint2*>(smem + LO + rho * PITCH + kc * 8) = lo;
+            }
+        }
+    } else if constexpr (!WKM) {                                        // W[n][k], k contiguous
         constexpr int CPR = K / 8, NIT = BN * CPR / NTH;
         uint4 wv[NIT];
 #pragma unroll
@@ -191,6 +218,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ws_kernel(const GemmK p) {
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm)
                     acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acc[fm][jn], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    const bf16x8_t wlo = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl + LO + jn * 16 * PITCH + kk * 64));
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm)
+                        acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acc[fm][jn], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) a[fm][kk] = *reinterpret_cast<const uint4*>(qn[fm] + kk * 32);
@@ -267,10 +300,10 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ws_kernel(const GemmK p) {
     if (u < u_hi) iteration(u, std::true_type{});
 }
 
-template <typename TC, int KIND, bool WKM, int FM, int NTH>
+template <typename TC, int KIND, bool WKM, int FM, int NTH, bool SPLIT = false, int BN = 128>
 void ws_launch_cfg(const GemmK& p, int nblocks, hipStream_t st) {
-    constexpr int LDS = 128 * (8 * 64 + 16) + 128 * 4;
-    auto kern = gemm_ws_kernel<TC, KIND, WKM, FM, NTH>;
+    constexpr int LDS = (SPLIT ? 2 : 1) * BN * (8 * 64 + 16) + BN * 4;
+    auto kern = gemm_ws_kernel<TC, KIND, WKM, FM, NTH, SPLIT, BN>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -285,9 +318,29 @@ void ws_launch_cfg(const GemmK& p, int nblocks, hipStream_t st) {
 // halves the LDS traffic that would otherwise bound them (measured at M = 102080: N = 256 31.3 -> 29.3 us with 16 rows,
 // N = 1024 90 -> 105 us).
 template <typename TC, int KIND, bool WKM>
-void ws_launch(const GemmK& p, int nblocks, hipStream_t st) {
-    if (p.d.N <= 256) ws_launch_cfg<TC, KIND, WKM, 1, 512>(p, nblocks, st);
-    else ws_launch_cfg<TC, KIND, WKM, 2, 256>(p, nblocks, st);
+bool ws_launch(const GemmK& p, int nblocks, hipStream_t st) {
+    if (p.d.N <= 256) { ws_launch_cfg<TC, KIND, WKM, 1, 512>(p, nblocks, st); return true; }
+    // two row fragments per wave + prefetched epilogue operands: the f32-residual / gate+residual forms would spill
+    // (scratch memory = 2-3x slower than the tiled kernel they would replace); they do not occur on the path
+    if constexpr ((sizeof(TC) == 4 && (KIND & (WS_ADD | WS_GATE))) || KIND == (WS_GATE | WS_ADD)) return false;
+    else { ws_launch_cfg<TC, KIND, WKM, 2, 256>(p, nblocks, st); return true; }
+}
+
+// b_split shapes.  The two weight images take 135 KB of LDS for a 128-column slice: ONE workgroup per CU with twice the
+// waves keeps the occupancy of the plain kernel (wide outputs: 8 waves; narrow: 16 waves need <= 128 VGPRs -- variant 0),
+// or a 64-column slice keeps two workgroups per CU at twice the A re-reads through L2 (variant 1, default; variant 2 =
+// one 8-wave workgroup per CU on a 128-column slice).  POET_WS_SPLIT_NARROW selects the narrow-output variant (A/B aid).
+int ws_blocks(int N, int BN, int wg_per_cu);
+template <typename TC, int KIND>
+bool ws_launch_split(const GemmK& p, hipStream_t st) {
+    static const int narrow = [] { const char* e = getenv("POET_WS_SPLIT_NARROW"); return e ? atoi(e) : 1; }();
+    if (p.d.N <= 256) {
+        if (narrow == 2) ws_launch_cfg<TC, KIND, false, 1, 512, true, 128>(p, ws_blocks(p.d.N, 128, 1), st);
+        else ws_launch_cfg<TC, KIND, false, 1, 512, true, 64>(p, ws_blocks(p.d.N, 64, 2), st);
+        return true;
+    }
+    if constexpr (sizeof(TC) == 4 && (KIND & (WS_ADD | WS_GATE))) return false;
+    else { ws_launch_cfg<TC, KIND, false, 2, 512, true, 128>(p, ws_blocks(p.d.N, 128, 1), st); return true; }
 }
 
 // the epilogue kinds that occur on the path: forward {plain, +residual, +row mask}, input gradient {plain, ReLU gate,
@@ -296,20 +349,28 @@ template <typename TC>
 bool ws_kind(const GemmK& p, int nblocks, hipStream_t st) {
     const PoetGemmDesc& d = p.d;
     const int kind = (d.gate_ref ? WS_GATE : 0) | (d.add_src ? WS_ADD : 0) | (d.row_mask ? WS_MASK : 0);
+    if (d.b_split) {
+        switch (kind) {
+            case 0: return ws_launch_split<TC, 0>(p, st);
+            case WS_ADD: return ws_launch_split<TC, WS_ADD>(p, st);
+            case WS_MASK: return ws_launch_split<TC, WS_MASK>(p, st);
+            default: return false;
+        }
+    }
     if (!d.b_kmajor) {
         switch (kind) {
-            case 0: ws_launch<TC, 0, false>(p, nblocks, st); return true;
-            case WS_ADD: ws_launch<TC, WS_ADD, false>(p, nblocks, st); return true;
-            case WS_MASK: ws_launch<TC, WS_MASK, false>(p, nblocks, st); return true;
+            case 0: return ws_launch<TC, 0, false>(p, nblocks, st);
+            case WS_ADD: return ws_launch<TC, WS_ADD, false>(p, nblocks, st);
+            case WS_MASK: return ws_launch<TC, WS_MASK, false>(p, nblocks, st);
             default: return false;
         }
     }
     switch (kind) {
-        case 0: ws_launch<TC, 0, true>(p, nblocks, st); return true;
-        case WS_GATE: ws_launch<TC, WS_GATE, true>(p, nblocks, st); return true;
-        case WS_ADD: ws_launch<TC, WS_ADD, true>(p, nblocks, st); return true;
+        case 0: return ws_launch<TC, 0, true>(p, nblocks, st);
+        case WS_GATE: return ws_launch<TC, WS_GATE, true>(p, nblocks, st);
+        case WS_ADD: return ws_launch<TC, WS_ADD, true>(p, nblocks, st);
         case WS_GATE | WS_ADD:
-            if constexpr (sizeof(TC) == 2) { ws_launch<TC, WS_GATE | WS_ADD, true>(p, nblocks, st); return true; }
+            if constexpr (sizeof(TC) == 2) return ws_launch<TC, WS_GATE | WS_ADD, true>(p, nblocks, st);
             return false;                                               // f32: 128 VGPRs of prefetched epilogue operands
         default: return false;
     }
@@ -326,15 +387,23 @@ int device_cus() {
     return cus;
 }
 
+int ws_blocks(int N, int BN, int wg_per_cu) {
+    const int NT = N / BN;
+    int per = wg_per_cu * device_cus() / 8;                             // workgroups per XCD
+    if (per < NT) per = NT;
+    return per * 8;
+}
+
 }  // namespace
 
 bool gemm_ws_try(const GemmK& p, hipStream_t st) {
     const PoetGemmDesc& d = p.d;
     static const int disabled = [] { const char* e = getenv("POET_GEMM_NO_WS"); return e && atoi(e) ? 1 : 0; }();
     if (disabled) return false;
-    if (d.compute != POET_BF16 || d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || d.a_kmajor || d.batch != 1 || d.splitk != 1 ||
-        d.atomic || d.A2)
+    if (d.compute != POET_BF16 || d.a_dtype != POET_BF16 || d.b_dtype != (d.b_split ? POET_F32 : POET_BF16) || d.a_kmajor || d.batch != 1 ||
+        d.splitk != 1 || d.atomic || d.A2)
         return false;
+    if (d.b_split && ((reinterpret_cast<uintptr_t>(d.B) & 15) || (d.ldb & 3))) return false;
     if (d.K != 256 || d.N % 128 != 0 || d.M < 4096) return false;
     if (!p.a_vec || !p.b_vec || !p.c_vec) return false;
     if (d.out_mode == 1 && d.hm_D % 8 != 0) return false;

@@ -16,6 +16,8 @@ from torch import nn
 from . import ops
 
 ALIGN = 64   # elements (256 B): every parameter starts on a 16-B-aligned, vector-friendly offset
+# parameter-name prefixes of the hot path (pose_estimation_transformer.py:85-144 heads / input_proj; the transformer)
+HOT_PREFIXES = ("input_proj.", "transformer.", "translation_head", "rotation_head")
 
 
 def _bucket_of(name: str) -> str:
@@ -46,6 +48,13 @@ class ParamArena:
     def __init__(self, model: nn.Module, lr=2e-4, lr_proj_mult=0.1, proj_names=("reference_points", "sampling_offsets"),
                  weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, exclude=("transformer.reference_points",)):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not any(e in n for e in exclude)]
+        # Only the hot path's own parameters live here (their gradients are written by the HIP backward programs).  Anything
+        # else that is trainable -- e.g. a real backbone, which the reference trains at lr_backbone (main.py:253-271) -- would
+        # be weight-decayed every step without ever receiving a gradient: refuse it instead of mis-training it silently.
+        stray = [n for n, _ in named if not n.startswith(HOT_PREFIXES)]
+        if stray:
+            raise ValueError(f"ParamArena: trainable parameters outside the hot path (freeze them or give them their own optimiser): {stray[:4]}"
+                             f"{' ...' if len(stray) > 4 else ''}")
         is_proj = lambda n: any(k in n for k in proj_names)
         # Order: by bucket (backward-completion order), named_parameters order inside a bucket -- except that the two
         # query-side projections of every MSDeformAttn are laid out as [sampling_offsets.weight | attention_weights.weight]
@@ -101,12 +110,47 @@ class ParamArena:
             p.grad = p._grad_view
             p._bf16 = self.flat_bf16[o:o + k].view(p.shape)
         self.refresh_shadow()
-        self.lr_scale = torch.tensor(scale, dtype=torch.float32, device=dev)
+        # Learning rate = base_lr (a host scalar baked into captured graphs) x this per-64-element DEVICE table: the table
+        # carries the 0.1x group of sampling_offsets AND the schedule (set_lr rescales it in place, so a replayed graph
+        # follows a StepLR exactly like the eager path does; main.py:278 lr_scheduler.step()).
+        self.lr_scale_base = torch.tensor(scale, dtype=torch.float32, device=dev)
+        self.lr_scale = self.lr_scale_base.clone()
+        self.base_lr = self.lr = float(lr)
         self.groups = [(0, self.total, lr)]
         self._link_projection_pairs()
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.step_count = 0
+        self.step_word = torch.zeros(1, dtype=torch.int32, device=dev)       # device copy of step_count (graph replays bump it)
         self.world = 1
+        # model.load_state_dict copies into the fp32 arena views in place; the bf16 operand shadow must follow
+        model.register_load_state_dict_post_hook(lambda module, incompatible: self.refresh_shadow())
+
+    def set_lr(self, lr: float):
+        """Scheduler entry (the reference's StepLR, main.py:277-278): effective from the next optimiser launch, eager or
+        replayed.  The sampling_offsets group keeps its 0.1x ratio."""
+        self.lr = float(lr)
+        self.lr_scale.copy_(self.lr_scale_base * (self.lr / self.groups[0][2]))
+
+    def step_lr(self, epoch: int, lr_drop: int, gamma: float = 0.1):
+        """torch.optim.lr_scheduler.StepLR(optimizer, lr_drop) evaluated at `epoch` (main.py:277)."""
+        self.set_lr(self.base_lr * gamma ** (epoch // lr_drop))
+
+    def state_dict(self):
+        """What the reference checkpoints as 'optimizer' + 'lr_scheduler' (main.py:293-301,364-372): Adam moments, step, lr."""
+        if self.step_word.is_cuda:
+            self.step_count = max(self.step_count, int(self.step_word.item()))
+        return {"m": self.m.detach().cpu().clone(), "v": self.v.detach().cpu().clone(), "step": self.step_count,
+                "lr": self.lr, "base_lr": self.base_lr, "names": [n for n, _, _ in self.entries]}
+
+    def load_state_dict(self, sd):
+        if list(sd["names"]) != [n for n, _, _ in self.entries]:
+            raise ValueError("ParamArena.load_state_dict: parameter layout differs from the checkpoint's")
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
+        self.step_word.fill_(self.step_count)
+        self.base_lr = float(sd["base_lr"])
+        self.set_lr(float(sd["lr"]))
+        self.refresh_shadow()
 
     def _link_projection_pairs(self):
         """Hang the stacked views of every adjacent [sampling_offsets | attention_weights] pair on the sampling_offsets
@@ -613,6 +657,9 @@ class GraphedTrainer(Trainer):
         if segment_backward is None:         # per-bucket backward graphs: needed (only) to overlap all-reduces with backward
             segment_backward = (self.reducer is not None and self.reducer.active) or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
         self.segment_backward = bool(segment_backward)
+        if not self.segment_backward and self.reducer is not None and self.reducer.active:
+            raise ValueError("GraphedTrainer: world > 1 needs segment_backward=True (the single backward graph contains no "
+                             "all-reduce: the replicas would drift apart silently)")
 
     def _static_inputs(self, samples, targets):
         m = self.model
@@ -637,7 +684,8 @@ class GraphedTrainer(Trainer):
         self.s_cls = self.ring[0]["cls"].to(dev)
         self.s_valid = self.ring[0]["valid"].to(dev)
         self.seed_word = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.step_word = torch.full((1,), self.arena.step_count, dtype=torch.int32, device=dev)
+        self.step_word = self.arena.step_word
+        self.step_word.fill_(self.arena.step_count)
         self.handle = torch.zeros(1, device=dev, requires_grad=True)
         ops.SEED_DEV[0] = self.seed_word
         set_reducer(None)
@@ -703,6 +751,8 @@ class GraphedTrainer(Trainer):
             if f.tensors.data_ptr() != sf.data_ptr():
                 sf.copy_(f.tensors, non_blocking=True)
             sm.copy_(f.mask.view(torch.uint8) if f.mask.dtype == torch.bool else f.mask, non_blocking=True)
+        im = samples.mask                                   # the extra levels' masks / valid ratios / sine encodings derive from it
+        self.s_imask.copy_(im.view(torch.uint8) if im.dtype == torch.bool else im, non_blocking=True)
         slot = self.ring[self.ring_pos]
         self.ring_pos = (self.ring_pos + 1) % len(self.ring)
         if slot["ev"] is not None:

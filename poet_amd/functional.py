@@ -56,7 +56,7 @@ class EncoderFn(torch.autograd.Function):
         for i in range(cfg["n_layers"]):
             P_ = _pdict(names, params, f"layers.{i}.")
             x, x16, sv = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
-                                         cfg["training"], cfg.get("act"))
+                                         cfg["training"], cfg.get("act"), cfg.get("split", False))
             saved.append(sv)
         ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
         ctx.ref, ctx.mask, ctx.level_embed, ctx.shape = ref, mask, level_embed, (N, S, d)
@@ -105,7 +105,7 @@ class DecoderFn(torch.autograd.Function):
         for i in range(cfg["n_layers"]):
             P_ = _pdict(names, params, f"layers.{i}.")
             V = B.value_proj_fwd(mem2, P_["cross_attn.value_proj.weight"], P_["cross_attn.value_proj.bias"], mask, N, S, M, D,
-                                 cfg.get("act"))
+                                 cfg.get("act"), cfg.get("split", False))
             x, sv = B.dec_layer_fwd(x, qp, V, P_, ref_in, geom, N, Q, M, cfg["P"], cfg["p"], cfg["training"])
             ops.cast(x, hs[i])
             saved.append(sv)
@@ -321,7 +321,8 @@ class InputProjFn(torch.autograd.Function):
         N = feats[0].shape[0]
         d = params[0].shape[0]
         S = geom.S
-        act_dtype, stream_dtype = dtypes          # branch (conv output) dtype, residual-stream dtype
+        act_dtype, stream_dtype = dtypes[:2]      # branch (conv output) dtype, residual-stream dtype
+        split = len(dtypes) > 2 and bool(dtypes[2]) and act_dtype == torch.bfloat16     # fp32 conv weights as bf16 hi + lo
         src = torch.empty((N, S, d), dtype=stream_dtype, device=feats[0].device)
         saved = []
         for lvl in range(geom.L):
@@ -333,7 +334,8 @@ class InputProjFn(torch.autograd.Function):
             if lvl < len(feats):
                 f = feats[lvl].contiguous()
                 C = f.shape[1]
-                ops.gemm(f, W, pre, HW, d, C, lda=HW, ldb=C, ldc=d, a_kmajor=True, bias=b, batch=N, strideA=C * HW, strideC=HW * d)
+                ops.gemm(f, W, pre, HW, d, C, lda=HW, ldb=C, ldc=d, a_kmajor=True, bias=b, batch=N, strideA=C * HW, strideC=HW * d,
+                         b_split=split, compute=ops.BF16 if split else None)
                 col = None
             else:
                 if lvl == len(feats):
@@ -345,7 +347,7 @@ class InputProjFn(torch.autograd.Function):
                 C, Hi, Wi = inp.shape[1:]
                 col = torch.empty((N * HW, C * 9), dtype=act_dtype, device=src.device)
                 ops.im2col3x3s2(inp, col, N, C, Hi, Wi, H, Wd)
-                ops.linear_fwd(col, W.view(d, C * 9), b, pre)
+                ops.linear_fwd(col, W.view(d, C * 9), b, pre, split=split)
                 f = None
             stats = torch.empty((N, n_groups, 2), dtype=torch.float32, device=src.device)
             ops.groupnorm_fwd(pre, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S)

@@ -159,10 +159,10 @@ class DeformableTransformerEncoder(nn.Module):
         self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
         self.num_layers = num_layers
 
-    def run(self, src, pos, level_embed, ref, mask_u8, geom: LevelGeom, act=None):
+    def run(self, src, pos, level_embed, ref, mask_u8, geom: LevelGeom, act=None, split=False):
         l0 = self.layers[0]
         cfg = dict(M=l0.self_attn.n_heads, P=l0.self_attn.n_points, p=l0.dropout1.p, training=self.training,
-                   n_layers=self.num_layers, act=act)
+                   n_layers=self.num_layers, act=act, split=split)
         names, params = _named(self.layers, "layers.")
         return Fn.EncoderFn.apply(src, pos, level_embed, ref, mask_u8, geom, cfg, names, *params)
 
@@ -194,10 +194,10 @@ class DeformableTransformerDecoder(nn.Module):
         self.bbox_embed = None
         self.class_embed = None
 
-    def run(self, memory, memory16, tgt, qpos, ref_in, mask_u8, geom: LevelGeom, act=None):
+    def run(self, memory, memory16, tgt, qpos, ref_in, mask_u8, geom: LevelGeom, act=None, split=False):
         l0 = self.layers[0]
         cfg = dict(M=l0.cross_attn.n_heads, P=l0.cross_attn.n_points, p=l0.dropout1.p, training=self.training,
-                   n_layers=self.num_layers, act=act)
+                   n_layers=self.num_layers, act=act, split=split)
         names, params = _named(self.layers, "layers.")
         return Fn.DecoderFn.apply(memory, memory16, tgt, qpos, ref_in, mask_u8, geom, cfg, names, *params)
 
@@ -225,11 +225,18 @@ class DeformableTransformer(nn.Module):
                  a GEMM / the sampling kernel in the ENCODER (offsets+logits, value maps, sampled output, FFN
                  hidden, pre-norm branch), fp32 for the residual stream (LayerNorm outputs) and the whole
                  320-row decoder/head stream (only the value maps it samples are bf16); fp32 accumulate everywhere.
-        'bf16_pure' : residual stream in bf16 too (fastest, misses the 1e-2 bound at full size: measured 1.04e-2)."""
+                 FORWARD weights enter every 102k-row GEMM (input_proj, the encoder's four Linears per layer, the decoder's
+                 value projections) as bf16 hi + bf16 lo of the fp32 master (two MFMAs per fragment pair, PoetGemmDesc.b_split):
+                 weight rounding is one fixed perturbation shared by all 6380 tokens of an image, so unlike per-token
+                 activation rounding it does not average out in the decoder's sampling -- it was 4/5 of the rotation error.
+        'bf16_nosplit' : the same with single bf16 weights (the round-1 policy; A/B and ablation).
+        'bf16_pure' : residual stream in bf16 too, single bf16 weights (fastest, misses the 1e-2 bound at full size)."""
+        self.split_w = False
         if mode == "fp32":
             self.act_dtype, self.stream_dtype = torch.float32, torch.float32
-        elif mode == "bf16":
+        elif mode in ("bf16", "bf16_nosplit"):
             self.act_dtype, self.stream_dtype = torch.bfloat16, torch.float32
+            self.split_w = mode == "bf16"
         elif mode == "bf16_pure":
             self.act_dtype, self.stream_dtype = torch.bfloat16, torch.bfloat16
         else:
@@ -261,11 +268,11 @@ class DeformableTransformer(nn.Module):
         mask_flat = torch.cat([m.reshape(N, -1) for m in masks_u8], 1).contiguous().view(-1)
         ref = torch.empty((N, S, geom.L, 2), dtype=torch.float32, device=dev)
         ops.enc_ref_points(vr, geom, ref, N)
-        memory, memory16 = self.encoder.run(src, pos, self.level_embed, ref, mask_flat, geom, self.act_dtype)
+        memory, memory16 = self.encoder.run(src, pos, self.level_embed, ref, mask_flat, geom, self.act_dtype, self.split_w)
         Q = tgt.shape[1]
         ref_in = torch.empty((N, Q, geom.L, 2), dtype=torch.float32, device=dev)
         ops.dec_ref_points(reference_points.contiguous(), vr, ref_in, N, Q, geom.L)
-        hs = self.decoder.run(memory, memory16, tgt, qpos, ref_in, mask_flat, geom, self.act_dtype)
+        hs = self.decoder.run(memory, memory16, tgt, qpos, ref_in, mask_flat, geom, self.act_dtype, self.split_w)
         self._last_memory = memory
         return hs
 
@@ -479,7 +486,7 @@ class PoET(nn.Module):
             masks.append(m)
         geom = LevelGeom(shapes)
         names, params = _named(self.input_proj)
-        src = Fn.InputProjFn.apply(feats, geom, 32, (act, stream), names, *params)
+        src = Fn.InputProjFn.apply(feats, geom, 32, (act, stream, tr.split_w), names, *params)
         self._last_src = src                          # autograd-node boundaries: the graphed trainer splits backward here
         pos = torch.empty((N, geom.S, self.hidden_dim), dtype=act, device=dev)
         lvl_embed = tr.level_embed.detach().contiguous()

@@ -15,8 +15,8 @@ import struct as _struct
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 # PoetGemmDesc as one packed record (natural C layout of include/poet_hip.h; checked against ctypes below)
-_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q")     # native alignment inserts the same padding as the C compiler
-assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 8 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
+_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i")     # native alignment inserts the same padding as the C compiler
+assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 16 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
 
 # Device word mixed into every dropout seed (and the Adam step) at run time.  None in eager mode; engine.GraphedTrainer
 # sets it so captured hipGraphs draw fresh masks on each replay.
@@ -201,7 +201,7 @@ class LevelGeom:
 def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
          a_kmajor=False, b_kmajor=False, bias=None, act=0, add_src=None, ld_add=0, gate_ref=None, gate_scale=1.0,
          row_mask=None, drop_p=0.0, seed=0, compute=None, batch=1, strideA=0, strideB=0, strideC=0, stride_bias=0,
-         splitk=1, atomic=False, alpha=1.0, head_major=None):
+         splitk=1, atomic=False, alpha=1.0, head_major=None, b_split=False):
     lib = _lib.load()
     if not (A.is_cuda and B.is_cuda and Cout.is_cuda):
         raise _lib.PoetHipError("poet_amd: GEMM operands must live on the GPU (no CPU path exists)")
@@ -218,7 +218,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                          M, N, K, lda, ldb, ldc, ld_add, int(a_kmajor), int(b_kmajor), ad, bd, cd, compute, batch,
                          strideA, strideB, strideC, stride_bias, splitk, int(atomic), act, alpha, gate_scale, drop_p,
                          seed & 0xFFFFFFFF, 1 if head_major is not None else 0, hm[0], hm[1], hm[2],
-                         (_seed_dev() or 0) if drop_p > 0 else 0)
+                         (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), 0)
     if PROFILE.on:
         e0 = PROFILE.begin()
         _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
@@ -236,12 +236,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
 
 
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, *, act=0,
-               drop_p=0.0, seed=0, row_mask=None, add_src=None, head_major=None, ldc=None, ldx=None):
-    """out[rows, N] = act(x[rows, K] @ W[N, K]^T + b).  x / out may be column slices (ldx / ldc)."""
+               drop_p=0.0, seed=0, row_mask=None, add_src=None, head_major=None, ldc=None, ldx=None, split=False):
+    """out[rows, N] = act(x[rows, K] @ W[N, K]^T + b).  x / out may be column slices (ldx / ldc).
+    split: W is the fp32 master, used as bf16 hi + bf16 lo (PoetGemmDesc.b_split)."""
     rows = x.numel() // x.shape[-1] if ldx is None else x.shape[0]
     N, K = W.shape
     return gemm(x, W, out, rows, N, K, lda=ldx or K, ldb=K, ldc=ldc or N, bias=b, act=act, drop_p=drop_p, seed=seed,
-                row_mask=row_mask, add_src=add_src, ld_add=(ldc or N), head_major=head_major)
+                row_mask=row_mask, add_src=add_src, ld_add=(ldc or N), head_major=head_major,
+                b_split=split, compute=BF16 if split else None)
 
 
 def linear_dx(dy: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, rows: int, ldy=None, add_src=None,
