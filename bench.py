@@ -234,7 +234,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="ycbv", choices=sorted(CONFIGS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_pure", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_nosplit", "bf16_pure", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -321,7 +321,7 @@ def main():
             "metric": "images/sec fwd+bwd (loss + backward + clip + AdamW), PoET encoder-decoder",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "bf16_pure": "bf16", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "bf16_nosplit": "bf16", "bf16_pure": "bf16", "fp32": "f32"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['enc_layers']} enc / {cfg['dec_layers']} dec / {cfg['nheads']} heads, "
                                    f"{cfg['d_model']}-d, {cfg['n_levels']} levels, {iw}x{ih}, {cfg['num_queries']} queries, "
                                    f"bs={batch} per GPU, dropout {cfg['dropout']}, AdamW + clip 0.1, random init",

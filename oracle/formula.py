@@ -42,13 +42,20 @@ def n_backbone_levels(cfg):
 
 
 # ---- closed-form weights -------------------------------------------------------------------------
-def _phase(name: str) -> float:
-    return (zlib.crc32(name.encode()) % 6283) * 1e-3
-
-
-def _wave(numel: int, name: str, freq: float = 0.37) -> torch.Tensor:
-    i = torch.arange(numel, dtype=torch.float64)
-    return torch.sin(freq * i + _phase(name))
+def _wave(numel: int, name: str) -> torch.Tensor:
+    """Name-keyed closed-form pseudo-noise in [-sqrt(1.5), sqrt(1.5)) with variance 1/2: element i of tensor `name` is an
+    integer hash (lowbias32, exact uint32 arithmetic -- bit-identical on every machine) of i + crc32(name) * 0x9E3779B1.
+    (Round 1 used sin(0.37 i + phase): by the angle-sum identity every matrix filled that way is a sum of two outer products,
+    i.e. RANK 2 with a spectral norm of ~22 -- a degenerate network that amplifies input noise ~6x where the reference's own
+    initialisation attenuates it.  A full-rank fill keeps the fixture representative of what the kernels are used on.)"""
+    key = np.uint32((zlib.crc32(name.encode()) * 0x9E3779B1) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = np.arange(numel, dtype=np.uint32) + key
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    u = x.astype(np.float64) * (2.0 / 4294967296.0) - 1.0          # uniform [-1, 1)
+    return torch.from_numpy(u * math.sqrt(1.5))
 
 
 @torch.no_grad()

@@ -266,6 +266,11 @@ def main():
         for rm, al in (("quat", False), ("silho_quat", False), ("6d", True)):
             _run_model("tiny", 2, True, True, rotation_mode=rm, aleatoric=al)
         return
+    if "--big" in sys.argv:                   # BASELINE.json configs[3] / configs[4] at bs 1: outputs + checksums only
+        _run_model("lmo", 1, False, False)
+        _run_model("lmo", 2, True, False)
+        _run_model("hires", 1, False, False)
+        return
     if "--modes" in sys.argv:                 # only the jitter / class-agnostic goldens
         _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
         _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
@@ -277,6 +282,9 @@ def main():
     _run_model("cfg0", 2, True, False)
     _run_model("ycbv", 1, False, False)
     _run_model("ycbv", 1, False, False, default_init=True)
+    _run_model("lmo", 1, False, False)
+    _run_model("lmo", 2, True, False)
+    _run_model("hires", 1, False, False)
     _run_model("tiny", 2, True, True, default_init=True)
     _run_inference("tiny")
     _run_inference("cfg0")

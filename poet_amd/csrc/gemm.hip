@@ -25,6 +25,8 @@
 
 #include "gemm.cuh"
 
+#include <stdlib.h>
+
 namespace poet {
 
 template <typename Src, typename CT, int N> struct cvt_pack;           // N source elements -> packed compute type
@@ -239,6 +241,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 bfr[j] = *reinterpret_cast<const uint4*>(Bs + (wn * WN + j * 16 + frow) * PITCH + ks * 64 + fchunk * 16);
+            uint4 blo[SPLIT ? FN : 1];
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    blo[j] = *reinterpret_cast<const uint4*>(Bs + (BN + wn * WN + j * 16 + frow) * PITCH + ks * 64 + fchunk * 16);
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -246,11 +254,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
                     if constexpr (sizeof(CT) == 2) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
-                        if constexpr (SPLIT) {
-                            const uint4 blo = *reinterpret_cast<const uint4*>(Bs + (BN + wn * WN + j * 16 + frow) * PITCH + ks * 64 + fchunk * 16);
+                        if constexpr (SPLIT)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, blo), acc[i][j], 0, 0, 0);
-                        }
+                                __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, blo[j]), acc[i][j], 0, 0, 0);
                     } else {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
     // so bias / gate / residual are 16-32 B vector loads and C leaves as 16-B (bf16x8) or 2x16-B (f32x8) stores that
     // are contiguous along the row across lanes (the MFMA layout itself would give 2-byte stores 4 rows apart).
     constexpr int CP = BN + 4;                               // fp32 pitch of the staged C tile
-    static_assert(BM * CP * 4 <= 2 * STAGE, "C tile must fit in the staging buffers");
+    // (launch_one sizes the dynamic LDS as max(2 * STAGE, BM * CP * 4): the C tile re-uses the staging buffers)
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -358,7 +364,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
 
 template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB, bool AKM, bool BKM, bool SPLIT = false>
 static void launch_one(const GemmK& p, hipStream_t st) {
-    constexpr int LDS = 2 * (BM + (SPLIT ? 2 : 1) * BN) * (BKB + 16);
+    constexpr int LDS_ST = 2 * (BM + (SPLIT ? 2 : 1) * BN) * (BKB + 16), LDS_C = BM * (BN + 4) * 4;
+    constexpr int LDS = LDS_ST > LDS_C ? LDS_ST : LDS_C;
     auto kern = gemm_kernel<TA, TB, TC, CT, BM, BN, BKB, AKM, BKM, SPLIT>;
     static bool attr_set = false;          // per instantiation; idempotent, so a race between host threads is benign
     if (!attr_set) {
@@ -373,13 +380,6 @@ static void launch_one(const GemmK& p, hipStream_t st) {
 template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB>
 static void launch_layout(const GemmK& p, hipStream_t st) {
     const int key = p.d.a_kmajor * 2 + p.d.b_kmajor;
-    if constexpr (sizeof(TB) == 4 && sizeof(CT) == 2 && BM >= 64) {
-        if (p.d.b_split) {                          // (validated by poet_gemm: b_kmajor == 0)
-            if (p.d.a_kmajor) launch_one<TA, TB, TC, CT, BM, BN, BKB, true, false, true>(p, st);
-            else launch_one<TA, TB, TC, CT, BM, BN, BKB, false, false, true>(p, st);
-            return;
-        }
-    }
     switch (key) {
         case 0: launch_one<TA, TB, TC, CT, BM, BN, BKB, false, false>(p, st); break;
         case 1: launch_one<TA, TB, TC, CT, BM, BN, BKB, false, true>(p, st); break;
@@ -398,9 +398,30 @@ static int tile_choice(const PoetGemmDesc& d) {
     return 1;
 }
 
+// b_split (fp32 [N,K] weight as bf16 hi + lo): the two B images make a 128-byte K stage of the 128x128 tile 110 KB of LDS,
+// i.e. ONE 4-wave workgroup per CU and nothing to overlap its barriers with (measured: 4.4x slower than the plain kernel);
+// 64-byte stages keep two workgroups per CU (61 KB).  POET_SPLIT_BKB=128 selects the wide stage (A/B aid).
+template <typename TA, typename TB, typename TC, typename CT, int BM, int BN, int BKB>
+static void launch_split_layout(const GemmK& p, hipStream_t st) {
+    if (p.d.a_kmajor) launch_one<TA, TB, TC, CT, BM, BN, BKB, true, false, true>(p, st);
+    else launch_one<TA, TB, TC, CT, BM, BN, BKB, false, false, true>(p, st);
+}
+static int split_bkb() {
+    static const int v = [] { const char* e = getenv("POET_SPLIT_BKB"); return e ? atoi(e) : 64; }();
+    return v;
+}
+
 template <typename TA, typename TB, typename TC, typename CT>
 static void launch_tile(const GemmK& p, hipStream_t st) {
     const int tc = tile_choice(p.d);
+    if constexpr (sizeof(TB) == 4 && sizeof(CT) == 2) {
+        if (p.d.b_split) {                          // (validated by poet_gemm: b_kmajor == 0)
+            if (tc == 0 && split_bkb() == 128) launch_split_layout<TA, TB, TC, CT, 128, 128, 128>(p, st);
+            else if (tc == 0) launch_split_layout<TA, TB, TC, CT, 128, 128, 64>(p, st);
+            else launch_split_layout<TA, TB, TC, CT, 64, 64, 128>(p, st);
+            return;
+        }
+    }
     if (tc == 0) launch_layout<TA, TB, TC, CT, 128, 128, 128>(p, st);
     else if (tc == 1) launch_layout<TA, TB, TC, CT, 64, 64, 256>(p, st);
     else if constexpr (sizeof(CT) == 4) {
@@ -445,7 +466,7 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         POET_CHECK(d.b_dtype == POET_F32 && d.compute == POET_BF16 && !d.b_kmajor && !atomic, POET_ERR_ARG,
                    "poet_gemm: b_split needs an fp32 [N,K] weight, bf16 compute, no split-K");
     const int tcs = tile_choice(d);
-    const int BKB = tcs == 0 ? 128 : (tcs == 3 ? 1024 : 256);
+    const int BKB = d.b_split ? (tcs == 0 ? split_bkb() : 128) : (tcs == 0 ? 128 : (tcs == 3 ? 1024 : 256));
     const int BK = BKB / (d.compute == POET_BF16 ? 2 : 4);
     p.kchunk = cdiv(cdiv(d.K, d.splitk), BK) * BK;
     p.a_vec = vec_ok(d.A, d.lda, d.strideA);

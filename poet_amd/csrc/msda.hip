@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
 // flushes each window once with coalesced global atomics; a sample whose corner falls outside the window (large
 // learned offset, padded image) goes straight to a global atomic, so the result never depends on the halo.
 // Global atomics drop from (16 points x 4 corners x D) per (query, head) to ~(window pixels x D) per workgroup (~20x).
-struct TileP { int TX, TY, HALO; };
+struct TileP { int TX, TY, HALO, skip; };     // skip: timing-breakdown aid (POET_DV_SKIP bits: 1 max pass, 2 accumulate, 4 flush)
 // 512 threads: twice the waves on the same LDS windows (the accumulate loop is VALU/LDS-issue bound at 2 waves/SIMD)
 constexpr int TILED_NT = 1024;
 
@@ -503,9 +503,9 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
 
     // pass 1: max |grad_out| over this tile's queries (those whose pixel centre falls in the tile, at every level)
     // -> power-of-two scale
-    float gm = 0.f;
+    float gm = (tp.skip & 1) ? 4.f : 0.f;
 #pragma unroll 1
-    for (int lq = 0; lq < L; ++lq) {
+    for (int lq = 0; lq < ((tp.skip & 1) ? 0 : L); ++lq) {
         const int W = p.W[lq], H = p.H[lq];
         const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     const int dummy = (loff[L] + r) * 64;
 
 #pragma unroll 1
-    for (int lq = 0; lq < L; ++lq) {
+    for (int lq = 0; lq < ((tp.skip & 2) ? 0 : L); ++lq) {
         const int W = p.W[lq], H = p.H[lq];
         const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
@@ -623,6 +623,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
         }
     }
     __syncthreads();
+    if (tp.skip & 4) return;
 #pragma unroll
     for (int l2 = 0; l2 < L; ++l2) {
         const int cnt = wp[l2] * wh[l2] * D;
@@ -678,6 +679,7 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
     TileP tp{};
     const size_t lds = plan_tiles(p, L, tp);
     { const char* e = getenv("POET_NO_TILED_SCATTER"); if (e && atoi(e)) return false; }
+    { const char* e = getenv("POET_DV_SKIP"); tp.skip = e ? atoi(e) : 0; }
     if (!lds) return false;
     auto kern = msda_bwd_dv_tiled_kernel<TQ, L>;
     static bool attr_set = false;

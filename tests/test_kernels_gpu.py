@@ -517,6 +517,93 @@ def test_msda_fused_grid_queries_tiled_scatter(ops, shapes, m, dt):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+def _explicit_from_fused(shapes, value_nsmd, oa, ref_pts, gout, m, p):
+    """float64 closed form (oracle/msda_explicit.py) of the FUSED op: softmax over L*P logits, loc = ref + off / (W, H);
+    returns out, d(value) (N,S,M,D), d(offsets|logits) laid out like `oa`."""
+    n, lq = oa.shape[:2]
+    L = len(shapes)
+    mlp = m * L * p
+    off = oa[..., : 2 * mlp].double().view(n, lq, m, L, p, 2)
+    lg = oa[..., 2 * mlp:].double().view(n, lq, m, L * p)
+    w = torch.softmax(lg, -1)
+    norm = torch.tensor([[wd, ht] for ht, wd in shapes], dtype=torch.float64)
+    loc = ref_pts.double()[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    v = value_nsmd.double().numpy()
+    wn = w.view(n, lq, m, L, p).numpy()
+    out = msda_explicit.msda_forward(v, shapes, loc.numpy(), wn)
+    dv, dl, da = msda_explicit.msda_backward(v, shapes, loc.numpy(), wn, gout.double().numpy())
+    doff = torch.from_numpy(dl) / norm[None, None, None, :, None, :]
+    da = torch.from_numpy(da).view(n, lq, m, L * p)
+    dlg = w * (da - (w * da).sum(-1, keepdim=True))
+    doa = torch.cat([doff.reshape(n, lq, 2 * mlp), dlg.reshape(n, lq, mlp)], -1)
+    return torch.from_numpy(out), torch.from_numpy(dv), doa
+
+
+@pytest.mark.parametrize("case", ["ycbv_init_like", "ycbv_wide_offsets", "hires_tiles", "one_pixel_pileup"])
+def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case):
+    """The kernels the benchmark runs -- fused forward, d(offsets|logits), and the LDS-tiled int32 fixed-point d(value)
+    scatter -- at the benchmark's geometry (M = 16 heads, D = 16, bf16 storage, grid queries, bs 2) against the float64
+    closed form, not against each other:
+      ycbv_init_like    (60,80)..(8,10): offsets = the reference's initial directional grid (+-1..4 px) + noise
+      ycbv_wide_offsets the same with 10 % of the samples thrown 10-40 px away (out of window -> global-atomic pass, out of image)
+      hires_tiles       (120,160)..(15,20) at bs 1: the 16x16-tile plan with halo-dominated windows (BASELINE configs[4])
+      one_pixel_pileup  every sample of every query aims at ONE pixel per level with same-sign gradients: the worst case for
+                        the int32 windows (n_queries_in_tile x 2^18 per word; the tile plan keeps that below 2^31)."""
+    m, d, p = 16, 16, 4
+    if case == "hires_tiles":
+        shapes, n = [(120, 160), (60, 80), (30, 40), (15, 20)], 1
+    else:
+        shapes, n = [(60, 80), (30, 40), (15, 20), (8, 10)], 2
+    L = len(shapes)
+    geom = ops.LevelGeom(shapes)
+    S = geom.S
+    rng = np.random.default_rng(23)
+    mlp = m * L * p
+    value = torch.from_numpy(rng.standard_normal((n, S, m, d)).astype(np.float32)).to(torch.bfloat16)
+    th = np.arange(m) * (2 * np.pi / m)
+    grid = np.stack([np.cos(th), np.sin(th)], -1)
+    grid = grid / np.abs(grid).max(-1, keepdims=True)
+    base = (grid[:, None, None, :] * (np.arange(p) + 1)[None, None, :, None]).repeat(L, 1)          # (m, L, p, 2)
+    off = base[None, None] + 0.3 * rng.standard_normal((n, S, m, L, p, 2))
+    lg = rng.standard_normal((n, S, mlp))
+    gout = rng.standard_normal((n, S, m * d))
+    if case == "ycbv_wide_offsets":
+        far = rng.random((n, S, m, L, p, 1)) < 0.1
+        off = np.where(far, off * rng.uniform(5, 20, off.shape), off)
+    vr = torch.ones(n, L, 2)
+    ref = torch.empty(n, S, L, 2, device="cuda")
+    ops.enc_ref_points(dev(vr), geom, ref, n)
+    if case == "one_pixel_pileup":
+        # offset = (target pixel centre) - (query's reference point in pixels): every corner weight lands on one pixel
+        refc = ref.cpu().numpy()                                                               # (n,S,L,2) normalised
+        tgt = np.array([[(wd // 2 + 0.5), (ht // 2 + 0.5)] for ht, wd in shapes])              # pixel centres (x, y)
+        wh = np.array([[wd, ht] for ht, wd in shapes], np.float64)
+        off = (tgt[None, None] - refc * wh[None, None])[:, :, None, :, None, :].repeat(m, 2).repeat(p, 4)
+        gout = np.abs(gout) + 1.0                                                              # same sign: magnitudes add up
+    oa = torch.from_numpy(np.concatenate([off.reshape(n, S, 2 * mlp), lg], -1).astype(np.float32)).to(torch.bfloat16)
+    gout = torch.from_numpy(gout.astype(np.float32)).to(torch.bfloat16)
+    out_ref, dv_ref, doa_ref = _explicit_from_fused(shapes, value.float(), oa.float(), ref.cpu(), gout.float(), m, p)
+
+    vdev = dev(value.permute(0, 2, 1, 3).contiguous())                                        # head-major (N,M,S,D)
+    vstr = (m * S * d, d, S * d)
+    out = torch.empty(n, S, m * d, dtype=torch.bfloat16, device="cuda")
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S)
+    e_out = (out.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item()
+    gv = torch.zeros(n, m, S, d, device="cuda")
+    goa = torch.empty_like(dev(oa))
+    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv, goa, n, m, d, p, S, grid_queries=True)
+    dv = gv.double().cpu().permute(0, 2, 1, 3)
+    e_dv = (dv - dv_ref).abs().max().item() / dv_ref.abs().max().item()
+    dq = goa.double().cpu()
+    e_off = (dq[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs().max().item() / doa_ref[..., : 2 * mlp].abs().max().item()
+    e_lg = (dq[..., 2 * mlp:] - doa_ref[..., 2 * mlp:]).abs().max().item() / doa_ref[..., 2 * mlp:].abs().max().item()
+    print(f"{case}: rel max err out {e_out:.2e} dV {e_dv:.2e} d(off) {e_off:.2e} d(logit) {e_lg:.2e}; max|dV| {dv_ref.abs().max():.3g}")
+    # inputs are bf16-exact, accumulation fp32 / int32 fixed point (2^-18 of the tile's max |grad_out| per contribution):
+    # only the bf16 rounding of the stored outputs (out, d(off|logit): 2^-9 relative) and the fixed point remain
+    assert e_out < 6e-3 and e_off < 8e-3 and e_lg < 8e-3, (e_out, e_off, e_lg)
+    assert e_dv < 2e-4, e_dv
+
+
 # ------------------------------------------------------------------------- streaming (weight-stationary) GEMM
 @pytest.mark.parametrize("cdtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("wdtype", [torch.bfloat16, torch.float32])

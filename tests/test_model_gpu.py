@@ -201,36 +201,65 @@ def test_rotation_modes_fp32_vs_reference_golden(gpu, golden_dir, rotation_mode,
     assert runs["segmented"] == pytest.approx(runs["eager"], rel=2e-3, abs=2e-3), runs
 
 
-@pytest.mark.parametrize("init", [False, True])
-def test_full_size_ycbv_checksums(gpu, golden_dir, init):
-    """BASELINE configs[1] geometry (5/5/16h, 4 levels, 640x480, Q=20) at bs=1 against the reference's golden:
-    closed-form weights (init=False) and the reference's own seeded default initialisation (init=True)."""
-    g = np.load(os.path.join(golden_dir, f"poet_ycbv_b1{'_init' if init else ''}.npz"))
-    for dtype, tol in ((torch.float32, TOL_F32), (torch.bfloat16, TOL_BF16)):
-        r = gpu("ycbv", 1, False, dtype, default_init=init)
+FULL_SIZE = [("ycbv", 1, False, False), ("ycbv", 1, False, True),          # BASELINE.json configs[1]: closed-form weights / the reference's own init
+             ("lmo", 1, False, False), ("lmo", 2, True, False),              # configs[3] geometry (30,40)..(4,5), Q=10, 8 classes; padded batch
+             ("hires", 1, False, False)]                                    # configs[4]: 1280x960, 6 enc / 6 dec, Q=50, S=25500
+# bf16 backward: every gradient GEMM takes bf16 operands (2^-9 relative per element) and the value-gradient scatter is
+# 2^-18 fixed point; parameter-gradient checksums (L2 norm + 8 sampled entries) must agree with the real reference's to this
+# fraction of the tensor's gradient norm
+GRAD_TOL_F32, GRAD_TOL_BF16 = 3e-3, 4e-2
+
+
+@pytest.mark.parametrize("name,batch,pad,init", FULL_SIZE)
+def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, batch, pad, init):
+    """Full-size geometries of BASELINE.json against goldens of the REAL reference (outputs, losses and the checksums of
+    all parameter gradients), fp32 at 1e-3 and the benchmarked bf16 policy at 1e-2 -- strict max-norm on every query's
+    translation and rotation.  At >= 4096 token rows per image the forward AND backward run exactly the kernels the benchmark
+    runs (weight-stationary / dW streaming GEMMs, LDS-tiled value-gradient scatter, bf16 MSDA gathers)."""
+    g = np.load(os.path.join(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz"))
+    for dtype, tol, gtol in ((torch.float32, TOL_F32, GRAD_TOL_F32), (torch.bfloat16, TOL_BF16, GRAD_TOL_BF16)):
+        r = gpu(name, batch, pad, dtype, default_init=init)
+        model, crit = r["model"], r["crit"]
         if init:
-            for (n, p), ref_sum in zip(r["model"].named_parameters(), g["param_checksums"]):
+            for (n, p), ref_sum in zip(model.named_parameters(), g["param_checksums"]):
                 np.testing.assert_allclose(checksum(p.cpu()), ref_sum, atol=0, rtol=0, err_msg=n)
-        r["model"].eval()
-        with torch.no_grad():
-            out, _ = r["model"](r["samples"], r["targets"])
-        et = (out["pred_translation"].cpu() - torch.from_numpy(g["pred_translation"])).abs().max().item()
-        er = (out["pred_rotation"].cpu() - torch.from_numpy(g["pred_rotation"])).abs().max().item()
-        rms_r = (out["pred_rotation"].cpu() - torch.from_numpy(g["pred_rotation"])).pow(2).mean().sqrt().item()
-        print(f"ycbv init={init} {dtype}: max|dt| {et:.2e} max|dR| {er:.2e} rms dR {rms_r:.2e}")
-        assert et < tol, (dtype, et)
-        if dtype == torch.bfloat16:
-            # Full size, bf16 MFMA operands: every GEMM input is rounded to 8 mantissa bits, which puts ~5e-3 rms into the
-            # encoder memory (random walk over ~25 branch GEMMs; the fp32 path is at 1e-6), and the 6D->R normalisation
-            # divides by |a1| ~ 0.1 at random init.  A sweep over 6 (input, init) seeds against the fp32 oracle gives
-            # max|dR| 0.9e-2 .. 4.6e-2 and rms 1.7e-3 .. 5.6e-3 with max|dt| <= 1.1e-3 (DESIGN.md, "bf16 parity"): the max
-            # over 180 rotation entries is a heavy-tailed draw dominated by one ill-conditioned query, so at full size the
-            # 1e-2 tolerance is asserted on the rms and the max is bounded at 2x; the strict max bound is asserted on
-            # translations here, on both outputs of every small config (test_forward_bf16_vs_reference_golden) and on
-            # rotations with well-conditioned heads (test_bf16_full_size_seed_sweep[conditioned]: 6e-4 .. 9e-4).
-            assert rms_r < tol and er < 2 * tol, (dtype, er, rms_r)
-        else:
-            assert er < tol, (dtype, et, er)
+        model.eval()                                            # dropout off, as in the golden run
+        out, n_boxes = model(r["samples"], r["targets"])
+        assert list(n_boxes) == list(g["n_boxes"])
+        dt = (out["pred_translation"].detach().cpu() - torch.from_numpy(g["pred_translation"])).abs().max().item()
+        dR = out["pred_rotation"].detach().cpu() - torch.from_numpy(g["pred_rotation"])
+        at = torch.stack([a["pred_translation"] for a in out["aux_outputs"]]).detach().cpu()
+        ar = torch.stack([a["pred_rotation"] for a in out["aux_outputs"]]).detach().cpu()
+        dta = (at - torch.from_numpy(g["aux_translation"])).abs().max().item()
+        dra = (ar - torch.from_numpy(g["aux_rotation"])).abs().max().item()
+        losses = crit(out, r["targets"], n_boxes)
+        names = sorted(losses)
+        assert names == [str(x) for x in g["loss_names"]]
+        lv = np.array([float(losses[k]) for k in names])
+        lerr = float(np.abs(lv - g["loss_values"]).max())
+        total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+        model.zero_grad()
+        total.backward()
+        params = dict(model.named_parameters())
+        worst, bad = 0.0, []
+        for n, ref in zip(g["grad_names"], g["grad_checksums"]):
+            p = params[str(n)]
+            if np.isnan(ref).all():
+                assert p.grad is None, n
+                continue
+            assert p.grad is not None, n
+            got = checksum(p.grad.cpu())
+            scale = max(1e-3, abs(ref[0]))                       # the tensor's gradient norm
+            e = float(np.abs(got - ref).max()) / scale
+            worst = max(worst, e)
+            if e > gtol:
+                bad.append((str(n), e, float(ref[0])))
+        print(f"{name} b{batch} init={init} {dtype}: max|dt| {dt:.2e} (aux {dta:.2e}) max|dR| {dR.abs().max():.2e} (aux {dra:.2e}) "
+              f"rms dR {dR.pow(2).mean().sqrt():.2e}; max loss err {lerr:.2e}; worst grad-checksum error {worst:.2e} of the norm")
+        assert dt < tol and dR.abs().max().item() < tol, (dtype, dt, dR.abs().max().item())
+        assert dta < tol and dra < tol, (dtype, dta, dra)       # the four auxiliary decoder layers' poses as well
+        assert lerr < (2e-4 if dtype == torch.float32 else 2e-2) * max(1.0, float(np.abs(g["loss_values"]).max())), lerr
+        assert not bad, bad[:10]
 
 
 def test_arena_trainer_matches_oracle_step(gpu):
@@ -406,12 +435,12 @@ def test_device_resident_targets_match_host_targets(gpu):
 @pytest.mark.parametrize("conditioned", [False, True])
 def test_bf16_full_size_seed_sweep(gpu, input_seed, init_seed, conditioned):
     """bf16 forward at YCB-V geometry against the fp32 oracle run on this box's CPU, over different inputs and different
-    default initialisations.
-    conditioned=False: the reference's random init as is.  Translations stay within 1e-2 (measured <= 1.1e-3).  Rotations
-      are reported and only loosely bounded: at random init the 6D output has |a1| ~ 0.1 or less and the Gram-Schmidt
-      normalisation amplifies the ~1e-3 relative bf16 error of `hs` without limit (measured max 1.7e-2 .. 9e-2).
+    default initialisations: strict max-norm 1e-2 on translations and rotations.
+    conditioned=False: the reference's random init as is -- the hard case: the 6D head output has |a1| ~ 0.1 or less, so the
+      Gram-Schmidt normalisation amplifies the error of `hs` 10-60x (with single-bf16 weights these seeds measured
+      1.7e-2 .. 9.2e-2; with split weights 1.6e-3 .. 6.4e-3).
     conditioned=True: same models, but the last Linear of every rotation head gets the bias [1,0,0, 0,1,0] per class, i.e.
-      a 6D output of unit scale as trained heads produce.  Then the strict max-norm 1e-2 holds on both outputs."""
+      a 6D output of unit scale as trained heads produce (measured 2.3e-4 .. 2.7e-4)."""
     import tests.oracle_runner as orr
     from oracle import poet_ref
     from oracle.formula import CONFIGS, make_inputs, make_samples
@@ -442,11 +471,7 @@ def test_bf16_full_size_seed_sweep(gpu, input_seed, init_seed, conditioned):
     dR = out["pred_rotation"].cpu() - oout["pred_rotation"]
     rms, mx = dR.pow(2).mean().sqrt().item(), dR.abs().max().item()
     print(f"bf16 ycbv seeds ({input_seed},{init_seed}) conditioned={conditioned}: max|dt| {dt:.2e} rms dR {rms:.2e} max|dR| {mx:.2e}")
-    assert dt < TOL_BF16, dt
-    if conditioned:
-        assert mx < TOL_BF16, (rms, mx)
-    else:
-        assert rms < 5e-2 and mx < 0.5, (rms, mx)
+    assert dt < TOL_BF16 and mx < TOL_BF16, (dt, rms, mx)          # strict max-norm, conditioned or not
 
 
 @pytest.mark.parametrize("mode", ["graph", "eager"])

@@ -60,7 +60,10 @@ def test_msda_core_vs_hf(golden_dir):
 
 @pytest.mark.parametrize("name,batch,pad,full,init", [("tiny", 2, True, True, False), ("tiny", 2, False, True, False),
                                                       ("cfg0", 2, False, True, False), ("cfg0", 2, True, False, False),
-                                                      ("tiny", 2, True, True, True)])
+                                                      ("tiny", 2, True, True, True),
+                                                      # BASELINE.json configs[3] (LM-O geometry) and configs[4] (1280x960, 6/6, Q=50)
+                                                      ("lmo", 1, False, False, False), ("lmo", 2, True, False, False),
+                                                      ("hires", 1, False, False, False)])
 def test_poet_vs_reference(golden_dir, name, batch, pad, full, init):
     g = _load(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz")
     r = run_oracle(name, batch, pad, default_init=init)
