@@ -300,6 +300,263 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
     if (u < u_hi) iteration(u, std::true_type{});
 }
 
+// ---- K-chunked variant: K = KC x 256 (FFN2 and the K = 512 / 768 / 1024 input-gradient products) ----------------------
+// The weight no longer fits LDS whole, so the loop nest is turned inside out: a workgroup owns ONE (256-row block, 128-column
+// slice) item, its 8 waves keep the 32 x 128 accumulators of their rows in registers for the whole K loop, and the W chunk
+// [128 columns][256 k] (hi | lo images when SPLIT) is re-staged in LDS per chunk.  Weight traffic per activation row is 1/2
+// of the 128 x 128 tiled kernel's, the activation operand still goes global -> registers in MFMA layout (the next chunk's
+// rows are in flight while the current chunk is multiplied), and the epilogue is the register epilogue of the kernel above.
+template <typename TC, int KIND, bool WKM, bool SPLIT>
+__global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
+    constexpr int BN = 128, KS = 8, NTH = 512, FM = 2;
+    constexpr int K = KS * 32, PITCH = K * 2 + 16, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
+    constexpr int LO = SPLIT ? BN * PITCH : 0;
+    constexpr bool GATE = KIND & WS_GATE, ADD = KIND & WS_ADD, MASK = KIND & WS_MASK;
+    static_assert(!SPLIT || !WKM, "b_split is a forward ([N,K] weight) feature");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sbias = reinterpret_cast<float*>(smem + (SPLIT ? 2 : 1) * BN * PITCH);
+    const PoetGemmDesc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int frow = lane & 15, g = lane >> 4;
+
+    // item = (row block, column slice); the slices of one row block run on one XCD (A is re-read through that L2)
+    const int NT = d.N / BN, RB = (d.M + 255) >> 8;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nt = j % NT, rb = (j / NT) * 8 + xcd;
+    if (rb >= RB) return;
+    const int n0 = nt * BN, KC = d.K >> 8;
+    const int row0 = rb * 256 + wid * 32;                                // this wave's 32 rows
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(d.A);
+    int grow[FM];
+    const bf16_t* ap[FM];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        grow[fm] = row0 + fm * 16 + frow;
+        ap[fm] = A + (int64_t)min(grow[fm], d.M - 1) * d.lda + g * 8;
+    }
+    uint4 a[FM][KS], an[FM][KS];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a[fm][kk] = *reinterpret_cast<const uint4*>(ap[fm] + kk * 32);
+    if (tid < BN) sbias[tid] = d.bias ? d.bias[n0 + tid] : 0.f;
+
+    f32x4_t acc[FM][FNT];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < FNT; ++jn) acc[i][jn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int woff = frow * PITCH + g * 16;
+
+#pragma unroll 1
+    for (int c = 0; c < KC; ++c) {
+        if (c) __syncthreads();                                          // every wave is done reading the previous chunk of W
+        // ---- W chunk c -> LDS ----
+        if constexpr (SPLIT) {
+            const float* Bf = reinterpret_cast<const float*>(d.B) + c * K;
+            constexpr int CPR = K / 4, NCH = BN * CPR, GRP = 8;
+#pragma unroll 1
+            for (int base = 0; base < NCH; base += NTH * GRP) {
+                float4 wv[GRP];
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                    wv[i] = *reinterpret_cast<const float4*>(Bf + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                    const uint2 hi = make_uint2(pack_bf2(wv[i].x, wv[i].y), pack_bf2(wv[i].z, wv[i].w));
+                    const uint2 lo = make_uint2(pack_bf2(wv[i].x - __uint_as_float(hi.x << 16), wv[i].y - __uint_as_float(hi.x & 0xffff0000u)),
+                                                pack_bf2(wv[i].z - __uint_as_float(hi.y << 16), wv[i].w - __uint_as_float(hi.y & 0xffff0000u)));
+                    *reinterpret_cast<uint2*>(smem + rho * PITCH + kc * 8) = hi;
+                    *reinterpret_cast<uint2*>(smem + LO + rho * PITCH + kc * 8) = lo;
+                }
+            }
+        } else if constexpr (!WKM) {
+            const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B) + c * K;
+            constexpr int CPR = K / 8, NIT = BN * CPR / NTH;
+            uint4 wv[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                wv[i] = *reinterpret_cast<const uint4*>(B + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                *reinterpret_cast<uint4*>(smem + rho * PITCH + kc * 16) = wv[i];
+            }
+        } else {
+            const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B) + (int64_t)c * K * d.ldb;
+            constexpr int NG = BN / 8, NIT = (K / 4) * NG / NTH;
+#pragma unroll 1
+            for (int i = 0; i < NIT; ++i) {                              // one item at a time: the registers belong to a / acc
+                const int idx = tid + i * NTH, kq = idx / NG, nl = (idx - kq * NG) * 8;
+                uint4 wv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wv[r] = *reinterpret_cast<const uint4*>(B + (int64_t)(kq * 4 + r) * d.ldb + n0 + nl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    uint32_t h[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t w = (e >> 1) == 0 ? wv[r].x : (e >> 1) == 1 ? wv[r].y : (e >> 1) == 2 ? wv[r].z : wv[r].w;
+                        h[r] = (e & 1) ? (w >> 16) : (w & 0xffffu);
+                    }
+                    *reinterpret_cast<uint2*>(smem + ws_inv_perm(nl + e) * PITCH + kq * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- next chunk's activation rows go in flight, then this chunk is multiplied ----
+        if (c + 1 < KC) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) an[fm][kk] = *reinterpret_cast<const uint4*>(ap[fm] + (c + 1) * K + kk * 32);
+        }
+        asm volatile("" : "+v"(woff));
+        const char* wl = smem + woff;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+            for (int jn = 0; jn < FNT; ++jn) {
+                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl + jn * 16 * PITCH + kk * 64));
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acc[fm][jn], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    const bf16x8_t wlo = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl + LO + jn * 16 * PITCH + kk * 64));
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm)
+                        acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acc[fm][jn], 0, 0, 0);
+                }
+            }
+        }
+        if (c + 1 < KC) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) a[fm][kk] = an[fm][kk];
+        }
+    }
+
+    // ---- epilogue on registers (as gemm_ws_kernel) ----
+    const TC* addp = reinterpret_cast<const TC*>(d.add_src);
+    const TC* gate = reinterpret_cast<const TC*>(d.gate_ref);
+    TC* C = reinterpret_cast<TC*>(d.C);
+    const uint32_t sd = d.seed ^ (d.seed_dev ? *d.seed_dev * 0x9E3779B1u : 0u);
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const bool live = grow[fm] < d.M;
+        const int gr = min(grow[fm], d.M - 1);
+        uint32_t mk = 0u;
+        if constexpr (MASK) mk = d.row_mask[gr];
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int lcol = jq * 64 + h * 32 + g * 8, gcol = n0 + lcol;
+                float v[8];
+#pragma unroll
+                for (int lo = 0; lo < 2; ++lo)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[lo * 4 + t] = acc[fm][jq * 4 + h * 2 + lo][t] * d.alpha;
+                {
+                    float b[8];
+                    vec<float, 8>::ld(sbias + lcol, b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += b[e];
+                }
+                if (d.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if constexpr (GATE) {
+                    uint4 gq[NV];
+                    float gt[8];
+                    run8<TC>::ld(gate + (int64_t)gr * d.ldc + gcol, gq);
+                    run8<TC>::dec(gq, gt);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gt[e] > 0.f ? v[e] * d.gate_scale : 0.f;
+                }
+                if (p.drop_thresh) {
+                    const uint32_t base = (uint32_t)gr * (uint32_t)d.N + (uint32_t)gcol;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const uint32_t hsh = drop_pair(sd, (base + e) >> 1);
+                        v[e] = (hsh & 0xffffu) >= p.drop_thresh ? v[e] * p.drop_scale : 0.f;
+                        v[e + 1] = (hsh >> 16) >= p.drop_thresh ? v[e + 1] * p.drop_scale : 0.f;
+                    }
+                }
+                if constexpr (ADD) {
+                    uint4 rq[NV];
+                    float r[8];
+                    run8<TC>::ld(addp + (int64_t)gr * d.ld_add + gcol, rq);
+                    run8<TC>::dec(rq, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if constexpr (MASK) {
+                    if (mk & 0xffu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                    }
+                }
+                if (live) {
+                    if (d.out_mode == 1) {
+                        const int hn = gr / d.hm_S, hs = gr - hn * d.hm_S, hm = gcol / d.hm_D, hd = gcol - hm * d.hm_D;
+                        vec<TC, 8>::st(C + (((int64_t)hn * d.hm_M + hm) * d.hm_S + hs) * d.hm_D + hd, v);
+                    } else {
+                        vec<TC, 8>::st(C + (int64_t)gr * d.ldc + gcol, v);
+                    }
+                }
+            }
+    }
+}
+
+template <typename TC, int KIND, bool WKM, bool SPLIT>
+bool wsk_launch(const GemmK& p, hipStream_t st) {
+    constexpr int LDS = (SPLIT ? 2 : 1) * 128 * (8 * 64 + 16) + 128 * 4;
+    auto kern = gemm_wsk_kernel<TC, KIND, WKM, SPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int NT = p.d.N / 128, RB = (p.d.M + 255) >> 8;
+    const int nblocks = ((RB + 7) / 8) * NT * 8;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), LDS, st, p);
+    return true;
+}
+
+template <typename TC>
+bool wsk_kind(const GemmK& p, hipStream_t st) {
+    const PoetGemmDesc& d = p.d;
+    const int kind = (d.gate_ref ? WS_GATE : 0) | (d.add_src ? WS_ADD : 0) | (d.row_mask ? WS_MASK : 0);
+    if (d.b_split) {
+        if (kind == 0) return wsk_launch<TC, 0, false, true>(p, st);
+        return false;
+    }
+    if (!d.b_kmajor) {
+        if (kind == 0) return wsk_launch<TC, 0, false, false>(p, st);
+        return false;
+    }
+    if constexpr (sizeof(TC) == 4) {
+        if (kind == WS_ADD) return wsk_launch<TC, WS_ADD, true, false>(p, st);       // FFN1 dX accumulated onto the fp32 stream gradient
+        if (kind == 0) return wsk_launch<TC, 0, true, false>(p, st);
+        return false;
+    } else {
+        switch (kind) {
+            case 0: return wsk_launch<TC, 0, true, false>(p, st);
+            case WS_ADD: return wsk_launch<TC, WS_ADD, true, false>(p, st);
+            case WS_GATE: return wsk_launch<TC, WS_GATE, true, false>(p, st);
+            default: return false;
+        }
+    }
+}
+
 template <typename TC, int KIND, bool WKM, int FM, int NTH, bool SPLIT = false, int BN = 128>
 void ws_launch_cfg(const GemmK& p, int nblocks, hipStream_t st) {
     constexpr int LDS = (SPLIT ? 2 : 1) * BN * (8 * 64 + 16) + BN * 4;
@@ -404,9 +661,14 @@ bool gemm_ws_try(const GemmK& p, hipStream_t st) {
         d.splitk != 1 || d.atomic || d.A2)
         return false;
     if (d.b_split && ((reinterpret_cast<uintptr_t>(d.B) & 15) || (d.ldb & 3))) return false;
-    if (d.K != 256 || d.N % 128 != 0 || d.M < 4096) return false;
+    if (d.N % 128 != 0 || d.M < 4096) return false;
     if (!p.a_vec || !p.b_vec || !p.c_vec) return false;
     if (d.out_mode == 1 && d.hm_D % 8 != 0) return false;
+    if (d.K != 256) {                                                   // K = 512 / 768 / 1024 ...: the K-chunked kernel
+        static const int no_wsk = [] { const char* e = getenv("POET_GEMM_NO_WSK"); return e && atoi(e) ? 1 : 0; }();
+        if (no_wsk || d.K % 256 != 0 || d.K > 4096) return false;
+        return d.c_dtype == POET_BF16 ? wsk_kind<bf16_t>(p, st) : wsk_kind<float>(p, st);
+    }
     const int NT = d.N / 128;
     int per = 2 * device_cus() / 8;                                     // two workgroups per CU, per XCD
     if (per < NT) per = NT;
