@@ -155,7 +155,10 @@ int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
                         const void* offattn, int64_t ldq, int logit_col,
                         const float* ref, int64_t ref_batch_stride, void* out,
                         int N, int S, int M, int D, int L, int P, int Lq,
-                        int v_dtype, int q_dtype, void* stream);
+                        int v_dtype, int q_dtype,
+                        int grid_queries /* 1: query q is pixel q of the flattened levels (encoder self-attention): enables
+                                            the kernels that stage the value maps as per-tile LDS windows */,
+                        void* stream);
 int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m,
                         const int64_t* spatial_shapes_host, const int64_t* level_start_host,
                         const void* offattn, int64_t ldq, int logit_col,
@@ -180,6 +183,8 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
 int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                 void* y, void* z_out, float* mean, float* rstd,
                 int64_t rows, int d, float eps, float drop_p, uint32_t seed, int dtype_x, int dtype_r,
+                int dtype_z /* dtype of z_out; -1 = dtype_x.  (f32 x, f32 stream, bf16 z): the branch arrives as the GEMM's
+                               fp32 accumulators, only the copy saved for backward is bf16 */,
                 void* y_bf16 /* optional: bf16 copy of y, the MFMA operand of the next GEMM */,
                 const uint32_t* seed_dev /* optional, see PoetGemmDesc.seed_dev */, void* stream);
 int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,

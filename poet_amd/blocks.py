@@ -101,7 +101,7 @@ def _pair(so_w, like):
     return (pr["w16"] if like.dtype == torch.bfloat16 else pr["w"]), pr["b"], pr["gw"], pr["gb"]
 
 
-def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P, act=None, split=False):
+def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P, act=None, split=False, grid_queries=False):
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
     OA = empty((rows, ldq), act or q2d.dtype, q2d)
@@ -117,7 +117,7 @@ def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P
         Wt, sp = Wf(aw_w, q2d, split)
         ops.linear_fwd(q2d, Wt, aw_b, OA[:, 2 * mlp:], ldc=ldq, split=sp)
     out = empty((rows, M * D), OA.dtype, q2d)
-    ops.msda_fused_fwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq)
+    ops.msda_fused_fwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq, grid_queries=grid_queries)
     return out, OA
 
 
@@ -150,16 +150,18 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
 def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False):
     """Returns (y, y16, saved): y in the residual-stream dtype; y16 = bf16 copy for the next GEMM when the stream is
-    fp32 but the branch is bf16 (else y itself)."""
+    fp32 but the branch is bf16 (else y itself).  With split weights the projection hands its fp32 accumulators to the
+    LayerNorm unrounded (the branch is never stored in bf16); only the pre-norm sum saved for backward is bf16."""
     rows, d = res.shape[0], W.shape[0]
-    tmp = empty((rows, d), x_in.dtype, res)          # branch dtype
+    mixed = x_in.dtype == torch.bfloat16 and res.dtype == torch.float32
     Wt, sp = Wf(W, x_in, split)
+    tmp = empty((rows, d), torch.float32 if (sp and mixed) else x_in.dtype, res)
     ops.linear_fwd(x_in, Wt, b, tmp, split=sp)
     y = torch.empty_like(res)                        # residual-stream dtype
-    z = torch.empty_like(tmp)
+    z = empty((rows, d), x_in.dtype, res)            # branch dtype
     mean = empty((rows,), torch.float32, res)
     rstd = empty((rows,), torch.float32, res)
-    y16 = torch.empty_like(tmp) if (tmp.dtype == torch.bfloat16 and res.dtype == torch.float32) else None
+    y16 = empty((rows, d), torch.bfloat16, res) if mixed else None
     ops.ln_fwd(tmp, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, p, seed, y16=y16)
     return y, (y16 if y16 is not None else y), (z, mean, rstd)
 
@@ -222,7 +224,7 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
                        act, split)
     out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
                            P_["self_attn.attention_weights.weight"], P_["self_attn.attention_weights.bias"],
-                           V, geom, ref, ref_bs, N, S, M, D, npts, act, split)
+                           V, geom, ref, ref_bs, N, S, M, D, npts, act, split, grid_queries=True)
     x1, x1_16, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
                                  P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0], split)
     x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],

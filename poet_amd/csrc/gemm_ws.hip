@@ -666,7 +666,10 @@ bool gemm_ws_try(const GemmK& p, hipStream_t st) {
     if (d.out_mode == 1 && d.hm_D % 8 != 0) return false;
     if (d.K != 256) {                                                   // K = 512 / 768 / 1024 ...: the K-chunked kernel
         static const int no_wsk = [] { const char* e = getenv("POET_GEMM_NO_WSK"); return e && atoi(e) ? 1 : 0; }();
-        if (no_wsk || d.K % 256 != 0 || d.K > 4096) return false;
+        // (single-weight forms are still faster on the tiled kernel: the W chunk restaging of a one-workgroup-per-CU kernel is
+        // exposed; POET_GEMM_WSK_ALL=1 routes them here anyway)
+        static const int all = [] { const char* e = getenv("POET_GEMM_WSK_ALL"); return e && atoi(e) ? 1 : 0; }();
+        if (no_wsk || d.K % 256 != 0 || d.K > 4096 || (!d.b_split && !all)) return false;
         return d.c_dtype == POET_BF16 ? wsk_kind<bf16_t>(p, st) : wsk_kind<float>(p, st);
     }
     const int NT = d.N / 128;

@@ -641,30 +641,293 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     }
 }
 
-// host: pick the tile grid / halo so the windows fit the LDS budget; returns bytes (0 = do not use the tiled kernel)
-static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
-    if (p.D != 16) return 0;
-    const int budget = 150 * 1024;                         // two workgroups per CU (160 KB LDS); 640x480 fits a 4x4 tiling
-    for (int halo = 4; halo >= 2; halo -= 2) {
+// ====================================================================================================================
+// Encoder gathers with LDS-STAGED VALUE WINDOWS (grid queries, bf16, D = 16, P = 4): forward and d(offsets | logits).
+// Workgroup = (spatial tile, HPW heads, image), the tiling of the scatter above.  It first copies the bf16 value windows of
+// its heads (tile + halo of every level, 32 B per pixel and head) from the head-major maps into LDS with coalesced 16-B
+// loads -- each value pixel is read from L2/HBM ~2x (halo) per launch instead of ~64x through the per-CU L1 -- and then
+// every thread walks (query, head) items of the tile: ONE lane owns all 16 channels of its item, so the softmax, the
+// sampling geometry and (backward) the three reductions are plain per-lane arithmetic with no cross-lane traffic, and the 4
+// corners of a sample are 8 ds_read_b128.  A sample with an in-image corner outside the window (large learned offset,
+// padded image) takes the global-memory path for that sample, so results never depend on the halo.
+struct GTileP { int TX, TY, HALO, HPW; };
+constexpr int WIN_NT = 512;
+
+struct WinGeo {                    // per-level window of this tile (uniform across the workgroup -> SGPRs)
+    int wx0, wy0, ww, wh, loff;
+};
+
+template <int L>
+__device__ __forceinline__ int win_layout(const MsdaP& p, const GTileP& tp, int tx, int ty, WinGeo (&wg)[L]) {
+    int off = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int W = p.W[l], H = p.H[l];
+        const int ax = max((tx * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((tx + 1) * W, tp.TX) + tp.HALO, W);
+        const int ay = max((ty * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((ty + 1) * H, tp.TY) + tp.HALO, H);
+        wg[l].wx0 = ax; wg[l].wy0 = ay; wg[l].ww = bx - ax; wg[l].wh = by - ay; wg[l].loff = off;
+        off += wg[l].ww * wg[l].wh;
+    }
+    return off;
+}
+
+template <int L>
+__device__ __forceinline__ void win_fill(const MsdaP& p, const WinGeo (&wg)[L], int tot, int hpw, int n, int m0, uint4* win, int tid, int nt) {
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.value) + (int64_t)n * p.vs_n;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int npx2 = wg[l].ww * wg[l].wh * 2, cnt = npx2 * hpw;
+        const float inv_n = 1.f / (float)npx2, inv_w = 1.f / (float)wg[l].ww;
+        for (int i = tid; i < cnt; i += nt) {
+            const int h = idiv_small(i, npx2, inv_n), r = i - h * npx2;
+            const int pix = r >> 1, half = r & 1;
+            const int y = idiv_small(pix, wg[l].ww, inv_w), x = pix - y * wg[l].ww;
+            const bf16_t* src = vb + (int64_t)(m0 + h) * p.vs_m + (int64_t)(p.start[l] + (wg[l].wy0 + y) * p.W[l] + wg[l].wx0 + x) * p.vs_s + half * 8;
+            win[(h * tot + wg[l].loff + pix) * 2 + half] = *reinterpret_cast<const uint4*>(src);
+        }
+    }
+}
+
+// the 4 corners (16 channels each, raw bf16 pairs) of one sample + their masked bilinear weights
+struct Sample {
+    uint4 c[4][2];                 // [corner 00, 01, 10, 11][channel half]
+    float fx, fy;
+    float v00, v01, v10, v11;      // validity (1 inside the image, else 0)
+};
+
+__device__ __forceinline__ void sample_corners(const MsdaP& p, const WinGeo& w, int Wl, int Hl, int startl, const uint4* winh,
+                                               const bf16_t* vhead, float px, float py, Sample& s) {
+    const float x0f = floorf(px), y0f = floorf(py);
+    s.fx = px - x0f; s.fy = py - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;                    // v_cvt saturates; every use is an unsigned range test or a clamp
+    const int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);
+    const bool ix0 = (unsigned)x0 < (unsigned)Wl, ix1 = (unsigned)x1 < (unsigned)Wl;
+    const bool iy0 = (unsigned)y0 < (unsigned)Hl, iy1 = (unsigned)y1 < (unsigned)Hl;
+    s.v00 = (ix0 && iy0) ? 1.f : 0.f; s.v01 = (ix1 && iy0) ? 1.f : 0.f;
+    s.v10 = (ix0 && iy1) ? 1.f : 0.f; s.v11 = (ix1 && iy1) ? 1.f : 0.f;
+    const int lx0 = x0 - w.wx0, ly0 = y0 - w.wy0;
+    const int lx1 = (int)((unsigned)lx0 + 1u), ly1 = (int)((unsigned)ly0 + 1u);
+    const bool wx0 = (unsigned)lx0 < (unsigned)w.ww, wx1 = (unsigned)lx1 < (unsigned)w.ww;
+    const bool wy0 = (unsigned)ly0 < (unsigned)w.wh, wy1 = (unsigned)ly1 < (unsigned)w.wh;
+    // windows are clipped to the image, so "in window" implies "in image"; far = in the image but outside the window
+    const bool far = (ix0 && iy0 && !(wx0 && wy0)) || (ix1 && iy0 && !(wx1 && wy0)) || (ix0 && iy1 && !(wx0 && wy1)) || (ix1 && iy1 && !(wx1 && wy1));
+    if (!far) {
+        const int cx0 = clamp0(lx0, w.ww - 1), cx1 = clamp0(lx1, w.ww - 1), cy0 = clamp0(ly0, w.wh - 1), cy1 = clamp0(ly1, w.wh - 1);
+        const int r0 = w.loff + cy0 * w.ww, r1 = w.loff + cy1 * w.ww;
+        const uint4* a00 = winh + (r0 + cx0) * 2; const uint4* a01 = winh + (r0 + cx1) * 2;
+        const uint4* a10 = winh + (r1 + cx0) * 2; const uint4* a11 = winh + (r1 + cx1) * 2;
+        s.c[0][0] = a00[0]; s.c[0][1] = a00[1]; s.c[1][0] = a01[0]; s.c[1][1] = a01[1];
+        s.c[2][0] = a10[0]; s.c[2][1] = a10[1]; s.c[3][0] = a11[0]; s.c[3][1] = a11[1];
+    } else {                                                    // rare: straight from the value map
+        const int gx0 = clamp0(x0, Wl - 1), gx1 = clamp0(x1, Wl - 1), gy0 = clamp0(y0, Hl - 1), gy1 = clamp0(y1, Hl - 1);
+        const bf16_t* b = vhead + (int64_t)startl * p.vs_s;
+        const uint4* a00 = reinterpret_cast<const uint4*>(b + (int64_t)(gy0 * Wl + gx0) * p.vs_s);
+        const uint4* a01 = reinterpret_cast<const uint4*>(b + (int64_t)(gy0 * Wl + gx1) * p.vs_s);
+        const uint4* a10 = reinterpret_cast<const uint4*>(b + (int64_t)(gy1 * Wl + gx0) * p.vs_s);
+        const uint4* a11 = reinterpret_cast<const uint4*>(b + (int64_t)(gy1 * Wl + gx1) * p.vs_s);
+        s.c[0][0] = a00[0]; s.c[0][1] = a00[1]; s.c[1][0] = a01[0]; s.c[1][1] = a01[1];
+        s.c[2][0] = a10[0]; s.c[2][1] = a10[1]; s.c[3][0] = a11[0]; s.c[3][1] = a11[1];
+    }
+}
+
+__device__ __forceinline__ void fma16(float (&acc)[16], float w, const uint4 (&c)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t u[4] = {c[h].x, c[h].y, c[h].z, c[h].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[h * 8 + 2 * k] = fmaf(w, __uint_as_float(u[k] << 16), acc[h * 8 + 2 * k]);
+            acc[h * 8 + 2 * k + 1] = fmaf(w, __uint_as_float(u[k] & 0xffff0000u), acc[h * 8 + 2 * k + 1]);
+        }
+    }
+}
+__device__ __forceinline__ float dot16(const float (&g)[16], const uint4 (&c)[2]) {
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t u[4] = {c[h].x, c[h].y, c[h].z, c[h].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d0 = fmaf(g[h * 8 + 2 * k], __uint_as_float(u[k] << 16), d0);
+            d1 = fmaf(g[h * 8 + 2 * k + 1], __uint_as_float(u[k] & 0xffff0000u), d1);
+        }
+    }
+    return d0 + d1;
+}
+__device__ __forceinline__ void unpack8(const uint4 v, float* o) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+template <int L, bool BWD>
+__global__ __launch_bounds__(WIN_NT, 2) void msda_win_kernel(const MsdaP p, const GTileP tp) {
+    extern __shared__ __attribute__((aligned(16))) uint4 winv[];
+    constexpr int P = 4, D = 16, LP = L * P;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m0 = blockIdx.y * tp.HPW, n = blockIdx.z;
+    WinGeo wg[L];
+    const int tot = win_layout<L>(p, tp, tx, ty, wg);
+    win_fill<L>(p, wg, tot, tp.HPW, n, m0, winv, tid, nt);
+    __syncthreads();
+
+    const bf16_t* OA = reinterpret_cast<const bf16_t*>(p.q1);
+    const int hshift = tp.HPW == 1 ? 0 : (tp.HPW == 2 ? 1 : (tp.HPW == 4 ? 2 : 3)), hmask = tp.HPW - 1;
+#pragma unroll 1
+    for (int lq = 0; lq < L; ++lq) {
+        int W = p.W[0], H = p.H[0], st = p.start[0];
+#pragma unroll
+        for (int k = 1; k < L; ++k)
+            if (lq == k) { W = p.W[k]; H = p.H[k]; st = p.start[k]; }
+        const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
+        const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
+        const int qw = qx1 - qx0, nit = qw * (qy1 - qy0) * tp.HPW;
+        const float inv_qw = 1.f / (float)max(qw, 1);
+#pragma unroll 1
+        for (int it = tid; it < nit; it += nt) {
+            const int qi = it >> hshift, h = it & hmask, m = m0 + h;
+            const int iy = idiv_small(qi, qw, inv_qw), q = st + (qy0 + iy) * W + qx0 + (qi - iy * qw);
+            const int64_t row = (int64_t)n * p.Lq + q;
+            const bf16_t* orow = OA + row * p.ldq;
+            const uint4* winh = winv + (size_t)h * tot * 2;
+            const bf16_t* vhead = reinterpret_cast<const bf16_t*>(p.value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m;
+            // softmax over the L*P logits of (query, head)
+            float a[16];
+            {
+                const uint4* lp = reinterpret_cast<const uint4*>(orow + p.logit_col + m * LP);
+                unpack8(lp[0], a);
+                if constexpr (LP > 8) unpack8(lp[1], a + 8);
+                float mx = a[0];
+#pragma unroll
+                for (int i = 1; i < LP; ++i) mx = fmaxf(mx, a[i]);
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < LP; ++i) { a[i] = __expf(a[i] - mx); sum += a[i]; }
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int i = 0; i < LP; ++i) a[i] *= inv;
+            }
+            float g[16], acc[16], da[BWD ? 16 : 1];
+            if constexpr (BWD) {
+                const uint4* gp = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.grad_out) + row * ((int64_t)p.M * D) + m * D);
+                unpack8(gp[0], g); unpack8(gp[1], g + 8);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            }
+            const float* rp = p.ref + (int64_t)n * p.ref_bs + (int64_t)q * L * 2;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                float xy[8];
+                unpack8(*reinterpret_cast<const uint4*>(orow + (m * L + l) * 8), xy);
+                const float2 rf = *reinterpret_cast<const float2*>(rp + l * 2);
+                const float rx = rf.x * (float)p.W[l] - 0.5f, ry = rf.y * (float)p.H[l] - 0.5f;
+                float dxy[8];
+#pragma unroll 1                 // rolled on purpose: unrolled, the scheduler hoists the LDS reads of all 16 samples to the front and spills
+                for (int i = 0; i < P; ++i) {
+                    Sample s;
+                    const float ox = i == 0 ? xy[0] : i == 1 ? xy[2] : i == 2 ? xy[4] : xy[6];
+                    const float oy = i == 0 ? xy[1] : i == 1 ? xy[3] : i == 2 ? xy[5] : xy[7];
+                    sample_corners(p, wg[l], p.W[l], p.H[l], p.start[l], winh, vhead, ox + rx, oy + ry, s);
+                    const float aw = i == 0 ? a[l * P] : i == 1 ? a[l * P + 1] : i == 2 ? a[l * P + 2] : a[l * P + 3];
+                    if constexpr (!BWD) {
+                        const float wy0 = (1.f - s.fy) * aw, wy1 = s.fy * aw;
+                        fma16(acc, wy0 * (1.f - s.fx) * s.v00, s.c[0]);
+                        fma16(acc, wy0 * s.fx * s.v01, s.c[1]);
+                        fma16(acc, wy1 * (1.f - s.fx) * s.v10, s.c[2]);
+                        fma16(acc, wy1 * s.fx * s.v11, s.c[3]);
+                    } else {
+                        const float d00 = dot16(g, s.c[0]) * s.v00, d01 = dot16(g, s.c[1]) * s.v01;
+                        const float d10 = dot16(g, s.c[2]) * s.v10, d11 = dot16(g, s.c[3]) * s.v11;
+                        const float T0 = fmaf(s.fy, d10 - d00, d00), T1 = fmaf(s.fy, d11 - d01, d01);      // x0 / x1 columns
+                        const float dai = fmaf(s.fx, T1 - T0, T0), dxi = aw * (T1 - T0), dyi = aw * fmaf(s.fx, (d11 - d01) - (d10 - d00), d10 - d00);
+#pragma unroll
+                        for (int k = 0; k < P; ++k)
+                            if (i == k) { da[l * P + k] = dai; dxy[2 * k] = dxi; dxy[2 * k + 1] = dyi; }
+                    }
+                }
+                if constexpr (BWD) {                      // d/d(offset) = (dpx, dpy): the W, H factors cancel
+                    bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldq + (m * L + l) * 8;
+                    *reinterpret_cast<uint4*>(gp) = make_uint4(pack_bf2(dxy[0], dxy[1]), pack_bf2(dxy[2], dxy[3]), pack_bf2(dxy[4], dxy[5]), pack_bf2(dxy[6], dxy[7]));
+                }
+            }
+            if constexpr (BWD) {                          // softmax backward
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < LP; ++i) dot = fmaf(a[i], da[i], dot);
+#pragma unroll
+                for (int i = 0; i < LP; ++i) da[i] = a[i] * (da[i] - dot);
+                bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldq + p.logit_col + m * LP;
+#pragma unroll
+                for (int i = 0; i < LP; i += 8)
+                    *reinterpret_cast<uint4*>(gp + i) = make_uint4(pack_bf2(da[i], da[i + 1]), pack_bf2(da[i + 2], da[i + 3]), pack_bf2(da[i + 4], da[i + 5]), pack_bf2(da[i + 6], da[i + 7]));
+            } else {
+                bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + row * ((int64_t)p.M * D) + m * D;
+                reinterpret_cast<uint4*>(op)[0] = make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
+                reinterpret_cast<uint4*>(op)[1] = make_uint4(pack_bf2(acc[8], acc[9]), pack_bf2(acc[10], acc[11]), pack_bf2(acc[12], acc[13]), pack_bf2(acc[14], acc[15]));
+            }
+        }
+    }
+}
+
+// host: pick the tile grid / halo so the windows fit the LDS budget; returns window PIXELS of the largest tile (0 = no plan).
+// px_budget: pixels that fit; extra_px: pixels reserved behind the windows.
+static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, size_t extra_px, int halo_hi = 4, int halo_lo = 2) {
+    for (int halo = halo_hi; halo >= halo_lo; halo -= 2) {
         for (int t = 1; t <= 16; t *= 2) {
             const int TX = min(t, max(p.W[0] / 4, 1)), TY = min(t, max(p.H[0] / 4, 1));
-            size_t worst = 0;
+            size_t worst = 0, worst_q = 0;
             for (int ty = 0; ty < TY; ++ty)
                 for (int tx = 0; tx < TX; ++tx) {
-                    size_t fl = 0;
+                    size_t px = 0, nq = 0;
                     for (int l = 0; l < L; ++l) {
                         const int W = p.W[l], H = p.H[l];
                         const int ax = max((tx * W) / TX - halo, 0), bx = min(cdiv((int64_t)(tx + 1) * W, TX) + halo, W);
                         const int ay = max((ty * H) / TY - halo, 0), by = min(cdiv((int64_t)(ty + 1) * H, TY) + halo, H);
-                        fl += (size_t)(bx - ax) * (by - ay) * p.D;
+                        px += (size_t)(bx - ax) * (by - ay);
+                        nq += (size_t)(cdiv((int64_t)W, TX) + 1) * (cdiv((int64_t)H, TY) + 1);      // queries whose centre falls in the tile (upper bound)
                     }
-                    worst = max(worst, fl);
+                    worst = max(worst, px);
+                    worst_q = max(worst_q, nq);
                 }
-            worst += 4 * (size_t)p.D;                          // 4 dummy pixels behind the windows (see the kernel)
-            if (worst * 4 <= (size_t)budget) { tp.TX = TX; tp.TY = TY; tp.HALO = halo; return worst * 4; }
+            // int32 fixed-point headroom of the scatter (2^18 per unit-weight contribution of the tile's largest gradient, the
+            // weights of one (query, head) sum to <= 1): queries per tile x (2^18 + rounding) must stay below 2^31
+            if (worst + extra_px <= px_budget && worst_q <= 8000) { tp.TX = TX; tp.TY = TY; tp.HALO = halo; tp.skip = 0; return worst + extra_px; }
         }
     }
     return 0;
+}
+static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
+    if (p.D != 16) return 0;
+    // 150 KB of int32 windows (one 1024-thread workgroup per CU; 640x480 fits a 4x4 tiling) + 4 dummy pixels (see the kernel)
+    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 4) * 16 * 4;
+}
+
+template <typename TV, typename TQ, int L, bool BWD>
+static bool launch_win(const MsdaP& p, int P, hipStream_t st) {
+    if constexpr (sizeof(TV) != 2 || sizeof(TQ) != 2) return false;
+    else {
+    if (P != 4 || p.D != 16 || L * P % 8 != 0 || !p.grid_queries || p.Lq != p.S || p.vs_s != 16) return false;
+    { const char* e = getenv("POET_NO_WIN_GATHER"); if (e && atoi(e)) return false; }
+    int hpw = 2, nthreads = WIN_NT;
+    { const char* e = getenv("POET_WIN_HPW"); if (e && atoi(e) > 0) hpw = atoi(e); }
+    { const char* e = getenv("POET_WIN_NT"); if (e && (atoi(e) == 256 || atoi(e) == 512)) nthreads = atoi(e); }
+    if (hpw != 1 && hpw != 2 && hpw != 4 && hpw != 8) return false;
+    while (hpw > 1 && p.M % hpw) hpw >>= 1;
+    TileP tp{};
+    GTileP gp{};
+    // two workgroups per CU: <= 78 KB of bf16 windows (32 B per pixel and head) each
+    const size_t px = plan_tiles_px(p, L, tp, (size_t)(78 * 1024) / (32 * hpw), 0);
+    if (!px) return false;
+    gp.TX = tp.TX; gp.TY = tp.TY; gp.HALO = tp.HALO; gp.HPW = hpw;
+    const size_t lds = px * 32 * hpw;
+    auto kern = msda_win_kernel<L, BWD>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(gp.TX * gp.TY, p.M / hpw, p.N), dim3(nthreads), lds, st, p, gp);
+    return true;
+    }
 }
 
 template <typename TQ, int L>
@@ -703,6 +966,9 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
         else hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 1, FUSED>), gridv, block, 0, st, p);
     }
     if (BWD && !(p.parts & 1)) return;
+    if constexpr (FUSED) {
+        if (launch_win<TV, TQ, L, BWD>(p, P, st)) return;
+    }
     if (P == 4) {
         if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
         else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
@@ -815,7 +1081,7 @@ static int fused_args(MsdaP& p, const void* value, int64_t vs_n, int64_t vs_s, i
 extern "C" int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m, const int64_t* shapes,
                                    const int64_t* starts, const void* offattn, int64_t ldq, int logit_col,
                                    const float* ref, int64_t ref_bs, void* out, int N, int S, int M, int D, int L,
-                                   int P, int Lq, int v_dtype, int q_dtype, void* stream) {
+                                   int P, int Lq, int v_dtype, int q_dtype, int grid_queries, void* stream) {
     MsdaP p{};
     int rc = fill_common(p, shapes, starts, N, S, M, D, L, P, Lq);
     if (rc) return rc;
@@ -823,6 +1089,7 @@ extern "C" int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s
     if (rc) return rc;
     POET_CHECK(out, POET_ERR_ARG, "msda_fused_fwd: null out");
     p.out = out;
+    p.grid_queries = grid_queries;
     rc = dispatch<true, false>(p, L, P, v_dtype, q_dtype, (hipStream_t)stream);
     if (rc) return rc;
     POET_LAUNCH_CHECK();

@@ -9,10 +9,10 @@ namespace poet {
 
 constexpr int LN_MAXIT = 4;   // d <= 1024
 
-template <typename TX, typename TR>
+template <typename TX, typename TR, typename TZ = TX>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const TR* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     TR* __restrict__ y, TX* __restrict__ z, float* __restrict__ mean,
+                                                     TR* __restrict__ y, TZ* __restrict__ z, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t rows, int d, float eps,
                                                      uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16,
                                                      const uint32_t* __restrict__ seed_dev) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
             for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * g[e] + b[e];
             vec<TR, 4>::st(y + row * d + c, o);
             if (y16) vec<bf16_t, 4>::st(y16 + row * d + c, o);
-            if (z) vec<TX, 4>::st(z + row * d + c, v[it]);
+            if (z) vec<TZ, 4>::st(z + row * d + c, v[it]);
         }
     }
 }
@@ -281,8 +281,9 @@ using namespace poet;
 
 extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
                            float* mean, float* rstd, int64_t rows, int d, float eps, float drop_p, uint32_t seed,
-                           int dtype_x, int dtype_r, void* y_bf16, const uint32_t* seed_dev, void* stream) {
+                           int dtype_x, int dtype_r, int dtype_z, void* y_bf16, const uint32_t* seed_dev, void* stream) {
     POET_CHECK(x && gamma && beta && y, POET_ERR_ARG, "ln_fwd: null pointer");
+    if (dtype_z < 0) dtype_z = dtype_x;
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_fwd: d=%d unsupported", d);
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "ln_fwd: drop_p");
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
@@ -290,7 +291,12 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
     dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev)
-    POET_DT2(dtype_x, dtype_r, LN_FWD);
+    if (dtype_z == dtype_x) {
+        POET_DT2(dtype_x, dtype_r, LN_FWD);
+    } else {        // fp32 branch input (the GEMM's accumulators, never rounded to bf16) with the pre-norm sum saved in bf16 for backward
+        POET_CHECK(dtype_x == POET_F32 && dtype_r == POET_F32 && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED, "ln_fwd: dtype triple (%d,%d,%d)", dtype_x, dtype_r, dtype_z);
+        ln_fwd_kernel<float, float, bf16_t><<<grid, block, 0, st>>>((const float*)x, (const float*)res, gamma, beta, (float*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev);
+    }
 #undef LN_FWD
     POET_LAUNCH_CHECK();
     return POET_OK;

@@ -352,11 +352,11 @@ def msda_bwd(value, geom: LevelGeom, loc, attn, grad_out, grad_value, grad_loc, 
                "poet_msda_bwd")
 
 
-def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, out, N, M, D, P, Lq):
+def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, out, N, M, D, P, Lq, grid_queries=False):
     lib = _lib.load()
     _lib.check(lib.poet_msda_fused_fwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
                                        offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, out.data_ptr(),
-                                       N, geom.S, M, D, geom.L, P, Lq, dcode(value), dcode(offattn), _stream()),
+                                       N, geom.S, M, D, geom.L, P, Lq, dcode(value), dcode(offattn), int(grid_queries), _stream()),
                "poet_msda_fused_fwd")
     return out
 
@@ -382,7 +382,8 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None):
     lib = _lib.load()
     _lib.check(lib.poet_ln_fwd(_req(x, "x").data_ptr(), _ptr(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(z),
-                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y), _ptr(y16),
+                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y),
+                               -1 if z is None else dcode(z), _ptr(y16),
                                _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_fwd")
     return y
 

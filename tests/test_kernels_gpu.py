@@ -514,7 +514,10 @@ def test_msda_fused_grid_queries_tiled_scatter(ops, shapes, m, dt):
     # 2^-18 of the tile's largest |grad_out| per contribution)
     tol = 2e-4 if dt == torch.float32 else 2e-3
     assert (outs[0][0] - outs[1][0]).abs().max().item() < tol * max(1.0, scale)
-    assert torch.equal(outs[0][1], outs[1][1])
+    # d(offsets | logits): the grid path stages value windows in LDS (bf16) and sums per lane, the plain path gathers from
+    # global memory and reduces across lanes: the same fp32 arithmetic in a different order, then one bf16 rounding
+    gs = outs[0][1].abs().max().item()
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= (1e-5 if dt == torch.float32 else 1e-2) * gs
 
 
 def _explicit_from_fused(shapes, value_nsmd, oa, ref_pts, gout, m, p):
@@ -591,8 +594,11 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case):
     vdev = dev(value.permute(0, 2, 1, 3).contiguous())                                        # head-major (N,M,S,D)
     vstr = (m * S * d, d, S * d)
     out = torch.empty(n, S, m * d, dtype=torch.bfloat16, device="cuda")
-    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S)
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
     e_out = (out.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item()
+    out_g = torch.empty_like(out)                             # the plain gather kernel (decoder path) on the same problem
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_g, n, m, d, p, S, grid_queries=False)
+    assert (out_g.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item() < 6e-3
     gv = torch.zeros(n, m, S, d, device="cuda")
     goa = torch.empty_like(dev(oa))
     ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv, goa, n, m, d, p, S, grid_queries=True)
