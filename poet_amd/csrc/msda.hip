@@ -873,8 +873,8 @@ __global__ __launch_bounds__(WIN_NT, 2) void msda_win_kernel(const MsdaP p, cons
 
 // host: pick the tile grid / halo so the windows fit the LDS budget; returns window PIXELS of the largest tile (0 = no plan).
 // px_budget: pixels that fit; extra_px: pixels reserved behind the windows.
-static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, size_t extra_px, int halo_hi = 4, int halo_lo = 2) {
-    for (int halo = halo_hi; halo >= halo_lo; halo -= 2) {
+static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, size_t extra_px, int halo_hi = 4, int halo_lo = 2, int halo_step = 2) {
+    for (int halo = halo_hi; halo >= halo_lo; halo -= halo_step) {
         for (int t = 1; t <= 16; t *= 2) {
             const int TX = min(t, max(p.W[0] / 4, 1)), TY = min(t, max(p.H[0] / 4, 1));
             size_t worst = 0, worst_q = 0;
@@ -910,15 +910,19 @@ static bool launch_win(const MsdaP& p, int P, hipStream_t st) {
     else {
     if (P != 4 || p.D != 16 || L * P % 8 != 0 || !p.grid_queries || p.Lq != p.S || p.vs_s != 16) return false;
     { const char* e = getenv("POET_NO_WIN_GATHER"); if (e && atoi(e)) return false; }
-    int hpw = 2, nthreads = WIN_NT;
+    int hpw = 1, nthreads = 256;
     { const char* e = getenv("POET_WIN_HPW"); if (e && atoi(e) > 0) hpw = atoi(e); }
     { const char* e = getenv("POET_WIN_NT"); if (e && (atoi(e) == 256 || atoi(e) == 512)) nthreads = atoi(e); }
     if (hpw != 1 && hpw != 2 && hpw != 4 && hpw != 8) return false;
     while (hpw > 1 && p.M % hpw) hpw >>= 1;
     TileP tp{};
     GTileP gp{};
-    // two workgroups per CU: <= 78 KB of bf16 windows (32 B per pixel and head) each
-    const size_t px = plan_tiles_px(p, L, tp, (size_t)(78 * 1024) / (32 * hpw), 0);
+    // <= 78 KB of bf16 windows (32 B per pixel and head) per workgroup: two (three at ~52 KB) workgroups per CU.  Halo 6 px:
+    // the reference's initial offsets reach 4 px (L-inf) and the right / lower bilinear corner one more; at halo 4, 1 % of
+    // the samples -- half of all (wave, sample) steps -- would take the global-memory path
+    int halo_hi = 6;
+    { const char* e = getenv("POET_WIN_HALO"); if (e && atoi(e) >= 2 && atoi(e) <= 12) halo_hi = atoi(e); }
+    const size_t px = plan_tiles_px(p, L, tp, (size_t)(78 * 1024) / (32 * hpw), 0, halo_hi, min(halo_hi, 4), 1);
     if (!px) return false;
     gp.TX = tp.TX; gp.TY = tp.TY; gp.HALO = tp.HALO; gp.HPW = hpw;
     const size_t lds = px * 32 * hpw;

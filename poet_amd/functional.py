@@ -43,6 +43,9 @@ class EncoderFn(torch.autograd.Function):
         """src (N,S,d) residual-stream dtype; pos (N,S,d); ref (N,S,L,2) fp32; mask (N*S) uint8 or None;
         cfg dict(M,P,p,training,n_layers,act).  Returns (memory, memory16): the stream and its bf16 GEMM-operand copy
         (the same tensor in the pure modes); memory16 is non-differentiable, gradients flow through `memory`."""
+        if pos.requires_grad:
+            raise NotImplementedError("EncoderFn: a position embedding that requires grad (learned positional encoding) is not supported: "
+                                      "its gradient would be dropped silently (only level_embed is differentiated)")
         N, S, d = src.shape
         x = src.reshape(N * S, d)
         act = cfg.get("act") or src.dtype
@@ -94,6 +97,9 @@ class DecoderFn(torch.autograd.Function):
         """memory (N,S,d): differentiable handle in the residual-stream dtype; memory16: the copy the value projections
         actually read (bf16 in the bf16 policy); tgt,qpos (N,Q,d) fp32; ref_in (N,Q,L,2) fp32.
         Returns hs (n_layers,N,Q,d) fp32."""
+        if qpos.requires_grad:
+            raise NotImplementedError("DecoderFn: query_pos that requires grad (learned query embeddings, query_embedding_mode="
+                                      "'learned') is not supported: the backward program produces d(tgt) only")
         N, S, d = memory.shape
         Q, M = tgt.shape[1], cfg["M"]
         D = d // M

@@ -139,3 +139,46 @@ def test_input_side_batching_and_prefetch_protocol():
                 break
             seen.append(float(t[0]["boxes"][0, 0]))
         assert seen == [0.0, 1.0, 2.0] and pf.next() == (None, None)
+
+
+def test_arena_refuses_trainable_parameters_outside_the_hot_path():
+    """A trainable backbone (the reference trains it at lr_backbone, main.py:253-271) must not land in the flat arena, where it
+    would be weight-decayed at the transformer's learning rate without ever receiving a gradient."""
+    from poet_amd.engine import ParamArena
+    m = _Toy()
+    m.backbone = nn.Linear(4, 4)
+    with pytest.raises(ValueError, match="outside the hot path"):
+        ParamArena(m)
+    for p in m.backbone.parameters():
+        p.requires_grad_(False)
+    ParamArena(m)                                            # frozen: fine
+
+
+def test_arena_lr_schedule_and_state_dict_roundtrip():
+    """StepLR semantics on the device-side LR table (main.py:277-278) and optimizer-state checkpointing (main.py:293-301):
+    the 0.1x sampling_offsets ratio survives set_lr; moments / step / lr round-trip through state_dict; loading weights into
+    the model refreshes the bf16 operand shadow."""
+    from poet_amd.engine import ParamArena
+    torch.manual_seed(1)
+    m = _Toy()
+    a = ParamArena(m, lr=2e-4)
+    base = a.lr_scale.clone()
+    a.step_lr(epoch=7, lr_drop=5)                             # one decay step: lr = 2e-5
+    assert abs(a.lr - 2e-5) < 1e-12
+    assert torch.allclose(a.lr_scale, base * 0.1)
+    so = [o for n, p, o in a.entries if "sampling_offsets.weight" in n][0]
+    lin = [o for n, p, o in a.entries if "linear1.weight" in n][0]
+    assert abs(float(a.lr_scale[so // 64]) / float(a.lr_scale[lin // 64]) - 0.1) < 1e-6
+    a.m.uniform_(); a.v.uniform_(); a.step_count = 12
+    sd = a.state_dict()
+    m2 = _Toy()
+    b = ParamArena(m2, lr=2e-4)
+    b.load_state_dict(sd)
+    assert torch.equal(b.m, a.m) and torch.equal(b.v, a.v) and b.step_count == 12 and int(b.step_word) == 12
+    assert abs(b.lr - 2e-5) < 1e-12 and torch.allclose(b.lr_scale, a.lr_scale)
+    # load_state_dict on the MODEL copies into the arena views in place; the bf16 shadow must follow
+    m2.load_state_dict(m.state_dict())
+    for (n, p), (_, q) in zip(m2.named_parameters(), m.named_parameters()):
+        assert torch.equal(p, q)
+        if hasattr(p, "_bf16"):
+            assert torch.equal(p._bf16, q.detach().to(torch.bfloat16)), n

@@ -214,7 +214,7 @@ GRAD_TOL_F32, GRAD_TOL_BF16 = 1e-2, 6e-2
 # is decided by the rounding of ITS `2 * loc - 1` / grid_sample arithmetic: those goldens are not a function of the inputs.
 KINK_TOL = 0.5
 AMP0 = 8.0       # 6D -> R amplification up to which the rotation bound is the plain tolerance (see _rotation_amplification)
-STRICT_FINAL = ("ycbv", "lmo")     # configs whose FINAL-layer rotations must meet the plain tolerance whatever the amplification
+
 
 
 def _rotation_amplification(name, batch, pad, init):
@@ -242,10 +242,10 @@ def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, b
     the checksums of all parameter gradients), fp32 at 1e-3 and the benchmarked bf16 policy at 1e-2, max-norm over every
     query.  At >= 4096 token rows per image the forward AND backward run exactly the kernels the benchmark runs
     (weight-stationary / K-chunked / dW streaming GEMMs, LDS-tiled value-gradient scatter, bf16 MSDA gathers).
-    Rotations: the plain tolerance on the model outputs (final decoder layer) of the YCB-V and LM-O goldens unconditionally,
-    and on every layer's query whose 6D -> R map amplifies by <= AMP0; tolerance x amplification / AMP0 beyond -- i.e. never
-    more than tol / AMP0 = 1.25e-3 (bf16) on the raw 6D head output.  (The auxiliary layers of the closed-form fixtures hold
-    queries at 50-150x: |a2_perp| < 0.01.)"""
+    Rotations: the plain tolerance on the model outputs (final decoder layer) unconditionally, and on every auxiliary layer's
+    query whose 6D -> R map amplifies by <= AMP0; tolerance x amplification / AMP0 beyond -- i.e. never more than
+    tol / AMP0 = 1.25e-3 (bf16) on the raw 6D head output.  The closed-form fixtures emit unit-scale 6D vectors (amplification
+    ~1, oracle/formula.py); the reference's own random init (init=True) reaches 23x on the final and 65x on auxiliary layers."""
     g = np.load(os.path.join(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz"))
     amp = _rotation_amplification(name, batch, pad, init)                      # (L, N, Q)
     allow = torch.clamp(amp / AMP0, min=1.0)[..., None, None]
@@ -291,8 +291,7 @@ def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, b
               f"{amp.numel()} (layer, query) above {AMP0:.0f}x; worst error / allowance {over:.2e}); max loss err {lerr:.2e}; "
               f"worst grad checksums {[(n, round(e, 4)) for _, e, n in errs[:3]]}")
         assert dt < tol and over < tol, (dtype, dt, over)
-        if name in STRICT_FINAL:
-            assert dR[-1].max().item() < tol, (dtype, dR[-1].max().item())
+        assert dR[-1].max().item() < tol, (dtype, dR[-1].max().item())     # the model outputs: plain tolerance, whatever the amplification
         assert lerr < (2e-4 if dtype == torch.float32 else 2e-2) * max(1.0, float(np.abs(g["loss_values"]).max())), lerr
         assert errs[0][0] <= 1.0, errs[:8]
 
@@ -441,6 +440,71 @@ def test_graphed_trainer_matches_eager(gpu):
         assert worst < 1e-3, (mode, worst)
     worst = max((runs["segmented"][1][n] - runs["graph"][1][n]).abs().max().item() for n in runs["graph"][1])
     assert worst < 1e-3, worst                    # same kernels in the same order (fp32 atomics make runs differ at ~1e-4 after AdamW)
+
+
+def test_graphed_trainer_follows_changing_padding(gpu):
+    """The captured graphs read the IMAGE mask (the extra feature level's mask, valid ratios and sine encoding derive from
+    it) from a static buffer: it must be refreshed on every replay.  Steps alternate between two paddings; graph == eager."""
+    import poet_amd
+    from poet_amd.synthetic import image_mask
+    runs = {}
+    for mode in ("eager", "graph"):
+        r = gpu("tiny", 2, True, "bf16", dropout=0.0)
+        r["model"].train()
+        tr = (poet_amd.Trainer if mode == "eager" else poet_amd.GraphedTrainer)(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1,
+                                                                                **({} if mode == "eager" else {"warm": 1}))
+        sizes_b = [(r["sizes"][0][0] - 16, r["sizes"][0][1] - 32), (r["sizes"][1][0] + 8, r["sizes"][1][1] - 24)]
+        hw = r["samples"].mask.shape[-2:]
+        losses = []
+        for step in range(6):
+            sizes = r["sizes"] if step % 2 == 0 else sizes_b
+            mask = image_mask(sizes, "cuda")
+            full = torch.ones((len(sizes), *hw), dtype=torch.bool, device="cuda")          # same padded canvas every step
+            full[:, : mask.shape[1], : mask.shape[2]] = mask
+            total, _ = tr.step(poet_amd.NestedTensor(None, full), r["targets"])
+            losses.append(float(total))
+        runs[mode] = losses
+    assert runs["graph"] == pytest.approx(runs["eager"], rel=2e-3, abs=2e-3), runs
+    assert abs(runs["eager"][0] - runs["eager"][1]) > 1e-4          # the two paddings really give different losses
+
+
+def test_optimizer_state_resume_and_lr_schedule(gpu):
+    """Checkpoint / resume of the flat-arena optimiser (the reference saves 'optimizer' and 'lr_scheduler', main.py:293-301):
+    3 steps + state_dict + fresh model/trainer + load + 2 steps == 5 uninterrupted steps, for the graphed trainer, with an
+    LR drop (StepLR) in between that the replayed graphs must follow."""
+    import poet_amd
+    def run(resume):
+        r = gpu("tiny", 2, True, "bf16", dropout=0.0)
+        r["model"].train()
+        tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1)
+        losses = []
+        for step in range(5):
+            if step == 2:
+                tr.arena.set_lr(2e-5)                               # scheduler step: captured graphs read the device-side table
+            if resume and step == 3:
+                msd, asd = {k: v.clone() for k, v in r["model"].state_dict().items()}, tr.arena.state_dict()
+                r = gpu("tiny", 2, True, "bf16", dropout=0.0, default_init=True)         # different weights until the load
+                r["model"].train()
+                tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1)
+                r["model"].load_state_dict(msd)                     # (post-hook refreshes the bf16 operand shadow)
+                tr.arena.load_state_dict(asd)
+            total, _ = tr.step(r["samples"], r["targets"])
+            losses.append(float(total))
+        return losses, torch.cat([p.detach().float().flatten() for p in r["model"].parameters()]).cpu()
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert lb == pytest.approx(la, rel=2e-3, abs=2e-3), (la, lb)
+    assert (pa - pb).abs().max().item() < 1e-3
+    # the LR drop is visible: the last steps move the weights ~10x less than the first
+    r = gpu("tiny", 2, True, "bf16", dropout=0.0)
+    r["model"].train()
+    tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=0.0, max_norm=0.1, warm=1)
+    flat = lambda: tr.arena.flat.clone()
+    tr.step(r["samples"], r["targets"]); tr.step(r["samples"], r["targets"])          # eager warm-up + capture
+    p0 = flat(); tr.step(r["samples"], r["targets"]); d_hi = (flat() - p0).abs().mean().item()
+    tr.arena.set_lr(2e-6)
+    p0 = flat(); tr.step(r["samples"], r["targets"]); d_lo = (flat() - p0).abs().mean().item()
+    assert d_lo < 0.05 * d_hi, (d_hi, d_lo)
 
 
 def test_device_resident_targets_match_host_targets(gpu):
