@@ -541,32 +541,57 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     // bank-quarter-aware corner order changes nothing.  The kernel is bound by the ~8 cycles the unit takes per ds_add.)
     const int dummy = (loff[L] + r) * 64;
 
-#pragma unroll 1
-    for (int lq = 0; lq < ((tp.skip & 2) ? 0 : L); ++lq) {
-        const int W = p.W[lq], H = p.H[lq];
+    // ONE loop over the tile's queries of ALL levels (a flat index, the query's own level found by three compares): the
+    // per-level loops cost a partly idle last round EACH -- at 640x480 a tile holds 300 + 75 + 20 + 6 queries, i.e. 5 + 2 + 1 + 1
+    // = 9 rounds of 64 query slots against 7 for the flat range.
+    // (plain SSA scalars and a macro, no lambdas with by-reference captures here: hipcc folds `cond ? *p1 : *p2` over captured
+    // variables into a load through a SELECTED ADDRESS, which pins them -- and everything captured alongside -- in scratch memory)
+    struct QGeo { int qw, qb, cnt; float iw; };
+    auto qgeo = [=](int W, int H, int start) __attribute__((always_inline)) {
         const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
         const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
-        const int qw = qx1 - qx0, nq = qw * (qy1 - qy0);
-        const float inv_qw = 1.f / (float)max(qw, 1);
-        const int qbase = p.start[lq] + qy0 * W + qx0;
+        QGeo r;
+        r.qw = qx1 - qx0;
+        r.iw = 1.f / (float)max(r.qw, 1);
+        r.qb = start + qy0 * W + qx0;
+        r.cnt = r.qw * (qy1 - qy0);
+        return r;
+    };
+    const QGeo g0 = qgeo(p.W[0], p.H[0], p.start[0]);
+    const QGeo g1 = L > 1 ? qgeo(p.W[L > 1 ? 1 : 0], p.H[L > 1 ? 1 : 0], p.start[L > 1 ? 1 : 0]) : QGeo{0, 0, 0, 1.f};
+    const QGeo g2 = L > 2 ? qgeo(p.W[L > 2 ? 2 : 0], p.H[L > 2 ? 2 : 0], p.start[L > 2 ? 2 : 0]) : QGeo{0, 0, 0, 1.f};
+    const QGeo g3 = L > 3 ? qgeo(p.W[L > 3 ? 3 : 0], p.H[L > 3 ? 3 : 0], p.start[L > 3 ? 3 : 0]) : QGeo{0, 0, 0, 1.f};
+    const int c1 = g0.cnt, c2 = c1 + g1.cnt, c3 = c2 + g2.cnt, c4 = c3 + g3.cnt;
+    const int W0 = p.W[0], W1 = p.W[L > 1 ? 1 : 0], W2 = p.W[L > 2 ? 2 : 0], W3 = p.W[L > 3 ? 3 : 0];
+    {
+        const int nq = (tp.skip & 2) ? 0 : c4;
         // software prefetch: the operands of query i + NSLOT are in flight while query i is scattered
         float n_g = 0.f, n_lg = -3.0e38f, n_ox = 0.f, n_oy = 0.f, n_rx = 0.f, n_ry = 0.f;
-        auto fetch = [&](int i) __attribute__((always_inline)) {
-            const int iy = idiv_small(i, qw, inv_qw);
-            const int q = qbase + iy * W + (i - iy * qw);
-            const uint32_t row = (uint32_t)(row0 + q);
-            n_g = bf2f(ldg32<TQ>(p.grad_out, row * g_row + g_lane));
-            const uint32_t oxy = ldg32<uint32_t>(p.q1, row * q_row + of_lane);         // (off_x, off_y) bf16 pair
-            n_lg = has ? bf2f(ldg32<TQ>(p.q1, row * q_row + lg_lane)) : -3.0e38f;
-            n_ox = __uint_as_float(oxy << 16);
-            n_oy = __uint_as_float(oxy & 0xffff0000u);
-            const float2 rf = ldg32<float2>(p.ref, (uint32_t)q * rf_q + rf_lane);
-            n_rx = rf.x; n_ry = rf.y;
-        };
-        if (slot < nq) fetch(slot);
+#define DV_FETCH(I)                                                                                                   \
+        do {                                                                                                          \
+            const int fi_ = (I);                                                                                      \
+            const bool s1_ = L > 1 && fi_ >= c1, s2_ = L > 2 && fi_ >= c2, s3_ = L > 3 && fi_ >= c3;                    \
+            const int li_ = fi_ - (s3_ ? c3 : s2_ ? c2 : s1_ ? c1 : 0);                                               \
+            const int qw_ = s3_ ? g3.qw : s2_ ? g2.qw : s1_ ? g1.qw : g0.qw;                                          \
+            const int qb_ = s3_ ? g3.qb : s2_ ? g2.qb : s1_ ? g1.qb : g0.qb;                                          \
+            const int Wq_ = s3_ ? W3 : s2_ ? W2 : s1_ ? W1 : W0;                                                      \
+            const float iw_ = s3_ ? g3.iw : s2_ ? g2.iw : s1_ ? g1.iw : g0.iw;                                        \
+            const int iy_ = idiv_small(li_, qw_, iw_);                                                                \
+            const int q_ = qb_ + iy_ * Wq_ + (li_ - iy_ * qw_);                                                       \
+            const uint32_t row_ = (uint32_t)(row0 + q_);                                                              \
+            n_g = bf2f(ldg32<TQ>(p.grad_out, row_ * g_row + g_lane));                                                 \
+            const uint32_t oxy_ = ldg32<uint32_t>(p.q1, row_ * q_row + of_lane);   /* (off_x, off_y) bf16 pair */      \
+            n_lg = has ? bf2f(ldg32<TQ>(p.q1, row_ * q_row + lg_lane)) : -3.0e38f;                                    \
+            n_ox = __uint_as_float(oxy_ << 16);                                                                       \
+            n_oy = __uint_as_float(oxy_ & 0xffff0000u);                                                               \
+            const float2 rf_ = ldg32<float2>(p.ref, (uint32_t)q_ * rf_q + rf_lane);                                   \
+            n_rx = rf_.x; n_ry = rf_.y;                                                                               \
+        } while (0)
+        if (slot < nq) DV_FETCH(slot);
+#pragma unroll 1
         for (int i = slot; i < nq; i += NSLOT) {
             const float gs = n_g * scale, lg = n_lg, ox = n_ox, oy = n_oy, rx = n_rx, ry = n_ry;
-            if (i + NSLOT < nq) fetch(i + NSLOT);
+            if (i + NSLOT < nq) DV_FETCH(i + NSLOT);
             // ---- lane j (< L*P) of the slot prepares sample point j: softmax over the DPP row, then its 4 corners ----
             const float mx = row16_max(lg);
             const float e = __expf(lg - mx);                             // lanes without a point carry -3e38: e = 0
@@ -608,15 +633,23 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             row_points<LP>(coff, cw, [&](int off, float wv) {
                 atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (off + lane_off)), cvt_rpi(wv * gs));
             });
-            if (__any(far)) {                                // compact and slow on purpose (rare)
+            // In-image corners outside the window: global atomics, one far POINT at a time (its owner lane found by ballot, its
+            // corner data read with v_readlane, applied by the 16 channel lanes of its row).  Cost is proportional to the number
+            // of far points: 1 % of them (learned offsets drifting past the halo) used to send half of all waves through a
+            // 64-step loop.
+            unsigned long long fmask = __ballot(far);
+            if (fmask) {
                 const int gp0 = startl + y0 * Wl + x0;
-#pragma unroll 1
-                for (int pt = 0; pt < LP; ++pt) {
+                const float gsi = gs * inv;
+                while (fmask) {
+                    const int src = __ffsll((long long)fmask) - 1;
+                    fmask &= fmask - 1;
+                    const bool mine = ((tid & 63) >> 4) == (src >> 4);
+                    const int gpb = __builtin_amdgcn_readlane(gp0, src), wlr = __builtin_amdgcn_readlane(Wl, src);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float wv = __shfl(cfar[k], pt, 16);
-                        const int gp = __shfl(gp0 + (k & 1) + (k >> 1) * Wl, pt, 16);
-                        if (wv != 0.f) atomicAdd(gvb + (int64_t)gp * p.vs_s, wv * gs * inv);
+                        const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfar[k]), src));
+                        if (mine && wv != 0.f) atomicAdd(gvb + (int64_t)(gpb + (k & 1) + (k >> 1) * wlr) * p.vs_s, wv * gsi);
                     }
                 }
             }
@@ -624,21 +657,33 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     }
     __syncthreads();
     if (tp.skip & 4) return;
-#pragma unroll
-    for (int l2 = 0; l2 < L; ++l2) {
-        const int cnt = wp[l2] * wh[l2] * D;
-        const float inv_wp = 1.f / (float)wp[l2];
-        float* gl = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)p.start[l2] * p.vs_s;
+    // flush.  The window geometry is RECOMPUTED here from an opaque copy of the tile index (a handful of scalar ops): kept
+    // live across the accumulate loop, its ~25 uniform values push the kernel past the SGPR file and into scratch memory.
+    int txf = tx, tyf = ty;
+    asm volatile("" : "+s"(txf), "+s"(tyf));
+    int lofff = 0;
+    // (explicit calls with constant level indices: see qgeo above)
+    auto flush_level = [&, txf, tyf](int W, int H, int start) __attribute__((always_inline)) {
+        const int ax = max((txf * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((txf + 1) * W, tp.TX) + tp.HALO, W);
+        const int ay = max((tyf * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((tyf + 1) * H, tp.TY) + tp.HALO, H);
+        const int wpf = bx - ax, cnt = wpf * (by - ay) * D;
+        const float inv_wp = 1.f / (float)wpf;
+        float* gl = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)start * p.vs_s;
         for (int i = tid; i < cnt; i += TILED_NT) {
-            const int v = win[loff[l2] * D + i];
+            const int v = win[lofff * D + i];
             if (v != 0) {
                 const int cc = i & 15, pix = i >> 4;
-                const int py = idiv_small(pix, wp[l2], inv_wp);
-                const int xx = wx0[l2] + pix - py * wp[l2], yy = wy0[l2] + py;
-                atomicAdd(gl + (int64_t)(yy * p.W[l2] + xx) * p.vs_s + cc, (float)v * inv);
+                const int py = idiv_small(pix, wpf, inv_wp);
+                const int xx = ax + pix - py * wpf, yy = ay + py;
+                atomicAdd(gl + (int64_t)(yy * W + xx) * p.vs_s + cc, (float)v * inv);
             }
         }
-    }
+        lofff += wpf * (by - ay);
+    };
+    flush_level(p.W[0], p.H[0], p.start[0]);
+    if constexpr (L > 1) flush_level(p.W[1], p.H[1], p.start[1]);
+    if constexpr (L > 2) flush_level(p.W[2], p.H[2], p.start[2]);
+    if constexpr (L > 3) flush_level(p.W[3], p.H[3], p.start[3]);
 }
 
 // ====================================================================================================================
@@ -909,7 +954,10 @@ static bool launch_win(const MsdaP& p, int P, hipStream_t st) {
     if constexpr (sizeof(TV) != 2 || sizeof(TQ) != 2) return false;
     else {
     if (P != 4 || p.D != 16 || L * P % 8 != 0 || !p.grid_queries || p.Lq != p.S || p.vs_s != 16) return false;
-    { const char* e = getenv("POET_NO_WIN_GATHER"); if (e && atoi(e)) return false; }
+    // OPT-IN (POET_WIN_GATHER=1).  Measured at 640x480, bs 16, M = 16: forward 267 us / backward 359 us
+    // at the best configuration against 250 / 330 us for the L1-served gathers below -- per-lane random 32-B LDS reads
+    // conflict 3-4 ways and a lane's offset / logit / output rows are 1.5 KB apart in HBM.
+    { const char* e = getenv("POET_WIN_GATHER"); if (!(e && atoi(e))) return false; }
     int hpw = 1, nthreads = 256;
     { const char* e = getenv("POET_WIN_HPW"); if (e && atoi(e) > 0) hpw = atoi(e); }
     { const char* e = getenv("POET_WIN_NT"); if (e && (atoi(e) == 256 || atoi(e) == 512)) nthreads = atoi(e); }
@@ -917,10 +965,10 @@ static bool launch_win(const MsdaP& p, int P, hipStream_t st) {
     while (hpw > 1 && p.M % hpw) hpw >>= 1;
     TileP tp{};
     GTileP gp{};
-    // <= 78 KB of bf16 windows (32 B per pixel and head) per workgroup: two (three at ~52 KB) workgroups per CU.  Halo 6 px:
+    // <= 78 KB of bf16 windows (32 B per pixel and head) per workgroup: two (three at ~52 KB) workgroups per CU.  Halo 5 px:
     // the reference's initial offsets reach 4 px (L-inf) and the right / lower bilinear corner one more; at halo 4, 1 % of
-    // the samples -- half of all (wave, sample) steps -- would take the global-memory path
-    int halo_hi = 6;
+    // noisy samples -- half of all (wave, sample) steps -- would take the global-memory path
+    int halo_hi = 5;
     { const char* e = getenv("POET_WIN_HALO"); if (e && atoi(e) >= 2 && atoi(e) <= 12) halo_hi = atoi(e); }
     const size_t px = plan_tiles_px(p, L, tp, (size_t)(78 * 1024) / (32 * hpw), 0, halo_hi, min(halo_hi, 4), 1);
     if (!px) return false;

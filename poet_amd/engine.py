@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import math
 import os
+import re
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -20,14 +21,21 @@ ALIGN = 64   # elements (256 B): every parameter starts on a 16-B-aligned, vecto
 HOT_PREFIXES = ("input_proj.", "transformer.", "translation_head", "rotation_head")
 
 
-def _bucket_of(name: str) -> str:
-    """Backward-completion order of the four autograd nodes (heads -> decoder -> encoder -> input_proj)."""
+_ENC_LAYER = re.compile(r"^transformer\.encoder\.layers\.(\d+)\.")
+
+
+def _bucket_of(name: str, n_enc: int = 0) -> str:
+    """Backward-completion order of the autograd nodes: heads -> decoder -> encoder layer n-1 ... 0 (one bucket each, the
+    reference's DDP buckets, main.py:280-283) -> level_embed / the rest of the encoder -> input_proj.  Names sort in that order."""
     if name.startswith(("translation_head", "rotation_head")):
         return "0_heads"
     if name.startswith("transformer.decoder"):
         return "1_decoder"
+    m = _ENC_LAYER.match(name)
+    if m and n_enc:
+        return f"2_encoder_{n_enc - 1 - int(m.group(1)):02d}"
     if name.startswith(("transformer.encoder", "transformer.level_embed")):
-        return "2_encoder"
+        return "2_encoder_99"
     return "3_input_proj"
 
 
@@ -63,8 +71,10 @@ class ParamArena:
         # one for dX, one for dW -- while state_dict still sees two nn.Linear modules.  The 0.1x learning rate of
         # sampling_offsets (main.py:41,253-271) is a per-64-element multiplier table instead of a separate arena range.
         byname = dict(named)
+        n_enc = 1 + max([int(m.group(1)) for m in (_ENC_LAYER.match(n) for n, _ in named) if m] or [-1])
+        bucket = lambda n: _bucket_of(n, n_enc)
         order, taken = [], set()
-        for n, p in sorted(named, key=lambda t: _bucket_of(t[0])):
+        for n, p in sorted(named, key=lambda t: bucket(t[0])):
             if n in taken:
                 continue
             if n.endswith("sampling_offsets.weight"):
@@ -83,7 +93,7 @@ class ParamArena:
         cur, start = None, 0
         scale = []
         for n, p in order:
-            b = _bucket_of(n)
+            b = bucket(n)
             if b != cur:
                 if cur is not None:
                     self.buckets.append((cur, start, off))
@@ -600,7 +610,9 @@ class Trainer:
         return total.detach(), loss_dict
 
 
-SEGMENT_TAGS = ("0_heads", "1_decoder", "2_encoder", "3_input_proj")      # bucket names of ParamArena, backward order
+def segment_tags(arena: ParamArena):
+    """Bucket names of the arena = the points the graphed trainer cuts backward at, in backward order."""
+    return [b[0] for b in arena.buckets]
 
 
 class _Replay(torch.autograd.Function):
@@ -622,10 +634,11 @@ class _Replay(torch.autograd.Function):
             t.g_bwd.replay()                 # backward + clip + AdamW in one graph (single GPU)
             return None, None
         reduce = t.reducer is not None and t.reducer.active
-        for g, tag in zip(t.segs, SEGMENT_TAGS):
+        for g, tags in zip(t.segs, t.seg_tags):
             g.replay()
             if reduce:
-                t.reducer.bucket_done(tag)   # event on this stream -> all-reduce of the bucket on the comm stream
+                for tag in tags:
+                    t.reducer.bucket_done(tag)   # event on this stream -> all-reduce of the bucket on the comm stream
         if reduce:
             t.reducer.finish()               # any range not announced yet, then this stream waits for the comm stream
         t.g_opt.replay()
@@ -699,29 +712,40 @@ class GraphedTrainer(Trainer):
         self.s_drot, self.s_dtrans = torch.zeros_like(rot), torch.zeros_like(trans)
         self.segs = None
         if self.segment_backward:
-            # Backward captured as FOUR graphs, one per autograd node (= one gradient bucket each): at replay time the
-            # bucket's RCCL all-reduce is enqueued on the comm stream right after its segment, so it overlaps the
-            # remaining segments (main.py:282's DDP overlap, with graphs).  The optimiser is a fifth graph.
+            # Backward captured as one graph per autograd node (= one gradient bucket each: heads, decoder, every encoder layer,
+            # input_proj): at replay time the bucket's RCCL all-reduce is enqueued on the comm stream right after its segment,
+            # so it overlaps the remaining segments (main.py:282's DDP overlap, with graphs).  The optimiser is a last graph.
             mem, src = m.transformer._last_memory, m._last_src
-            self.segs = []
+            outs = m.transformer.encoder._layer_outs          # [input, out_0, ..., out_{n-1}] of the encoder layers (N*S, d)
+            n_enc = len(outs) - 1
+            self.segs, self.seg_tags = [], []
 
-            def seg(fn):
+            def seg(fn, tags):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self.g_fwd.pool(), **_CAPTURE):
                     with ops.pinned_stream():
                         out = fn()
                 self.segs.append(g)
+                self.seg_tags.append(tags)
                 return out
 
             def first():
                 self.arena.zero_grad()
                 return torch.autograd.grad([rot, trans], [hs], [self.s_drot, self.s_dtrans], retain_graph=True)[0]
 
-            dhs = seg(first)
-            dmem = seg(lambda: torch.autograd.grad([hs], [mem], [dhs], retain_graph=True)[0])
-            dsrc = seg(lambda: torch.autograd.grad([mem], [src], [dmem], retain_graph=True)[0])
-            seg(lambda: torch.autograd.backward([src], [dsrc]))
-            self._seg_keep = (dhs, dmem, dsrc)
+            from .functional import enc_bucket_tag
+            dhs = seg(first, ["0_heads"])
+            dx = seg(lambda: torch.autograd.grad([hs], [outs[-1]], [dhs], retain_graph=True)[0], ["1_decoder"])
+            keep = [dhs, dx]
+            for i in reversed(range(n_enc)):
+                tags = [enc_bucket_tag(n_enc, i)] + (["2_encoder_99"] if i == 0 else [])
+                if i > 0 or outs[0].requires_grad:
+                    dx = seg(lambda i=i, dx=dx: torch.autograd.grad([outs[i + 1]], [outs[i]], [dx], retain_graph=True)[0], tags)
+                    keep.append(dx)
+                else:
+                    seg(lambda dx=dx: torch.autograd.backward([outs[1]], [dx], inputs=None), tags)
+            seg(lambda: torch.autograd.backward([outs[0]], [dx]), ["3_input_proj"])
+            self._seg_keep = keep
         else:
             self.g_bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), **_CAPTURE):

@@ -35,57 +35,68 @@ class CastFn(torch.autograd.Function):
 
 
 # ====================================================================================================
-# Encoder: all layers in one node
+# Encoder: one autograd node per layer (a gradient bucket each: the layer's parameter gradients are complete -- and their
+# all-reduce can start -- as soon as its backward program ends, main.py:280-283's DDP overlap)
 # ====================================================================================================
-class EncoderFn(torch.autograd.Function):
+def enc_bucket_tag(n_layers: int, i: int) -> str:
+    """Bucket name of encoder layer i (engine._bucket_of): backward completes layer n-1 first, so it sorts first."""
+    return f"2_encoder_{n_layers - 1 - i:02d}"
+
+
+class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, pos, level_embed, ref, mask, geom, cfg, names, *params):
-        """src (N,S,d) residual-stream dtype; pos (N,S,d); ref (N,S,L,2) fp32; mask (N*S) uint8 or None;
-        cfg dict(M,P,p,training,n_layers,act).  Returns (memory, memory16): the stream and its bf16 GEMM-operand copy
-        (the same tensor in the pure modes); memory16 is non-differentiable, gradients flow through `memory`."""
-        if pos.requires_grad:
-            raise NotImplementedError("EncoderFn: a position embedding that requires grad (learned positional encoding) is not supported: "
-                                      "its gradient would be dropped silently (only level_embed is differentiated)")
-        N, S, d = src.shape
-        x = src.reshape(N * S, d)
-        act = cfg.get("act") or src.dtype
-        if act != x.dtype:
-            x16 = torch.empty((N * S, d), dtype=act, device=src.device)
-            ops.cast(x, x16)
-        else:
-            x16 = x
-        pos2 = pos.reshape(N * S, d)
-        saved = []
-        for i in range(cfg["n_layers"]):
-            P_ = _pdict(names, params, f"layers.{i}.")
-            x, x16, sv = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
-                                         cfg["training"], cfg.get("act"), cfg.get("split", False))
-            saved.append(sv)
-        ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
-        ctx.ref, ctx.mask, ctx.level_embed, ctx.shape = ref, mask, level_embed, (N, S, d)
-        ctx.need_src = src.requires_grad
-        mem, mem16 = x.view(N, S, d), x16.view(N, S, d)
-        if mem16 is mem or mem16.data_ptr() == mem.data_ptr():
-            mem16 = mem.detach()
-        ctx.mark_non_differentiable(mem16)
-        return mem, mem16
+    def forward(ctx, x, x16, pos2, level_embed, ref, mask, geom, cfg, idx, names, *params):
+        """x (N*S,d) residual stream; x16 its GEMM-operand copy (non-differentiable; == x in the pure modes); pos2 (N*S,d);
+        ref (N,S,L,2) fp32; mask (N*S) uint8 or None; cfg dict(M,P,p,training,n_layers,act,split,N).  Returns (y, y16)."""
+        if pos2.requires_grad:
+            raise NotImplementedError("EncoderLayerFn: a position embedding that requires grad (learned positional encoding) is not "
+                                      "supported: its gradient would be dropped silently (only level_embed is differentiated)")
+        N, S = cfg["N"], geom.S
+        P_ = _pdict(names, params, "")
+        y, y16, sv = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
+                                     cfg["training"], cfg.get("act"), cfg.get("split", False))
+        ctx.saved, ctx.geom, ctx.cfg, ctx.idx, ctx.names, ctx.params = sv, geom, cfg, idx, names, params
+        ctx.ref, ctx.mask, ctx.level_embed = ref, mask, level_embed
+        ctx.need_x = x.requires_grad
+        if y16 is y or y16.data_ptr() == y.data_ptr():
+            y16 = y.detach()
+        ctx.mark_non_differentiable(y16)
+        return y, y16
 
     @staticmethod
-    def backward(ctx, dout, _unused=None):
-        N, S, d = ctx.shape
-        cfg, geom, names, params = ctx.cfg, ctx.geom, ctx.names, ctx.params
+    def backward(ctx, dy, _unused=None):
+        cfg, geom, names, params, i = ctx.cfg, ctx.geom, ctx.names, ctx.params, ctx.idx
+        N, S = cfg["N"], geom.S
         G = B.GradSink(list(names) + ["level_embed"], list(params) + [ctx.level_embed])
         g_level = G("level_embed") if ctx.level_embed.requires_grad else None
-        dx = dout.contiguous().view(N * S, d)
-        for i in reversed(range(cfg["n_layers"])):
-            pre = f"layers.{i}."
-            dx = B.enc_layer_bwd(dx, ctx.saved[i], _pdict(names, params, pre), G, pre, ctx.ref, S * geom.L * 2, ctx.mask, geom,
-                                 N, cfg["M"], cfg["P"], g_level)
-            ctx.saved[i] = None
+        dx = B.enc_layer_bwd(dy.contiguous(), ctx.saved, _pdict(names, params, ""), G, "", ctx.ref, S * geom.L * 2, ctx.mask, geom,
+                             N, cfg["M"], cfg["P"], g_level)
+        ctx.saved = None
         ops.SIDE.join()
-        announce("2_encoder")
-        dsrc = dx.view(N, S, d) if ctx.need_src else None
-        return (dsrc, None, G.ret[-1], None, None, None, None, None, *G.ret[:-1])
+        announce(enc_bucket_tag(cfg["n_layers"], i))
+        if i == 0:
+            announce("2_encoder_99")                      # level_embed (+ anything of the encoder outside its layers)
+        return (dx if ctx.need_x else None, None, None, G.ret[-1], None, None, None, None, None, None, *G.ret[:-1])
+
+
+def encoder_forward(src, pos, level_embed, ref, mask, geom, cfg, layers_named):
+    """src (N,S,d) residual-stream dtype; pos (N,S,d).  layers_named: per layer (names, params).  Returns (memory, memory16,
+    per-layer stream tensors [input, out_0, ..., out_{n-1}]) -- the handles the graphed trainer segments backward at."""
+    N, S, d = src.shape
+    x = src.reshape(N * S, d)
+    act = cfg.get("act") or src.dtype
+    if act != x.dtype:
+        x16 = torch.empty((N * S, d), dtype=act, device=src.device)
+        ops.cast(x.detach(), x16)
+    else:
+        x16 = x.detach()
+    pos2 = pos.reshape(N * S, d)
+    cfg = dict(cfg, N=N)
+    outs = [x]
+    for i, (names, params) in enumerate(layers_named):
+        x, x16 = EncoderLayerFn.apply(x, x16, pos2, level_embed, ref, mask, geom, cfg, i, names, *params)
+        outs.append(x)
+    return x.view(N, S, d), x16.view(N, S, d), outs
 
 
 # ====================================================================================================

@@ -163,8 +163,9 @@ class DeformableTransformerEncoder(nn.Module):
         l0 = self.layers[0]
         cfg = dict(M=l0.self_attn.n_heads, P=l0.self_attn.n_points, p=l0.dropout1.p, training=self.training,
                    n_layers=self.num_layers, act=act, split=split)
-        names, params = _named(self.layers, "layers.")
-        return Fn.EncoderFn.apply(src, pos, level_embed, ref, mask_u8, geom, cfg, names, *params)
+        memory, memory16, self._layer_outs = Fn.encoder_forward(src, pos, level_embed, ref, mask_u8, geom, cfg,
+                                                                [_named(l) for l in self.layers])
+        return memory, memory16
 
 
 class DeformableTransformerDecoderLayer(nn.Module):

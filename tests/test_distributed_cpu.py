@@ -48,9 +48,9 @@ def _worker(rank, world, port, q):
         assert not any("reference_points" in n for n in names)
         # buckets are contiguous, ordered by backward completion, and cover the arena exactly
         tags = [b[0] for b in arena.buckets]
-        from poet_amd.engine import SEGMENT_TAGS          # the graphed trainer announces exactly these after its backward segments
-        assert list(SEGMENT_TAGS) == tags[: len(SEGMENT_TAGS)], (SEGMENT_TAGS, tags)
-        assert tags == ["0_heads", "1_decoder", "2_encoder", "3_input_proj"], tags
+        from poet_amd.engine import segment_tags          # the graphed trainer cuts backward at exactly these buckets
+        assert segment_tags(arena) == tags
+        assert tags == ["0_heads", "1_decoder", "2_encoder_99", "3_input_proj"], tags      # (the toy encoder has no `layers.N`)
         assert arena.buckets[0][1] == 0 and arena.buckets[-1][2] == arena.total
         for (_, _, e), (_, s, _) in zip(arena.buckets[:-1], arena.buckets[1:]):
             assert e == s
@@ -69,7 +69,7 @@ def _worker(rank, world, port, q):
         arena.zero_grad()
         for n, p, _ in arena.entries:                      # "kernels" write rank-dependent gradients in place
             p._grad_view.fill_(float(rank + 1))
-        for tag in ["0_heads", "1_decoder", "2_encoder", "3_input_proj"]:   # order of the autograd nodes' announce()
+        for tag in ["0_heads", "1_decoder", "2_encoder_99", "3_input_proj"]:   # order of the autograd nodes' announce()
             announce(tag)
         red.finish()                                       # (nothing is left un-announced here; finish() also joins the comm stream)
         set_reducer(None)
@@ -182,3 +182,25 @@ def test_arena_lr_schedule_and_state_dict_roundtrip():
         assert torch.equal(p, q)
         if hasattr(p, "_bf16"):
             assert torch.equal(p._bf16, q.detach().to(torch.bfloat16)), n
+
+
+def test_encoder_layers_get_their_own_buckets_in_backward_order():
+    """One gradient bucket per encoder layer, laid out in backward-completion order (last layer first), then level_embed /
+    the rest of the encoder, then input_proj -- the reference's DDP bucket order (main.py:280-283): a layer's all-reduce can
+    start as soon as ITS backward program ends.  functional.enc_bucket_tag names the same buckets."""
+    from poet_amd.engine import ParamArena
+    from poet_amd.functional import enc_bucket_tag
+    m = _Toy()
+    m.transformer.encoder.layers = nn.ModuleList([nn.Linear(8, 8) for _ in range(3)])
+    a = ParamArena(m)
+    tags = [b[0] for b in a.buckets]
+    assert tags == ["0_heads", "1_decoder", "2_encoder_00", "2_encoder_01", "2_encoder_02", "2_encoder_99", "3_input_proj"], tags
+    assert [enc_bucket_tag(3, i) for i in (2, 1, 0)] == tags[2:5]
+    where = {n: o for n, _, o in a.entries}
+    rng = {t: (s0, e0) for t, s0, e0 in a.buckets}
+    for i in range(3):
+        s0, e0 = rng[enc_bucket_tag(3, i)]
+        assert s0 <= where[f"transformer.encoder.layers.{i}.weight"] < e0
+    s0, e0 = rng["2_encoder_99"]
+    assert s0 <= where["transformer.level_embed"] < e0
+    assert a.buckets[0][1] == 0 and a.buckets[-1][2] == a.total and all(x[2] == y[1] for x, y in zip(a.buckets[:-1], a.buckets[1:]))

@@ -547,7 +547,7 @@ def _explicit_from_fused(shapes, value_nsmd, oa, ref_pts, gout, m, p):
 
 
 @pytest.mark.parametrize("case", ["ycbv_init_like", "ycbv_wide_offsets", "hires_tiles", "one_pixel_pileup"])
-def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case):
+def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     """The kernels the benchmark runs -- fused forward, d(offsets|logits), and the LDS-tiled int32 fixed-point d(value)
     scatter -- at the benchmark's geometry (M = 16 heads, D = 16, bf16 storage, grid queries, bs 2) against the float64
     closed form, not against each other:
@@ -596,9 +596,17 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case):
     out = torch.empty(n, S, m * d, dtype=torch.bfloat16, device="cuda")
     ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
     e_out = (out.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item()
-    out_g = torch.empty_like(out)                             # the plain gather kernel (decoder path) on the same problem
-    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_g, n, m, d, p, S, grid_queries=False)
-    assert (out_g.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item() < 6e-3
+    # the opt-in variants that stage bf16 value windows in LDS (one lane per (query, head)), same problem
+    monkeypatch.setenv("POET_WIN_GATHER", "1")
+    out_w, goa_w = torch.empty_like(out), torch.empty_like(dev(oa))
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_w, n, m, d, p, S, grid_queries=True)
+    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), torch.zeros(n, m, S, d, device="cuda"), goa_w,
+                       n, m, d, p, S, grid_queries=True, parts=1)
+    monkeypatch.delenv("POET_WIN_GATHER")
+    assert (out_w.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item() < 6e-3
+    dqw = goa_w.double().cpu()
+    assert ((dqw[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs() * (~kink)).max().item() / doa_ref[..., : 2 * mlp].abs().max().item() < 8e-3
+    assert (dqw[..., 2 * mlp:] - doa_ref[..., 2 * mlp:]).abs().max().item() / doa_ref[..., 2 * mlp:].abs().max().item() < 8e-3
     gv = torch.zeros(n, m, S, d, device="cuda")
     goa = torch.empty_like(dev(oa))
     ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv, goa, n, m, d, p, S, grid_queries=True)
