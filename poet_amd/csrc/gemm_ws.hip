@@ -300,21 +300,22 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
     if (u < u_hi) iteration(u, std::true_type{});
 }
 
-// ---- K-chunked variant: K = KC x 256 (FFN2 and the K = 512 / 768 / 1024 input-gradient products) ----------------------
+// ---- K-chunked variant: K = KC x 128 (FFN2 and the K = 512 / 768 / 1024 input-gradient products) ----------------------
 // The weight no longer fits LDS whole, so the loop nest is turned inside out: a workgroup owns ONE (256-row block, 128-column
 // slice) item, its 8 waves keep the 32 x 128 accumulators of their rows in registers for the whole K loop, and the W chunk
-// [128 columns][256 k] (hi | lo images when SPLIT) is re-staged in LDS per chunk.  Weight traffic per activation row is 1/2
-// of the 128 x 128 tiled kernel's, the activation operand still goes global -> registers in MFMA layout (the next chunk's
-// rows are in flight while the current chunk is multiplied), and the epilogue is the register epilogue of the kernel above.
+// [128 columns][128 k] (hi | lo images when SPLIT) is DOUBLE-BUFFERED in LDS: the global loads of chunk c+1 (W through
+// registers, fp32 -> hi/lo conversion included; the activation rows straight into MFMA operand registers) are issued before
+// the MFMAs of chunk c and land under them, its LDS stores follow, ONE barrier per chunk.  Weight traffic per activation row is
+// 1/2 of the 128 x 128 tiled kernel's, and the epilogue is the register epilogue of the kernel above.
 template <typename TC, int KIND, bool WKM, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
-    constexpr int BN = 128, KS = 8, NTH = 512, FM = 2;
-    constexpr int K = KS * 32, PITCH = K * 2 + 16, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
-    constexpr int LO = SPLIT ? BN * PITCH : 0;
+    constexpr int BN = 128, KS = 4, NTH = 512, FM = 2;
+    constexpr int K = KS * 32, PITCH = K * 2 + 16, IMG = BN * PITCH, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
+    constexpr int BUF = (SPLIT ? 2 : 1) * IMG;                           // one W chunk (hi | lo)
     constexpr bool GATE = KIND & WS_GATE, ADD = KIND & WS_ADD, MASK = KIND & WS_MASK;
     static_assert(!SPLIT || !WKM, "b_split is a forward ([N,K] weight) feature");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sbias = reinterpret_cast<float*>(smem + (SPLIT ? 2 : 1) * BN * PITCH);
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x BUF | bias[BN] f32
+    float* sbias = reinterpret_cast<float*>(smem + 2 * BUF);
     const PoetGemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int frow = lane & 15, g = lane >> 4;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int nt = j % NT, rb = (j / NT) * 8 + xcd;
     if (rb >= RB) return;
-    const int n0 = nt * BN, KC = d.K >> 8;
+    const int n0 = nt * BN, KC = d.K >> 7;
     const int row0 = rb * 256 + wid * 32;                                // this wave's 32 rows
     const bf16_t* A = reinterpret_cast<const bf16_t*>(d.A);
     int grow[FM];
@@ -334,90 +335,100 @@ __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
         grow[fm] = row0 + fm * 16 + frow;
         ap[fm] = A + (int64_t)min(grow[fm], d.M - 1) * d.lda + g * 8;
     }
+
+    // W chunk staging, split in two halves around the MFMAs: loads (global -> registers), then stores (registers -> LDS)
+    constexpr int NWV = SPLIT ? 8 : (WKM ? 4 : 4);                        // 16-B registers per thread and chunk
+    auto w_load = [&](uint4 (&wv)[NWV], int c) __attribute__((always_inline)) {
+        if constexpr (SPLIT) {
+            const float* Bf = reinterpret_cast<const float*>(d.B) + c * K;
+            constexpr int CPR = K / 4;                                   // float4 chunks per row
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                wv[i] = *reinterpret_cast<const uint4*>(Bf + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 4);
+            }
+        } else if constexpr (!WKM) {
+            const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B) + c * K;
+            constexpr int CPR = K / 8;
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                wv[i] = *reinterpret_cast<const uint4*>(B + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 8);
+            }
+        } else {                                                         // W[k][n]: item = 4 consecutive k x 8 consecutive n
+            const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B) + (int64_t)c * K * d.ldb;
+            constexpr int NG = BN / 8;
+            const int kq = tid / NG, nl = (tid - kq * NG) * 8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[r] = *reinterpret_cast<const uint4*>(B + (int64_t)(kq * 4 + r) * d.ldb + n0 + nl);
+        }
+    };
+    auto w_store = [&](const uint4 (&wv)[NWV], char* buf) __attribute__((always_inline)) {
+        if constexpr (SPLIT) {
+            constexpr int CPR = K / 4;
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                const float f0 = __uint_as_float(wv[i].x), f1 = __uint_as_float(wv[i].y), f2 = __uint_as_float(wv[i].z), f3 = __uint_as_float(wv[i].w);
+                const uint2 hi = make_uint2(pack_bf2(f0, f1), pack_bf2(f2, f3));
+                const uint2 lo = make_uint2(pack_bf2(f0 - __uint_as_float(hi.x << 16), f1 - __uint_as_float(hi.x & 0xffff0000u)),
+                                            pack_bf2(f2 - __uint_as_float(hi.y << 16), f3 - __uint_as_float(hi.y & 0xffff0000u)));
+                *reinterpret_cast<uint2*>(buf + rho * PITCH + kc * 8) = hi;
+                *reinterpret_cast<uint2*>(buf + IMG + rho * PITCH + kc * 8) = lo;
+            }
+        } else if constexpr (!WKM) {
+            constexpr int CPR = K / 8;
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                // (element by element: copied as a whole 16-byte object, the staging array is kept in scratch memory)
+                *reinterpret_cast<uint4*>(buf + rho * PITCH + kc * 16) = make_uint4(wv[i].x, wv[i].y, wv[i].z, wv[i].w);
+            }
+        } else {
+            constexpr int NG = BN / 8;
+            const int kq = tid / NG, nl = (tid - kq * NG) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                uint32_t h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t w = (e >> 1) == 0 ? wv[r].x : (e >> 1) == 1 ? wv[r].y : (e >> 1) == 2 ? wv[r].z : wv[r].w;
+                    h[r] = (e & 1) ? (w >> 16) : (w & 0xffffu);
+                }
+                *reinterpret_cast<uint2*>(buf + ws_inv_perm(nl + e) * PITCH + kq * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    };
+
     uint4 a[FM][KS], an[FM][KS];
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) a[fm][kk] = *reinterpret_cast<const uint4*>(ap[fm] + kk * 32);
+    uint4 wv[NWV];
+    w_load(wv, 0);
     if (tid < BN) sbias[tid] = d.bias ? d.bias[n0 + tid] : 0.f;
-
     f32x4_t acc[FM][FNT];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int jn = 0; jn < FNT; ++jn) acc[i][jn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    w_store(wv, smem);
+    __syncthreads();
     int woff = frow * PITCH + g * 16;
 
 #pragma unroll 1
     for (int c = 0; c < KC; ++c) {
-        if (c) __syncthreads();                                          // every wave is done reading the previous chunk of W
-        // ---- W chunk c -> LDS ----
-        if constexpr (SPLIT) {
-            const float* Bf = reinterpret_cast<const float*>(d.B) + c * K;
-            constexpr int CPR = K / 4, NCH = BN * CPR, GRP = 8;
-#pragma unroll 1
-            for (int base = 0; base < NCH; base += NTH * GRP) {
-                float4 wv[GRP];
-#pragma unroll
-                for (int i = 0; i < GRP; ++i) {
-                    const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
-                    wv[i] = *reinterpret_cast<const float4*>(Bf + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 4);
-                }
-#pragma unroll
-                for (int i = 0; i < GRP; ++i) {
-                    const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
-                    const uint2 hi = make_uint2(pack_bf2(wv[i].x, wv[i].y), pack_bf2(wv[i].z, wv[i].w));
-                    const uint2 lo = make_uint2(pack_bf2(wv[i].x - __uint_as_float(hi.x << 16), wv[i].y - __uint_as_float(hi.x & 0xffff0000u)),
-                                                pack_bf2(wv[i].z - __uint_as_float(hi.y << 16), wv[i].w - __uint_as_float(hi.y & 0xffff0000u)));
-                    *reinterpret_cast<uint2*>(smem + rho * PITCH + kc * 8) = hi;
-                    *reinterpret_cast<uint2*>(smem + LO + rho * PITCH + kc * 8) = lo;
-                }
-            }
-        } else if constexpr (!WKM) {
-            const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B) + c * K;
-            constexpr int CPR = K / 8, NIT = BN * CPR / NTH;
-            uint4 wv[NIT];
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
-                wv[i] = *reinterpret_cast<const uint4*>(B + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int idx = tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
-                *reinterpret_cast<uint4*>(smem + rho * PITCH + kc * 16) = wv[i];
-            }
-        } else {
-            const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B) + (int64_t)c * K * d.ldb;
-            constexpr int NG = BN / 8, NIT = (K / 4) * NG / NTH;
-#pragma unroll 1
-            for (int i = 0; i < NIT; ++i) {                              // one item at a time: the registers belong to a / acc
-                const int idx = tid + i * NTH, kq = idx / NG, nl = (idx - kq * NG) * 8;
-                uint4 wv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) wv[r] = *reinterpret_cast<const uint4*>(B + (int64_t)(kq * 4 + r) * d.ldb + n0 + nl);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    uint32_t h[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t w = (e >> 1) == 0 ? wv[r].x : (e >> 1) == 1 ? wv[r].y : (e >> 1) == 2 ? wv[r].z : wv[r].w;
-                        h[r] = (e & 1) ? (w >> 16) : (w & 0xffffu);
-                    }
-                    *reinterpret_cast<uint2*>(smem + ws_inv_perm(nl + e) * PITCH + kq * 8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                }
-            }
-        }
-        __syncthreads();
-        // ---- next chunk's activation rows go in flight, then this chunk is multiplied ----
-        if (c + 1 < KC) {
+        const bool more = c + 1 < KC;
+        if (more) {                                                      // chunk c+1: everything global goes in flight now
+            w_load(wv, c + 1);
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) an[fm][kk] = *reinterpret_cast<const uint4*>(ap[fm] + (c + 1) * K + kk * 32);
         }
         asm volatile("" : "+v"(woff));
-        const char* wl = smem + woff;
+        const char* wl = smem + (c & 1) * BUF + woff;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
@@ -427,18 +438,20 @@ __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
                 for (int fm = 0; fm < FM; ++fm)
                     acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acc[fm][jn], 0, 0, 0);
                 if constexpr (SPLIT) {
-                    const bf16x8_t wlo = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl + LO + jn * 16 * PITCH + kk * 64));
+                    const bf16x8_t wlo = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl + IMG + jn * 16 * PITCH + kk * 64));
 #pragma unroll
                     for (int fm = 0; fm < FM; ++fm)
                         acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acc[fm][jn], 0, 0, 0);
                 }
             }
         }
-        if (c + 1 < KC) {
+        if (more) {
+            w_store(wv, smem + ((c + 1) & 1) * BUF);                         // (its last readers passed the barrier that ended chunk c-1)
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) a[fm][kk] = an[fm][kk];
+            __syncthreads();
         }
     }
 
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
 
 template <typename TC, int KIND, bool WKM, bool SPLIT>
 bool wsk_launch(const GemmK& p, hipStream_t st) {
-    constexpr int LDS = (SPLIT ? 2 : 1) * 128 * (8 * 64 + 16) + 128 * 4;
+    constexpr int LDS = 2 * (SPLIT ? 2 : 1) * 128 * (4 * 64 + 16) + 128 * 4;
     auto kern = gemm_wsk_kernel<TC, KIND, WKM, SPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -669,7 +682,7 @@ bool gemm_ws_try(const GemmK& p, hipStream_t st) {
         // (single-weight forms are still faster on the tiled kernel: the W chunk restaging of a one-workgroup-per-CU kernel is
         // exposed; POET_GEMM_WSK_ALL=1 routes them here anyway)
         static const int all = [] { const char* e = getenv("POET_GEMM_WSK_ALL"); return e && atoi(e) ? 1 : 0; }();
-        if (no_wsk || d.K % 256 != 0 || d.K > 4096 || (!d.b_split && !all)) return false;
+        if (no_wsk || d.K % 128 != 0 || d.K > 4096 || (!d.b_split && !all)) return false;
         return d.c_dtype == POET_BF16 ? wsk_kind<bf16_t>(p, st) : wsk_kind<float>(p, st);
     }
     const int NT = d.N / 128;

