@@ -186,6 +186,8 @@ int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float*
                 int dtype_z /* dtype of z_out; -1 = dtype_x.  (f32 x, f32 stream, bf16 z): the branch arrives as the GEMM's
                                fp32 accumulators, only the copy saved for backward is bf16 */,
                 void* y_bf16 /* optional: bf16 copy of y, the MFMA operand of the next GEMM */,
+                const void* pos_bf16, void* q_bf16 /* optional pair: q_bf16 = bf16(y + pos_bf16), the query operand of the NEXT
+                                                      encoder layer (deformable_transformer.py:201 `src + pos`), same shape as y */,
                 const uint32_t* seed_dev /* optional, see PoetGemmDesc.seed_dev */, void* stream);
 int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                 void* dz_out, void* dx_out, float* dgamma, float* dbeta,

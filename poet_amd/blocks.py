@@ -148,7 +148,7 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
 
 
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
-def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False):
+def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=None):
     """Returns (y, y16, saved): y in the residual-stream dtype; y16 = bf16 copy for the next GEMM when the stream is
     fp32 but the branch is bf16 (else y itself).  With split weights the projection hands its fp32 accumulators to the
     LayerNorm unrounded (the branch is never stored in bf16); only the pre-norm sum saved for backward is bf16."""
@@ -162,7 +162,13 @@ def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False):
     mean = empty((rows,), torch.float32, res)
     rstd = empty((rows,), torch.float32, res)
     y16 = empty((rows, d), torch.bfloat16, res) if mixed else None
-    ops.ln_fwd(tmp, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, p, seed, y16=y16)
+    q_next = None
+    if pos_next is not None and mixed and pos_next.dtype == torch.bfloat16:       # the next layer's `src + pos`, written by this LayerNorm
+        q_next = empty((rows, d), torch.bfloat16, res)
+    ops.ln_fwd(tmp, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, p, seed, y16=y16,
+               pos16=pos_next if q_next is not None else None, q16=q_next)
+    if pos_next is not None:
+        return y, (y16 if y16 is not None else y), (z, mean, rstd), q_next
     return y, (y16 if y16 is not None else y), (z, mean, rstd)
 
 
@@ -182,12 +188,15 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
 
 
 # ---- (d) FFN block -------------------------------------------------------------------------------
-def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False):
+def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False, pos_next=None):
     """x: residual stream; x16: the GEMM operand copy of it (== x in the pure modes)."""
     rows = x.shape[0]
     Hd = empty((rows, W1.shape[0]), act or x.dtype, x)
     Wt, sp = Wf(W1, x16, split)
     ops.linear_fwd(x16, Wt, b1, Hd, act=1, drop_p=p_h, seed=seed_h, split=sp)
+    if pos_next is not None:
+        y, y16, ln_saved, q_next = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, pos_next=pos_next)
+        return y, y16, (Hd, ln_saved), q_next
     y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split)
     return y, y16, (Hd, ln_saved)
 
@@ -211,15 +220,19 @@ ENC_PARAMS = ("self_attn.sampling_offsets.weight", "self_attn.sampling_offsets.b
               "linear2.weight", "linear2.bias", "norm2.weight", "norm2.bias")
 
 
-def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None, split=False):
+def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None, split=False, q_in=None, emit_q=False):
     """src (N*S,d): residual stream; src16: its GEMM-operand copy (== src in the pure modes); pos (N*S,d).
-    Returns (out, out16, saved)."""
+    q_in: `src + pos` when the previous layer's LayerNorm already produced it; emit_q: have this layer's last LayerNorm
+    produce it for the next layer.  Returns (out, out16, saved[, q_next])."""
     S, d = geom.S, src.shape[1]
     D = d // M
     pd = p if training else 0.0
     seeds = [next_seed() for _ in range(3)]
-    q = empty(src.shape, src16.dtype, src)
-    ops.add(src, pos, q)
+    if q_in is not None:
+        q = q_in
+    else:
+        q = empty(src.shape, src16.dtype, src)
+        ops.add(src, pos, q)
     V = value_proj_fwd(src16, P_["self_attn.value_proj.weight"], P_["self_attn.value_proj.bias"], mask, N, S, M, D,
                        act, split)
     out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
@@ -227,9 +240,16 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
                            V, geom, ref, ref_bs, N, S, M, D, npts, act, split, grid_queries=True)
     x1, x1_16, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
                                  P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0], split)
-    x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                             P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split)
+    q_next = None
+    if emit_q:
+        x2, x2_16, ffn, q_next = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
+                                         P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, pos_next=pos)
+    else:
+        x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
+                                 P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split)
     saved = dict(src=src16, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1_16, ffn=ffn, seeds=seeds, pd=pd)
+    if emit_q:
+        return x2, x2_16, saved, q_next
     return x2, x2_16, saved
 
 

@@ -307,9 +307,9 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
 // registers, fp32 -> hi/lo conversion included; the activation rows straight into MFMA operand registers) are issued before
 // the MFMAs of chunk c and land under them, its LDS stores follow, ONE barrier per chunk.  Weight traffic per activation row is
 // 1/2 of the 128 x 128 tiled kernel's, and the epilogue is the register epilogue of the kernel above.
-template <typename TC, int KIND, bool WKM, bool SPLIT>
-__global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
-    constexpr int BN = 128, KS = 4, NTH = 512, FM = 2;
+template <typename TC, int KIND, bool WKM, bool SPLIT, int BN = 128, int NTH = 512>
+__global__ __launch_bounds__(NTH, 2) void gemm_wsk_kernel(const GemmK p) {
+    constexpr int KS = 4, FM = 2, RBLK = NTH / 2;                        // rows per workgroup: 32 per wave
     constexpr int K = KS * 32, PITCH = K * 2 + 16, IMG = BN * PITCH, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
     constexpr int BUF = (SPLIT ? 2 : 1) * IMG;                           // one W chunk (hi | lo)
     constexpr bool GATE = KIND & WS_GATE, ADD = KIND & WS_ADD, MASK = KIND & WS_MASK;
@@ -321,12 +321,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
     const int frow = lane & 15, g = lane >> 4;
 
     // item = (row block, column slice); the slices of one row block run on one XCD (A is re-read through that L2)
-    const int NT = d.N / BN, RB = (d.M + 255) >> 8;
+    const int NT = d.N / BN, RB = (d.M + RBLK - 1) / RBLK;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int nt = j % NT, rb = (j / NT) * 8 + xcd;
     if (rb >= RB) return;
     const int n0 = nt * BN, KC = d.K >> 7;
-    const int row0 = rb * 256 + wid * 32;                                // this wave's 32 rows
+    const int row0 = rb * RBLK + wid * 32;                               // this wave's 32 rows
     const bf16_t* A = reinterpret_cast<const bf16_t*>(d.A);
     int grow[FM];
     const bf16_t* ap[FM];
@@ -337,7 +337,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
     }
 
     // W chunk staging, split in two halves around the MFMAs: loads (global -> registers), then stores (registers -> LDS)
-    constexpr int NWV = SPLIT ? 8 : (WKM ? 4 : 4);                        // 16-B registers per thread and chunk
+    static_assert(BN == 128 || (BN == 64 && !WKM), "slice widths");
+    static_assert(NTH == 512 || !WKM, "the transposing staging assumes 512 threads");
+    constexpr int NWV = SPLIT ? BN * 32 / NTH : (WKM ? 4 : BN * 16 / NTH);      // 16-B registers per thread and chunk
     auto w_load = [&](uint4 (&wv)[NWV], int c) __attribute__((always_inline)) {
         if constexpr (SPLIT) {
             const float* Bf = reinterpret_cast<const float*>(d.B) + c * K;
@@ -529,18 +531,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wsk_kernel(const GemmK p) {
     }
 }
 
-template <typename TC, int KIND, bool WKM, bool SPLIT>
+template <typename TC, int KIND, bool WKM, bool SPLIT, int BN = 128, int NTH = 512>
 bool wsk_launch(const GemmK& p, hipStream_t st) {
-    constexpr int LDS = 2 * (SPLIT ? 2 : 1) * 128 * (4 * 64 + 16) + 128 * 4;
-    auto kern = gemm_wsk_kernel<TC, KIND, WKM, SPLIT>;
+    constexpr int LDS = 2 * (SPLIT ? 2 : 1) * BN * (4 * 64 + 16) + BN * 4;
+    auto kern = gemm_wsk_kernel<TC, KIND, WKM, SPLIT, BN, NTH>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    const int NT = p.d.N / 128, RB = (p.d.M + 255) >> 8;
+    const int NT = p.d.N / BN, RB = (p.d.M + NTH / 2 - 1) / (NTH / 2);
     const int nblocks = ((RB + 7) / 8) * NT * 8;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTH), LDS, st, p);
     return true;
 }
 
@@ -549,8 +551,11 @@ bool wsk_kind(const GemmK& p, hipStream_t st) {
     const PoetGemmDesc& d = p.d;
     const int kind = (d.gate_ref ? WS_GATE : 0) | (d.add_src ? WS_ADD : 0) | (d.row_mask ? WS_MASK : 0);
     if (d.b_split) {
-        if (kind == 0) return wsk_launch<TC, 0, false, true>(p, st);
-        return false;
+        // 64-column slices: the two weight images of a 128-wide chunk would leave ONE workgroup per CU (139 KB), whose
+        // activation loads (one chunk = 1.8 us of MFMAs ahead) then sit exposed; at 70 KB two 4-wave workgroups cover each other
+        static const int bn = [] { const char* e = getenv("POET_WSK_SPLIT_BN"); return e ? atoi(e) : 64; }();
+        if (kind != 0) return false;
+        return bn == 128 ? wsk_launch<TC, 0, false, true, 128, 512>(p, st) : wsk_launch<TC, 0, false, true, 64, 256>(p, st);
     }
     if (!d.b_kmajor) {
         if (kind == 0) return wsk_launch<TC, 0, false, false>(p, st);

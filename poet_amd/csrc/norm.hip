@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
                                                      TR* __restrict__ y, TZ* __restrict__ z, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t rows, int d, float eps,
                                                      uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16,
-                                                     const uint32_t* __restrict__ seed_dev) {
+                                                     const uint32_t* __restrict__ seed_dev,
+                                                     const bf16_t* __restrict__ pos = nullptr, bf16_t* __restrict__ q16 = nullptr) {
     if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wid;
@@ -70,6 +71,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
             vec<TR, 4>::st(y + row * d + c, o);
             if (y16) vec<bf16_t, 4>::st(y16 + row * d + c, o);
             if (z) vec<TZ, 4>::st(z + row * d + c, v[it]);
+            if (q16) {                                    // the NEXT layer's query operand y + pos (deformable_transformer.py:201)
+                float pp[4];
+                vec<bf16_t, 4>::ld(pos + row * d + c, pp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pp[e] += o[e];
+                vec<bf16_t, 4>::st(q16 + row * d + c, pp);
+            }
         }
     }
 }
@@ -281,8 +289,10 @@ using namespace poet;
 
 extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
                            float* mean, float* rstd, int64_t rows, int d, float eps, float drop_p, uint32_t seed,
-                           int dtype_x, int dtype_r, int dtype_z, void* y_bf16, const uint32_t* seed_dev, void* stream) {
+                           int dtype_x, int dtype_r, int dtype_z, void* y_bf16, const void* pos_bf16, void* q_bf16,
+                           const uint32_t* seed_dev, void* stream) {
     POET_CHECK(x && gamma && beta && y, POET_ERR_ARG, "ln_fwd: null pointer");
+    POET_CHECK((pos_bf16 == nullptr) == (q_bf16 == nullptr), POET_ERR_ARG, "ln_fwd: pos_bf16 and q_bf16 come together");
     if (dtype_z < 0) dtype_z = dtype_x;
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_fwd: d=%d unsupported", d);
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "ln_fwd: drop_p");
@@ -290,12 +300,12 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
     const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev)
+#define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16)
     if (dtype_z == dtype_x) {
         POET_DT2(dtype_x, dtype_r, LN_FWD);
     } else {        // fp32 branch input (the GEMM's accumulators, never rounded to bf16) with the pre-norm sum saved in bf16 for backward
         POET_CHECK(dtype_x == POET_F32 && dtype_r == POET_F32 && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED, "ln_fwd: dtype triple (%d,%d,%d)", dtype_x, dtype_r, dtype_z);
-        ln_fwd_kernel<float, float, bf16_t><<<grid, block, 0, st>>>((const float*)x, (const float*)res, gamma, beta, (float*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev);
+        ln_fwd_kernel<float, float, bf16_t><<<grid, block, 0, st>>>((const float*)x, (const float*)res, gamma, beta, (float*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16);
     }
 #undef LN_FWD
     POET_LAUNCH_CHECK();

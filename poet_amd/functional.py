@@ -45,26 +45,31 @@ def enc_bucket_tag(n_layers: int, i: int) -> str:
 
 class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x16, pos2, level_embed, ref, mask, geom, cfg, idx, names, *params):
-        """x (N*S,d) residual stream; x16 its GEMM-operand copy (non-differentiable; == x in the pure modes); pos2 (N*S,d);
-        ref (N,S,L,2) fp32; mask (N*S) uint8 or None; cfg dict(M,P,p,training,n_layers,act,split,N).  Returns (y, y16)."""
+    def forward(ctx, x, x16, q_in, pos2, level_embed, ref, mask, geom, cfg, idx, names, *params):
+        """x (N*S,d) residual stream; x16 its GEMM-operand copy (non-differentiable; == x in the pure modes); q_in: x + pos when
+        the previous layer's last LayerNorm already produced it (else None); pos2 (N*S,d); ref (N,S,L,2) fp32; mask (N*S) uint8
+        or None; cfg dict(M,P,p,training,n_layers,act,split,N).  Returns (y, y16, q_next): q_next = y + pos for the next layer
+        (an empty tensor when not produced)."""
         if pos2.requires_grad:
             raise NotImplementedError("EncoderLayerFn: a position embedding that requires grad (learned positional encoding) is not "
                                       "supported: its gradient would be dropped silently (only level_embed is differentiated)")
         N, S = cfg["N"], geom.S
         P_ = _pdict(names, params, "")
-        y, y16, sv = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
-                                     cfg["training"], cfg.get("act"), cfg.get("split", False))
+        emit = idx + 1 < cfg["n_layers"]
+        out = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
+                              cfg["training"], cfg.get("act"), cfg.get("split", False), q_in=q_in, emit_q=emit)
+        y, y16, sv = out[:3]
+        q_next = out[3] if emit and out[3] is not None else x.new_empty(0)
         ctx.saved, ctx.geom, ctx.cfg, ctx.idx, ctx.names, ctx.params = sv, geom, cfg, idx, names, params
         ctx.ref, ctx.mask, ctx.level_embed = ref, mask, level_embed
         ctx.need_x = x.requires_grad
         if y16 is y or y16.data_ptr() == y.data_ptr():
             y16 = y.detach()
-        ctx.mark_non_differentiable(y16)
-        return y, y16
+        ctx.mark_non_differentiable(y16, q_next)
+        return y, y16, q_next
 
     @staticmethod
-    def backward(ctx, dy, _unused=None):
+    def backward(ctx, dy, _unused=None, _unused2=None):
         cfg, geom, names, params, i = ctx.cfg, ctx.geom, ctx.names, ctx.params, ctx.idx
         N, S = cfg["N"], geom.S
         G = B.GradSink(list(names) + ["level_embed"], list(params) + [ctx.level_embed])
@@ -76,7 +81,7 @@ class EncoderLayerFn(torch.autograd.Function):
         announce(enc_bucket_tag(cfg["n_layers"], i))
         if i == 0:
             announce("2_encoder_99")                      # level_embed (+ anything of the encoder outside its layers)
-        return (dx if ctx.need_x else None, None, None, G.ret[-1], None, None, None, None, None, None, *G.ret[:-1])
+        return (dx if ctx.need_x else None, None, None, None, G.ret[-1], None, None, None, None, None, None, *G.ret[:-1])
 
 
 def encoder_forward(src, pos, level_embed, ref, mask, geom, cfg, layers_named):
@@ -93,8 +98,11 @@ def encoder_forward(src, pos, level_embed, ref, mask, geom, cfg, layers_named):
     pos2 = pos.reshape(N * S, d)
     cfg = dict(cfg, N=N)
     outs = [x]
+    q = None
     for i, (names, params) in enumerate(layers_named):
-        x, x16 = EncoderLayerFn.apply(x, x16, pos2, level_embed, ref, mask, geom, cfg, i, names, *params)
+        x, x16, q = EncoderLayerFn.apply(x, x16, q, pos2, level_embed, ref, mask, geom, cfg, i, names, *params)
+        if q.numel() == 0:
+            q = None
         outs.append(x)
     return x.view(N, S, d), x16.view(N, S, d), outs
 

@@ -379,11 +379,11 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 
 
 # ---- norms -----------------------------------------------------------------------------------------
-def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None):
+def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None, pos16=None, q16=None):
     lib = _lib.load()
     _lib.check(lib.poet_ln_fwd(_req(x, "x").data_ptr(), _ptr(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(z),
                                _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y),
-                               -1 if z is None else dcode(z), _ptr(y16),
+                               -1 if z is None else dcode(z), _ptr(y16), _ptr(pos16), _ptr(q16),
                                _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_fwd")
     return y
 
