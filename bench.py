@@ -128,7 +128,9 @@ def build_model(cfg, feats, precision, device):
     tr.set_precision(precision)
     model = poet_amd.PoET(bb, tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
                           n_classes=cfg["n_classes"], bbox_mode="gt", class_mode="specific", aux_loss=True).to(device)
-    crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(), poet_amd.build_weight_dict(cfg["dec_layers"]))
+    # assignment + target gather on the GPU (poet_lsa_boxes; POET_HOST_MATCHER=1: the SciPy path on the host copy of the boxes)
+    host = os.environ.get("POET_HOST_MATCHER", "0") not in ("", "0")
+    crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(device_assign=not host), poet_amd.build_weight_dict(cfg["dec_layers"]))
     return model, crit
 
 

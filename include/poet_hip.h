@@ -38,6 +38,8 @@
  *   poet_pose_loss             translation / rotation losses of all decoder layers + their gradients
  *                              (pose_estimation_transformer.py:635-674).
  *   poet_adamw / poet_sqnorm   optimizer.step + clip_grad_norm_ over the flat arenas (engine.py:75-81).
+ *   poet_lsa_boxes / poet_match_gather   PoseMatcher's assignment (models/matcher.py:158-229) + the target gather of
+ *                              SetCriterion (pose_estimation_transformer.py:649-668), on the device.
  */
 #ifndef POET_HIP_H
 #define POET_HIP_H
@@ -292,6 +294,16 @@ int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* 
 int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_idx, const float* tgt_trans,
                    const float* tgt_rot, int n_obj, int L, int NQ, float* losses, float* grad_trans, float* grad_rot,
                    void* stream);
+
+/* Batched on-device assignment, models/matcher.py:158-229 in 'gt' mode: per image the L1 cost between the first n_pred[i]
+ * query boxes (pred_boxes (N,Q,4) fp32) and the image's targets (tgt_boxes rows [tgt_off[i], tgt_off[i+1]), fp32 (T,4)),
+ * solved by the algorithm scipy.optimize.linear_sum_assignment uses (same tie-breaking; <= 64 per side).
+ * col_out (N,Q) int32: target index matched to query row, -1 = none.  *status != 0 on an oversized / infeasible problem.
+ * poet_match_gather turns it into the arrays poet_pose_loss takes (pairs in (image, query) order; N <= 256). */
+int poet_lsa_boxes(const float* pred_boxes, const float* tgt_boxes, const int* tgt_off, const int* n_pred, float cost_bbox,
+                   int N, int Q, int* col_out, int* status, void* stream);
+int poet_match_gather(const int* col, const int* tgt_off, const float* tgt_pos, const float* tgt_rot, int N, int Q,
+                      int64_t* query_idx, float* tgt_trans_out, float* tgt_rot_out, int* n_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Flat-arena optimizer pieces.  poet_sqnorm: out[0] += sum(g^2) (fp32, caller zero-fills out[0]); `out` must have room

@@ -461,6 +461,144 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (pb) pb[i] = f2bf(pi);
 }
 
+
+// ---- batched assignment on the device: models/matcher.py:158-229 ('gt' mode: L1 box cost + linear_sum_assignment) ----
+// One wave per image, at most 64 queries / targets.  The solver is SciPy's rectangular LSAP (Crouse's shortest augmenting
+// path, scipy/optimize/rectangular_lsap) restated step for step in double precision, so the assignment -- ties included --
+// is the one scipy.optimize.linear_sum_assignment returns for the same fp32 cost matrix: lane `it` owns entry `it` of the
+// "remaining columns" list, and the sequential scan
+//     for it: if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+// becomes a wave minimum plus its tie rule (equal minima: the LAST one whose column is still unassigned, else the FIRST).
+// cost[r][c] = cost_bbox * (((|d0| + |d1|) + |d2|) + |d3|) in fp32, numpy's summation order.
+constexpr int LSA_MAX = 64;
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void lsa_boxes_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                       const int* __restrict__ tgt_off, const int* __restrict__ n_pred, float cost_bbox,
+                                                       int Q, int* __restrict__ col_out, int* __restrict__ status) {
+    __shared__ double cost[LSA_MAX * LSA_MAX];
+    __shared__ double u[LSA_MAX], v[LSA_MAX], spc[LSA_MAX];
+    __shared__ int path[LSA_MAX], col4row[LSA_MAX], row4col[LSA_MAX], remaining[LSA_MAX];
+    __shared__ unsigned char SR[LSA_MAX], SC[LSA_MAX];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int nr0 = n_pred[img], t0 = tgt_off[img], nc0 = tgt_off[img + 1] - t0;
+    int* out = col_out + (int64_t)img * Q;
+    for (int k = lane; k < Q; k += 64) out[k] = -1;
+    if (nr0 <= 0 || nc0 <= 0) return;
+    if (nr0 > LSA_MAX || nc0 > LSA_MAX) { if (lane == 0) atomicExch(status, 1); return; }
+    // scipy transposes a tall matrix (more rows than columns) and solves that; rows = preds, columns = targets otherwise
+    const bool tr = nc0 < nr0;
+    const int nr = tr ? nc0 : nr0, nc = tr ? nr0 : nc0;
+    for (int e = lane; e < nr0 * nc0; e += 64) {
+        const int r = e / nc0, c = e - r * nc0;
+        const float* a = pred + ((int64_t)img * Q + r) * 4;
+        const float* b = tgt + (int64_t)(t0 + c) * 4;
+        float sum = fabsf(a[0] - b[0]);
+        sum = __fadd_rn(sum, fabsf(a[1] - b[1]));
+        sum = __fadd_rn(sum, fabsf(a[2] - b[2]));
+        sum = __fadd_rn(sum, fabsf(a[3] - b[3]));
+        const double cv = (double)__fmul_rn(cost_bbox, sum);
+        if (tr) cost[c * nc + r] = cv; else cost[r * nc + c] = cv;
+    }
+    if (lane < nr) { u[lane] = 0.0; col4row[lane] = -1; }
+    if (lane < nc) { v[lane] = 0.0; path[lane] = -1; row4col[lane] = -1; }
+    __syncthreads();
+
+    for (int cur = 0; cur < nr; ++cur) {
+        // ---- augmenting_path(cur) ----
+        double minVal = 0.0;
+        int num_remaining = nc, i = cur, sink = -1;
+        if (lane < nc) { remaining[lane] = nc - lane - 1; SC[lane] = 0; spc[lane] = INFINITY; }
+        if (lane < nr) SR[lane] = 0;
+        __syncthreads();
+        bool infeasible = false;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            const bool act = lane < num_remaining;
+            const int j = act ? remaining[lane] : 0;
+            double val = INFINITY;
+            bool unassigned = false;
+            if (act) {
+                const double r = minVal + cost[i * nc + j] - u[i] - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                val = spc[j];
+                unassigned = row4col[j] == -1;
+            }
+            const double lowest = wave_min_f64(val);
+            if (!(lowest < INFINITY)) { infeasible = true; break; }
+            const unsigned long long cand = __ballot(act && val == lowest), free_c = __ballot(act && val == lowest && unassigned);
+            const int index = free_c ? 63 - __clzll((long long)free_c) : __ffsll((long long)cand) - 1;
+            minVal = lowest;
+            __syncthreads();
+            const int js = remaining[index];
+            const int owner = row4col[js];
+            if (owner == -1) sink = js; else i = owner;
+            __syncthreads();
+            if (lane == 0) { SC[js] = 1; remaining[index] = remaining[num_remaining - 1]; }
+            --num_remaining;
+            __syncthreads();
+        }
+        if (infeasible) { if (lane == 0) atomicExch(status, 2); return; }
+        // ---- dual update ----
+        if (lane == 0) u[cur] += minVal;
+        if (lane < nr && SR[lane] && lane != cur) u[lane] += minVal - spc[col4row[lane]];
+        if (lane < nc && SC[lane]) v[lane] -= minVal - spc[lane];
+        __syncthreads();
+        // ---- augment ----
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                const int ii = path[j];
+                row4col[j] = ii;
+                const int t = col4row[ii]; col4row[ii] = j; j = t;
+                if (ii == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    // result as (row -> column) over the ORIGINAL orientation: preds are rows
+    if (!tr) { if (lane < nr) out[lane] = col4row[lane]; }
+    else { if (lane < nr) out[col4row[lane]] = lane; }          // solved transposed: row `lane` is target `lane`, its column a pred
+}
+
+// matched pairs -> the flat arrays poet_pose_loss takes: for image b, pred row s with col[b][s] >= 0, in (b, s) order
+__global__ void match_gather_kernel(const int* __restrict__ col, const int* __restrict__ tgt_off, const float* __restrict__ tpos,
+                                    const float* __restrict__ trot, int N, int Q, int64_t* __restrict__ qi, float* __restrict__ tt,
+                                    float* __restrict__ trm, int* __restrict__ n_out) {
+    // one workgroup; a running count per image keeps the (b, s) order deterministic
+    __shared__ int base[257];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int acc = 0;
+        for (int b = 0; b < N; ++b) {
+            base[b] = acc;
+            for (int s = 0; s < Q; ++s) acc += col[b * Q + s] >= 0;
+        }
+        base[N] = acc;
+        if (n_out) *n_out = acc;
+    }
+    __syncthreads();
+    for (int b = tid; b < N; b += blockDim.x) {
+        int k = base[b];
+        for (int s = 0; s < Q; ++s) {
+            const int c = col[b * Q + s];
+            if (c < 0) continue;
+            const int g = tgt_off[b] + c;
+            qi[k] = (int64_t)b * Q + s;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) tt[k * 3 + e] = tpos[g * 3 + e];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) trm[k * 9 + e] = trot[g * 9 + e];
+            ++k;
+        }
+    }
+}
+
 }  // namespace poet
 
 using namespace poet;
@@ -633,6 +771,24 @@ extern "C" int poet_pose_loss(const float* trans, const float* rot, const int64_
     POET_CHECK(n_obj == 0 || (query_idx && tgt_trans && tgt_rot), POET_ERR_ARG, "pose_loss: null match arrays");
     hipLaunchKernelGGL(pose_loss_kernel, dim3(L), dim3(256), 0, ST, trans, rot, query_idx, tgt_trans, tgt_rot, n_obj, NQ, losses,
                        grad_trans, grad_rot);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_lsa_boxes(const float* pred_boxes, const float* tgt_boxes, const int* tgt_off, const int* n_pred, float cost_bbox,
+                              int N, int Q, int* col_out, int* status, void* stream) {
+    POET_CHECK(pred_boxes && tgt_boxes && tgt_off && n_pred && col_out && status && N > 0 && Q > 0, POET_ERR_ARG, "lsa_boxes: bad args");
+    hipLaunchKernelGGL(lsa_boxes_kernel, dim3(N), dim3(64), 0, ST, pred_boxes, tgt_boxes, tgt_off, n_pred, cost_bbox, Q, col_out, status);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_match_gather(const int* col, const int* tgt_off, const float* tgt_pos, const float* tgt_rot, int N, int Q,
+                                 int64_t* query_idx, float* tgt_trans_out, float* tgt_rot_out, int* n_out, void* stream) {
+    POET_CHECK(col && tgt_off && tgt_pos && tgt_rot && query_idx && tgt_trans_out && tgt_rot_out && N > 0 && N <= 256 && Q > 0, POET_ERR_ARG,
+               "match_gather: bad args (N <= 256)");
+    hipLaunchKernelGGL(match_gather_kernel, dim3(1), dim3(256), 0, ST, col, tgt_off, tgt_pos, tgt_rot, N, Q, query_idx, tgt_trans_out,
+                       tgt_rot_out, n_out);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

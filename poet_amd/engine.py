@@ -291,11 +291,16 @@ def announce(tag: str):
 # models/pose_estimation_transformer.py:454-674 (translation + geodesic rotation losses)
 # ====================================================================================================
 class PoseMatcher(nn.Module):
-    def __init__(self, cost_bbox: float = 1, cost_class: float = 1, bbox_mode: str = "gt", class_mode: str = "specific"):
+    def __init__(self, cost_bbox: float = 1, cost_class: float = 1, bbox_mode: str = "gt", class_mode: str = "specific",
+                 device_assign: bool = False):
+        """device_assign ('gt' mode): SetCriterion runs the assignment ON THE GPU (poet_lsa_boxes: the algorithm SciPy's
+        linear_sum_assignment uses, same tie-breaking) and gathers the matched targets there too -- no SciPy call, no
+        host-built index arrays between the forward and backward graphs.  forward() below stays the host path."""
         super().__init__()
         if bbox_mode not in ("gt", "jitter"):
             raise NotImplementedError("PoseMatcher: bbox_mode 'gt' and 'jitter' are implemented ('backbone' matching is evaluation-side)")
         self.cost_bbox, self.cost_class, self.bbox_mode = cost_bbox, cost_class, bbox_mode
+        self.device_assign = bool(device_assign) and bbox_mode == "gt"
         self._cache = (None, None)
 
     @torch.no_grad()
@@ -431,6 +436,43 @@ class SetCriterion(nn.Module):
         gi = idx[2].to(pos.device) if pos.device != idx.device else idx[2]
         return idx[0], idx[1], pos[gi].to(device), rot[gi].to(device), idx[2], targets
 
+    def _device_match(self, outputs, targets, n_boxes):
+        """matcher.py:158-229 + the target gather of pose_estimation_transformer.py:649-668 on the device ('gt' mode): returns
+        (flat query index b*Q+s, matched target translations, rotations, n_obj).  Host work: shapes (metadata) and one small
+        upload of the per-image offsets; no device->host copy."""
+        pb = outputs["pred_boxes"]
+        dev = pb.device
+        N, Q = pb.shape[:2]
+        counts = [int(t["boxes"].shape[0]) for t in targets]
+        n_obj = int(sum(min(int(a), c) for a, c in zip(n_boxes, counts)))
+        if n_obj == 0:
+            z = torch.zeros
+            return z(0, dtype=torch.int64, device=dev), z((0, 3), device=dev), z((0, 3, 3), device=dev), 0
+        meta = np.zeros(2 * N + 1, np.int64)
+        meta[1:N + 1] = np.cumsum(counts)
+        meta[N + 1:] = np.asarray(n_boxes, np.int64)
+        if not hasattr(self, "_ring"):
+            self._ring = _PinnedRing()
+        meta_d = self._ring.stage(meta, dev).to(torch.int32)
+        tb = torch.cat([t["boxes"].reshape(-1, 4) for t in targets], 0).to(dev, non_blocking=True).float().contiguous()
+        tpos = torch.cat([t["relative_position"] for t in targets], 0).to(dev, non_blocking=True).float().contiguous()
+        trot = torch.cat([t["relative_rotation"] for t in targets], 0).to(dev, non_blocking=True).float().contiguous()
+        if not hasattr(self, "_lsa_status") or self._lsa_status.device != dev:
+            self._lsa_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        col = torch.empty((N, Q), dtype=torch.int32, device=dev)
+        ops.lsa_boxes(pb.float().contiguous(), tb, meta_d[: N + 1], meta_d[N + 1:], col, self._lsa_status, self.matcher.cost_bbox)
+        qi = torch.empty(n_obj, dtype=torch.int64, device=dev)
+        tt = torch.empty((n_obj, 3), dtype=torch.float32, device=dev)
+        tr = torch.empty((n_obj, 3, 3), dtype=torch.float32, device=dev)
+        ops.match_gather(col, meta_d[: N + 1], tpos, trot, qi, tt, tr)
+        self._last_col = col
+        return qi, tt, tr, n_obj
+
+    def device_match_status(self) -> int:
+        """0 = every on-device assignment so far was solved (synchronises; call it at logging points, not per step)."""
+        st = getattr(self, "_lsa_status", None)
+        return 0 if st is None else int(st.item())
+
     def _losses(self, outputs, gathered):
         """pose_estimation_transformer.py:472-609, one entry of self.losses per term (the default pair normally takes the
         fused kernel in forward(); this is the general form)."""
@@ -470,6 +512,21 @@ class SetCriterion(nn.Module):
                 if k in outputs:
                     aux[k] = outputs[k]
         dev = outputs["pred_translation"].device
+        stacked0 = outputs.get("_stacked")
+        if (self.default_terms and getattr(self.matcher, "device_assign", False) and dev.type == "cuda" and stacked0 is not None
+                and stacked0[0].shape[0] == len(aux_list) + 1):
+            # every decoder layer carries the same query boxes in 'gt' mode: ONE assignment, solved on the GPU, feeds the fused
+            # loss of all layers
+            from .functional import PoseLossFn
+            qi, tt, tr, n_obj = self._device_match(outputs, targets, n_boxes)
+            vec = PoseLossFn.apply(stacked0[0], stacked0[1], qi, tt, tr, n_obj)
+            L = vec.shape[0]
+            losses = LossDict({"loss_trans": vec[L - 1, 0], "loss_rot": vec[L - 1, 1]})
+            for i in range(L - 1):
+                losses[f"loss_trans_{i}"] = vec[i, 0]
+                losses[f"loss_rot_{i}"] = vec[i, 1]
+            losses.vec = vec
+            return losses
         indices = self.matcher(main, targets, n_boxes)
         all_idx = [indices] + [self.matcher(aux, targets, n_boxes) for aux in aux_list]
         if self.default_terms and all(ix is indices for ix in all_idx[1:]):

@@ -538,6 +538,22 @@ def pose_loss(trans, rot, qi, tt, tr, n_obj, losses, gt, gr):
     return losses
 
 
+def lsa_boxes(pred_boxes, tgt_boxes, tgt_off, n_pred, col_out, status, cost_bbox=1.0):
+    """pred_boxes (N,Q,4) f32, tgt_boxes (T,4) f32, tgt_off (N+1) i32, n_pred (N) i32 -> col_out (N,Q) i32 (device tensors)."""
+    lib = _lib.load()
+    N, Q = pred_boxes.shape[:2]
+    _lib.check(lib.poet_lsa_boxes(_req(pred_boxes, "pred_boxes").data_ptr(), _req(tgt_boxes, "tgt_boxes").data_ptr(), tgt_off.data_ptr(),
+                                  n_pred.data_ptr(), float(cost_bbox), N, Q, col_out.data_ptr(), status.data_ptr(), _stream()), "poet_lsa_boxes")
+    return col_out
+
+
+def match_gather(col, tgt_off, tgt_pos, tgt_rot, qi, tt, tr, n_out=None):
+    lib = _lib.load()
+    N, Q = col.shape
+    _lib.check(lib.poet_match_gather(_req(col, "col").data_ptr(), tgt_off.data_ptr(), tgt_pos.data_ptr(), tgt_rot.data_ptr(), N, Q,
+                                     qi.data_ptr(), tt.data_ptr(), tr.data_ptr(), _ptr(n_out), _stream()), "poet_match_gather")
+
+
 def pose_finish_bwd(rot_all, cls, drot, dtrans, drot_all, dtrans_all, R, ncls):
     lib = _lib.load()
     _lib.check(lib.poet_pose_finish_bwd(_req(rot_all, "rot_all").data_ptr(), cls.data_ptr(), drot.data_ptr(), dtrans.data_ptr(),

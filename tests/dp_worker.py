@@ -42,7 +42,9 @@ def main():
         losses.append(float(total))
     torch.cuda.synchronize()
     if graphed:
-        assert tr.segs is not None and len(tr.segs) == 4
+        n_enc = len(r["model"].transformer.encoder.layers)          # one backward segment per gradient bucket: heads, decoder, encoder layers, input_proj
+        assert tr.segs is not None and len(tr.segs) == len(tr.seg_tags) == 3 + n_enc
+        assert [t for tags in tr.seg_tags for t in tags] == [b[0] for b in tr.arena.buckets]
     assert tr.reducer is not None and tr.reducer.active
     flat = torch.cat([p.detach().float().flatten() for p in r["model"].parameters()]).cpu().numpy()
     np.savez(out, flat=flat, losses=np.array(losses))

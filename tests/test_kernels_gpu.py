@@ -927,3 +927,51 @@ def test_gemm_dw_list_matches_loop(ops):
         D.next_layer(); ops.linear_dw(dy_a, x_a, g1, rows=rows)
         D.next_layer(); ops.linear_dw(dy_b, x_a, g2, rows=rows)
     assert (g1.cpu() - dy_a.cpu().t() @ x_a.cpu()).abs().max().item() < 2e-3 and (g2.cpu() - dy_b.cpu().t() @ x_a.cpu()).abs().max().item() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------- on-device matcher
+def test_lsa_boxes_matches_scipy_including_ties(ops):
+    """poet_lsa_boxes == scipy.optimize.linear_sum_assignment on the fp32 L1 box cost (models/matcher.py:60-75,158-229): random
+    boxes, exact duplicates (zero-cost ties), quantised boxes (many equal costs), fewer / more predictions than targets,
+    images without targets or predictions."""
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(5)
+    N, Q = 24, 50
+    pred = np.full((N, Q, 4), -1.0, np.float32)
+    tgts, n_pred, off = [], [], [0]
+    for i in range(N):
+        nt = int(rng.integers(0, 51)) if i % 7 else 0
+        kind = i % 4
+        if kind == 0:
+            t = rng.uniform(0, 1, (nt, 4))
+        elif kind == 1:
+            t = np.round(rng.uniform(0, 1, (nt, 4)) * 4) / 4                     # coarse grid: many equal costs
+        elif kind == 2:
+            t = np.repeat(rng.uniform(0, 1, (max(nt // 3, 1), 4)), 3, 0)[:nt]    # exact duplicates
+        else:
+            t = rng.uniform(0, 1, (nt, 4)) * 0 + 0.5                             # constant matrix (scipy: identity)
+        t = t.astype(np.float32)
+        npd = nt if i % 5 else int(rng.integers(0, 51))                           # usually square ('gt' mode), sometimes rectangular
+        if i % 3 == 0 and nt:
+            p_ = t[rng.permutation(nt)][:npd] if npd <= nt else np.concatenate([t, rng.uniform(0, 1, (npd - nt, 4)).astype(np.float32)])
+        else:
+            p_ = rng.uniform(0, 1, (npd, 4)).astype(np.float32)
+            if kind == 1:
+                p_ = (np.round(p_ * 4) / 4).astype(np.float32)
+        npd = len(p_)
+        pred[i, :npd] = p_
+        tgts.append(t); n_pred.append(npd); off.append(off[-1] + nt)
+    tb = np.concatenate(tgts + [np.zeros((1, 4), np.float32)])
+    col = torch.full((N, Q), -7, dtype=torch.int32, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.lsa_boxes(dev(torch.from_numpy(pred)), dev(torch.from_numpy(tb)), dev(torch.tensor(off, dtype=torch.int32)),
+                  dev(torch.tensor(n_pred, dtype=torch.int32)), col, status, 1.0)
+    assert int(status.item()) == 0
+    col = col.cpu().numpy()
+    for i in range(N):
+        c = np.float32(1.0) * np.abs(pred[i, : n_pred[i], None, :] - tgts[i][None, :, :]).sum(-1)
+        exp = np.full(Q, -1, np.int64)
+        if c.size:
+            r, cc = linear_sum_assignment(c)
+            exp[r] = cc
+        assert np.array_equal(col[i], exp), (i, n_pred[i], len(tgts[i]), col[i][:12], exp[:12])

@@ -509,6 +509,31 @@ def test_optimizer_state_resume_and_lr_schedule(gpu):
     assert d_lo < 0.05 * d_hi, (d_hi, d_lo)
 
 
+def test_device_matcher_equals_host_matcher(gpu):
+    """PoseMatcher(device_assign=True): assignment + target gather on the GPU (no SciPy, no host index arrays) gives the
+    losses and the training trajectory of the host matcher, bit for bit on the losses; the goldens' loss values hold too."""
+    import poet_amd
+    from oracle.formula import CONFIGS, make_inputs
+    cfg = CONFIGS["tiny"]
+    runs = {}
+    for where in ("host", "device"):
+        r = gpu("tiny", 2, True, torch.float32, dropout=0.0)
+        crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(device_assign=(where == "device")), poet_amd.build_weight_dict(cfg["dec_layers"]))
+        r["model"].train()
+        tr = poet_amd.Trainer(r["model"], crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+        losses = []
+        for step in range(5):
+            _, _, targets = make_inputs(cfg, seed=700 + step, batch=2, pad=True)
+            if step == 3:
+                targets[1] = {k: v[:0] for k, v in targets[1].items()}                  # an image without objects
+            gt = [{k: (v.cuda() if (k.startswith("relative") or step % 2) else v) for k, v in t.items()} for t in targets]
+            total, ld = tr.step(r["samples"], gt)
+            losses.append([float(total)] + [float(ld[k]) for k in sorted(ld)])
+        assert crit.device_match_status() == 0
+        runs[where] = np.asarray(losses)
+    np.testing.assert_allclose(runs["device"], runs["host"], rtol=1e-6, atol=1e-7)
+
+
 def test_device_resident_targets_match_host_targets(gpu):
     """The reference moves EVERY target field to the device (engine.py:63); boxes/labels on the GPU must give the same
     losses as boxes/labels on the host, step after step with fresh target tensors (whose freed addresses get reused --
