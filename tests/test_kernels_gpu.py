@@ -951,6 +951,7 @@ def test_lsa_boxes_matches_scipy_including_ties(ops):
         else:
             t = rng.uniform(0, 1, (nt, 4)) * 0 + 0.5                             # constant matrix (scipy: identity)
         t = t.astype(np.float32)
+        nt = len(t)
         npd = nt if i % 5 else int(rng.integers(0, 51))                           # usually square ('gt' mode), sometimes rectangular
         if i % 3 == 0 and nt:
             p_ = t[rng.permutation(nt)][:npd] if npd <= nt else np.concatenate([t, rng.uniform(0, 1, (npd - nt, 4)).astype(np.float32)])
