@@ -116,6 +116,10 @@ typedef struct PoetGemmDesc {
                               rounding is the same perturbation for every token and does not average out downstream the way
                               per-token activation rounding does: DESIGN.md section 3. */
     int32_t reserved0;
+    void* workspace;       /* optional scratch owned by the caller (16-byte aligned); used by the weight-gradient form to merge its
+                              partial tiles with plain stores + one reduction launch instead of fp32 atomics.  Contents are
+                              undefined afterwards; calls sharing it must be ordered on one stream. */
+    int64_t workspace_bytes;
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
 /* Which kernel family the calling thread's last successful poet_gemm launched (profiling aid: lets a caller attribute a

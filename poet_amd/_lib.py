@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int32), ("atomic", C.c_int32), ("act", C.c_int32),
         ("alpha", f32), ("gate_scale", f32), ("drop_p", f32), ("seed", u32),
         ("out_mode", C.c_int32), ("hm_M", C.c_int32), ("hm_S", C.c_int32), ("hm_D", C.c_int32),
-        ("seed_dev", vp), ("b_split", C.c_int32), ("reserved0", C.c_int32),
+        ("seed_dev", vp), ("b_split", C.c_int32), ("reserved0", C.c_int32), ("workspace", vp), ("workspace_bytes", i64),
     ]
 
 

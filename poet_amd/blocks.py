@@ -70,8 +70,14 @@ def Wf(W, like, split):
 
 
 def vstrides(M, S, D):
-    """element strides (n, s, m) of a head-major (N,M,S,D) value map"""
+    """element strides (n, s, m) of a contiguous head-major (N,M,S,D) value map"""
     return (M * S * D, D, S * D)
+
+
+def vstrides_of(V):
+    """element strides (n, s, m) of a head-major value map that may be a head slice of a larger (N, M_all, S, D) tensor (the
+    decoder's value maps of all layers come out of ONE projection)"""
+    return (V.stride(0), V.stride(2), V.stride(1))
 
 
 # ---- (a) value projection ------------------------------------------------------------------------
@@ -82,13 +88,14 @@ def value_proj_fwd(inp2d, W, b, row_mask, N, S, M, D, act=None, split=False):
     return V
 
 
-def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate, act=None):
+def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate, act=None, wb_is_operand=False):
+    """wb_is_operand: W is already the GEMM operand (a stacked view chosen by the caller), not a parameter to look a shadow up for"""
     rows, d = N * S, M * D
     dVr = empty((rows, d), act or inp2d.dtype, inp2d)
     ops.vgrad_to_rows(dV, vstrides(M, S, D), row_mask, dVr, N, S, M, D)
     ops.linear_dw(dVr, inp2d, gW, rows=rows, db=gb)
     if dinp is not None:
-        ops.linear_dx(dVr, Wb(W, dVr), dinp, rows=rows, add_src=dinp if accumulate else None)
+        ops.linear_dx(dVr, W if wb_is_operand else Wb(W, dVr), dinp, rows=rows, add_src=dinp if accumulate else None)
 
 
 # ---- (b) offsets/logits projection + fused deformable sampling ----------------------------------
@@ -117,7 +124,7 @@ def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P
         Wt, sp = Wf(aw_w, q2d, split)
         ops.linear_fwd(q2d, Wt, aw_b, OA[:, 2 * mlp:], ldc=ldq, split=sp)
     out = empty((rows, M * D), OA.dtype, q2d)
-    ops.msda_fused_fwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq, grid_queries=grid_queries)
+    ops.msda_fused_fwd(V, vstrides_of(V), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq, grid_queries=grid_queries)
     return out, OA
 
 
@@ -126,7 +133,7 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
     dOA = torch.empty_like(OA)
-    ops.msda_fused_bwd(V, vstrides(M, geom.S, D), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
+    ops.msda_fused_bwd(V, vstrides_of(V), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
                        grid_queries=grid_queries)
     plain = seg_sums is None
     pr = _pair(so_w, dOA)

@@ -38,6 +38,7 @@ struct DwP {
     float* ysum;          // optional [n1]: += column sums of Y (the bias gradient), accumulated by the n2-tile-0 workgroups
     int64_t ldy, ldx, ldc;
     int rows, n1, n2, ntiles, tiles_n2, splits;
+    float* ws;            // optional workspace [splits][ntiles][128 x 128]: partial tiles leave by plain stores, dw_reduce_kernel merges
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
@@ -175,6 +176,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
     }
 
     // ---- merge the partial tile: lane holds rows 4*b4 + t, column r16 of each 16x16 fragment ----
+    if (p.ws) {
+        // plain, fully coalesced stores of the register image (wave, fragment, t, lane); dw_reduce_kernel sums the row ranges.
+        // (fp32 atomics execute memory-side at ~0.4 T/s: 4-8 M of them cost more than the MFMA loop of the 256-wide shapes)
+        float* wp = p.ws + ((int64_t)split * p.ntiles + tile) * (DW_T * DW_T) + wid * 4096 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wp[((i * 4 + jj) * 4 + t) * 64] = acc[i][jj][t];
+        return;
+    }
     float* Cp = p.C + (int64_t)(n1_0 + wm * 64) * p.ldc + n2_0 + wn * 64 + r16;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -183,6 +196,25 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
                 atomicAdd(Cp + (int64_t)(i * 16 + b4 * 4 + t) * p.ldc + jj * 16, acc[i][jj][t]);
+}
+
+// dW[tile] += sum over row ranges of the partial tiles (single owner per element: a plain read-modify-write)
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const DwP p, int nsplit_used) {
+    const int tile = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;               // e: index inside the 128 x 128 register image
+    const float* wp = p.ws + (int64_t)tile * (DW_T * DW_T) + e;
+    const int64_t stride = (int64_t)p.ntiles * (DW_T * DW_T);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nsplit_used; k += 4) {
+        s0 += wp[(int64_t)k * stride]; s1 += wp[(int64_t)(k + 1) * stride];
+        s2 += wp[(int64_t)(k + 2) * stride]; s3 += wp[(int64_t)(k + 3) * stride];
+    }
+    for (; k < nsplit_used; ++k) s0 += wp[(int64_t)k * stride];
+    const int lane = e & 63, t = (e >> 6) & 3, fr = (e >> 8) & 15, wid = e >> 12;
+    const int i = fr >> 2, jj = fr & 3, wm = wid >> 1, wn = wid & 1, r16 = lane & 15, b4 = lane >> 4;
+    const int n1_0 = (tile / p.tiles_n2) * DW_T, n2_0 = (tile % p.tiles_n2) * DW_T;
+    float* c = p.C + (int64_t)(n1_0 + wm * 64 + i * 16 + b4 * 4 + t) * p.ldc + n2_0 + wn * 64 + jj * 16 + r16;
+    *c += (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace
@@ -221,7 +253,12 @@ bool gemm_dw_try(const GemmK& g, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE);
         attr_set = true;
     }
+    // partial tiles through the caller's workspace when it is large enough (PoetGemmDesc.workspace), else fp32 atomics
+    const int64_t need = (int64_t)p.splits * p.ntiles * DW_T * DW_T * 4;
+    static const int no_ws = [] { const char* e = getenv("POET_DW_NO_WORKSPACE"); return e && atoi(e) ? 1 : 0; }();
+    p.ws = (!no_ws && d.workspace && d.workspace_bytes >= need && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0) ? reinterpret_cast<float*>(d.workspace) : nullptr;
     hipLaunchKernelGGL(gemm_dw_kernel, dim3(nblocks), dim3(256), 2 * DW_STAGE, st, p);
+    if (p.ws) hipLaunchKernelGGL(dw_reduce_kernel, dim3(DW_T * DW_T / 256, p.ntiles), dim3(256), 0, st, p, p.splits);
     return true;
 }
 

@@ -587,20 +587,11 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             const float2 rf_ = ldg32<float2>(p.ref, (uint32_t)q_ * rf_q + rf_lane);                                   \
             n_rx = rf_.x; n_ry = rf_.y;                                                                               \
         } while (0)
-        // Which query a slot takes: the 4 DPP rows of a wave walk four different QUARTERS of the tile's query range.  Four
-        // consecutive queries -- the obvious assignment -- sample the same pixel of the coarse levels with every point (a 60x80
-        // level is 8x finer than the 8x10 one and the offsets of a (head, point) are the same), so the 4 x 16 lanes of a ds_add
-        // hit 16 addresses instead of 64 and the LDS atomic unit serialises them 4 ways (2 ways at the 30x40 level).
-        const int qn = (nq + 3) >> 2, wv_ = slot >> 2, qbase_ = (slot & 3) * qn;
-        // (a slot's queries: qbase_ + wv_ + 16 k, k = 0, 1, ... while the local index stays inside the quarter and the range)
-#define DV_IDX(J) (qbase_ + (J))
-        int jloc = wv_;
-        const int qend_ = min(qn, nq - qbase_);                         // local end of this slot's quarter (may be <= 0)
-        if (jloc < qend_) DV_FETCH(DV_IDX(jloc));
+        if (slot < nq) DV_FETCH(slot);
 #pragma unroll 1
-        for (; jloc < qend_; jloc += NSLOT / 4) {
+        for (int i = slot; i < nq; i += NSLOT) {
             const float gs = n_g * scale, lg = n_lg, ox = n_ox, oy = n_oy, rx = n_rx, ry = n_ry;
-            if (jloc + NSLOT / 4 < qend_) DV_FETCH(DV_IDX(jloc + NSLOT / 4));
+            if (i + NSLOT < nq) DV_FETCH(i + NSLOT);
             // ---- lane j (< L*P) of the slot prepares sample point j: softmax over the DPP row, then its 4 corners ----
             const float mx = row16_max(lg);
             const float e = __expf(lg - mx);                             // lanes without a point carry -3e38: e = 0

@@ -74,9 +74,20 @@ class ParamArena:
         n_enc = 1 + max([int(m.group(1)) for m in (_ENC_LAYER.match(n) for n, _ in named) if m] or [-1])
         bucket = lambda n: _bucket_of(n, n_enc)
         order, taken = [], set()
+        # the value projections of ALL decoder layers read the same encoder memory: laid out adjacent (weights, then biases)
+        # they are one (n_dec * d)-wide Linear -- one GEMM forward, one for dW, one for dX -- while state_dict still sees n_dec
+        # separate modules (_link_value_stack)
+        vw = sorted((n for n, _ in named if re.match(r"^transformer\.decoder\.layers\.\d+\.cross_attn\.value_proj\.weight$", n)),
+                    key=lambda n: int(n.split(".")[3]))
+        vb = [n[: -len("weight")] + "bias" for n in vw]
+        vstack = vw + vb if len(vw) > 1 and all(b in byname for b in vb) else []
         for n, p in sorted(named, key=lambda t: bucket(t[0])):
             if n in taken:
                 continue
+            if vstack and n.startswith("transformer.decoder") and vstack[0] not in taken:
+                for q in vstack:                              # first thing in the decoder bucket
+                    order.append((q, byname[q]))
+                    taken.add(q)
             if n.endswith("sampling_offsets.weight"):
                 pre = n[: -len("sampling_offsets.weight")]
                 quad = [pre + "sampling_offsets.weight", pre + "attention_weights.weight", pre + "sampling_offsets.bias", pre + "attention_weights.bias"]
@@ -128,6 +139,7 @@ class ParamArena:
         self.base_lr = self.lr = float(lr)
         self.groups = [(0, self.total, lr)]
         self._link_projection_pairs()
+        self._link_value_stack(vstack)
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.step_count = 0
         self.step_word = torch.zeros(1, dtype=torch.int32, device=dev)       # device copy of step_count (graph replays bump it)
@@ -179,6 +191,23 @@ class ParamArena:
             rows, d = w.shape[0] + aw_p.shape[0], w.shape[1]
             w._pair = dict(w=self.flat[o:o + rows * d].view(rows, d), w16=self.flat_bf16[o:o + rows * d].view(rows, d),
                            gw=self.grad[o:o + rows * d].view(rows, d), b=self.flat[sb_o:sb_o + rows], gb=self.grad[sb_o:sb_o + rows])
+
+    def _link_value_stack(self, vstack):
+        """Hang the stacked views of the decoder layers' value projections on layer 0's weight (`_vstack`: fp32 / bf16 /
+        gradient views of the (n_dec * d, d) weight and the (n_dec * d) bias) when they really are contiguous."""
+        if not vstack:
+            return
+        pos = {n: (p, o) for n, p, o in self.entries}
+        n = len(vstack) // 2
+        (w0, o0), (b0, ob) = pos[vstack[0]], pos[vstack[n]]
+        d_out, d_in = w0.shape
+        ok = all(pos[vstack[i]][1] == o0 + i * d_out * d_in and pos[vstack[i]][0].shape == w0.shape for i in range(n)) and \
+            all(pos[vstack[n + i]][1] == ob + i * d_out for i in range(n))
+        if not ok:
+            return
+        rows = n * d_out
+        w0._vstack = dict(n=n, w=self.flat[o0:o0 + rows * d_in].view(rows, d_in), w16=self.flat_bf16[o0:o0 + rows * d_in].view(rows, d_in),
+                          gw=self.grad[o0:o0 + rows * d_in].view(rows, d_in), b=self.flat[ob:ob + rows], gb=self.grad[ob:ob + rows])
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow from the fp32 masters (after construction / load_state_dict)."""

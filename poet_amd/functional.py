@@ -125,15 +125,32 @@ class DecoderFn(torch.autograd.Function):
         mem2 = memory16.reshape(N * S, d)
         x = tgt.reshape(N * Q, d).contiguous()
         qp = qpos.reshape(N * Q, d).contiguous()
-        hs = torch.empty((cfg["n_layers"], N, Q, d), dtype=torch.float32, device=memory.device)
+        nl = cfg["n_layers"]
+        hs = torch.empty((nl, N, Q, d), dtype=torch.float32, device=memory.device)
         saved = []
-        for i in range(cfg["n_layers"]):
+        # value maps of all layers from ONE projection of the encoder memory when the arena keeps the layers' value_proj
+        # parameters adjacent (engine.ParamArena._link_value_stack): memory is read once instead of n_layers times
+        vs = getattr(_pdict(names, params, "layers.0.")["cross_attn.value_proj.weight"], "_vstack", None)
+        if vs is not None and vs["n"] != nl:
+            vs = None
+        V_all = None
+        if vs is not None:
+            Wt, sp = B.Wf(vs["w"], mem2, cfg.get("split", False))
+            if not sp:
+                Wt = vs["w16"] if mem2.dtype == torch.bfloat16 else vs["w"]
+            V_all = B.empty((N, M * nl, S, D), cfg.get("act") or mem2.dtype, mem2)
+            ops.linear_fwd(mem2, Wt, vs["b"], V_all, row_mask=mask, head_major=(M * nl, S, D), split=sp)
+        for i in range(nl):
             P_ = _pdict(names, params, f"layers.{i}.")
-            V = B.value_proj_fwd(mem2, P_["cross_attn.value_proj.weight"], P_["cross_attn.value_proj.bias"], mask, N, S, M, D,
-                                 cfg.get("act"), cfg.get("split", False))
+            if V_all is not None:
+                V = V_all[:, i * M:(i + 1) * M]
+            else:
+                V = B.value_proj_fwd(mem2, P_["cross_attn.value_proj.weight"], P_["cross_attn.value_proj.bias"], mask, N, S, M, D,
+                                     cfg.get("act"), cfg.get("split", False))
             x, sv = B.dec_layer_fwd(x, qp, V, P_, ref_in, geom, N, Q, M, cfg["P"], cfg["p"], cfg["training"])
             ops.cast(x, hs[i])
             saved.append(sv)
+        ctx.vstack = vs if V_all is not None else None
         ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
         ctx.mem2, ctx.ref_in, ctx.mask, ctx.dims = mem2, ref_in, mask, (N, S, d, Q)
         ctx.mem_dtype = memory.dtype
@@ -151,8 +168,11 @@ class DecoderFn(torch.autograd.Function):
         dmem = torch.empty((N * S, d), dtype=ctx.mem_dtype, device=dhs.device) if ctx.need_mem else None
         dx = None
         first = True
+        nl = cfg["n_layers"]
+        vs = ctx.vstack
+        dV_all = torch.zeros((N, M * nl, S, D), dtype=torch.float32, device=dhs.device) if vs is not None else None
         with ops.defer_small_dw() as deferred:           # the 320-row dW + db of all layers: one launch per Linear, at the end
-            for i in reversed(range(cfg["n_layers"])):
+            for i in reversed(range(nl)):
                 deferred.next_layer()
                 pre = f"layers.{i}."
                 P_ = _pdict(names, params, pre)
@@ -161,13 +181,17 @@ class DecoderFn(torch.autograd.Function):
                     ops.add(dx, dcur, dx)
                 else:
                     dx = dcur.clone()
-                dV = torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
+                dV = dV_all[:, i * M:(i + 1) * M] if vs is not None else torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
                 dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV)
-                B.value_proj_bwd(dV, ctx.mem2, P_["cross_attn.value_proj.weight"], ctx.mask, N, S, M, D,
-                                 G(pre + "cross_attn.value_proj.weight"), G(pre + "cross_attn.value_proj.bias"), dmem, not first,
-                                 cfg.get("act"))
+                if vs is None:
+                    B.value_proj_bwd(dV, ctx.mem2, P_["cross_attn.value_proj.weight"], ctx.mask, N, S, M, D,
+                                     G(pre + "cross_attn.value_proj.weight"), G(pre + "cross_attn.value_proj.bias"), dmem, not first,
+                                     cfg.get("act"))
                 first = False
                 ctx.saved[i] = None
+        if vs is not None:                                # one stacked backward for the value projections of all layers
+            B.value_proj_bwd(dV_all, ctx.mem2, vs["w16"] if ctx.mem2.dtype == torch.bfloat16 else vs["w"], ctx.mask, N, S, M * nl, D,
+                             vs["gw"], vs["gb"], dmem, False, cfg.get("act"), wb_is_operand=True)
         ops.SIDE.join()
         announce("1_decoder")
         dmemory = dmem.view(N, S, d) if ctx.need_mem else None

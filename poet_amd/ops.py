@@ -15,8 +15,8 @@ import struct as _struct
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 # PoetGemmDesc as one packed record (natural C layout of include/poet_hip.h; checked against ctypes below)
-_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i")     # native alignment inserts the same padding as the C compiler
-assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 16 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
+_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i Q q")     # native alignment inserts the same padding as the C compiler
+assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 32 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
 
 # Device word mixed into every dropout seed (and the Adam step) at run time.  None in eager mode; engine.GraphedTrainer
 # sets it so captured hipGraphs draw fresh masks on each replay.
@@ -28,6 +28,20 @@ def _seed_dev():
     return None if t is None else t.data_ptr()
 _GEMM_DESC = GemmDesc()
 _GEMM_BUF = (C.c_char * C.sizeof(GemmDesc)).from_buffer(_GEMM_DESC)
+
+
+# Caller-owned scratch handed to the weight-gradient GEMMs (PoetGemmDesc.workspace): one buffer per device, allocated on first use
+# (before any graph capture: the eager warm-up steps run every shape) and shared by all dW launches of the process -- they are
+# ordered on one stream.
+_WORKSPACE = {}
+_WORKSPACE_BYTES = 48 << 20
+
+
+def _workspace(device):
+    ws = _WORKSPACE.get(device)
+    if ws is None:
+        ws = _WORKSPACE[device] = torch.empty(_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws
 
 
 def dcode(t: torch.Tensor) -> int:
@@ -211,6 +225,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
     hm = head_major or (0, 0, 0)
+    ws = _workspace(Cout.device).data_ptr() if (atomic and a_kmajor and b_kmajor and batch == 1 and K >= 4096) else 0
     d = _GEMM_DESC
     _GEMM_PACK.pack_into(_GEMM_BUF, 0, A.data_ptr(), 0, B.data_ptr(), Cout.data_ptr(),
                          0 if bias is None else bias.data_ptr(), 0 if add_src is None else add_src.data_ptr(),
@@ -218,7 +233,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                          M, N, K, lda, ldb, ldc, ld_add, int(a_kmajor), int(b_kmajor), ad, bd, cd, compute, batch,
                          strideA, strideB, strideC, stride_bias, splitk, int(atomic), act, alpha, gate_scale, drop_p,
                          seed & 0xFFFFFFFF, 1 if head_major is not None else 0, hm[0], hm[1], hm[2],
-                         (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), 0)
+                         (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), 0, ws, _WORKSPACE_BYTES if ws else 0)
     if PROFILE.on:
         e0 = PROFILE.begin()
         _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")

@@ -531,8 +531,18 @@ def test_frozen_backbone_padded_images_full_size(gpu, precision, tol):
     formula_fill(omodel)
     omodel.eval()
     osamples = poet_ref.nested_from_list(images)
+    cap = {}
+    omodel.rotation_head[-1].register_forward_hook(lambda m, i, o: cap.__setitem__("r6", o.detach()))
     with torch.no_grad():
         oout, onb = omodel(osamples, targets)
+    # conditioning of the reference's 6D -> R map per query, as in _rotation_amplification (a random backbone over noise
+    # images leaves one or two of the 40 queries above 8x)
+    cls = oout["pred_classes"].clamp(min=0).view(-1)
+    r6 = cap["r6"].reshape(-1, omodel.n_classes, 6)[torch.arange(cls.numel()), cls]
+    a1, a2 = r6[:, :3], r6[:, 3:]
+    x = a1 / a1.norm(dim=1, keepdim=True)
+    amp = 1.0 / torch.minimum(a1.norm(dim=1), (a2 - (a2 * x).sum(1, keepdim=True) * x).norm(dim=1))
+    allow = torch.clamp(amp / AMP0, min=1.0).view(len(images), -1, 1, 1)
     vr = otr.valid_ratio(osamples.mask)
     assert float(vr[1].max()) < 0.9                                    # the masks really are non-trivial
     # product (GPU)
@@ -550,9 +560,12 @@ def test_frozen_backbone_padded_images_full_size(gpu, precision, tol):
         out, nb = model(samples, [{k: v.cuda() for k, v in t.items()} for t in targets])
     assert list(nb) == list(onb)
     dt = (out["pred_translation"].cpu() - oout["pred_translation"]).abs().max().item()
-    dR = (out["pred_rotation"].cpu() - oout["pred_rotation"]).abs().max().item()
-    print(f"frozen backbone, padded batch, {precision}: max|dt| {dt:.2e} max|dR| {dR:.2e}")
-    assert dt < tol and dR < tol, (dt, dR)
+    eR = (out["pred_rotation"].cpu() - oout["pred_rotation"]).abs()
+    dR, over = eR.max().item(), (eR / allow).max().item()
+    well = eR[(amp.view(len(images), -1) <= AMP0)].max().item()
+    print(f"frozen backbone, padded batch, {precision}: max|dt| {dt:.2e} max|dR| {dR:.2e} (well-conditioned queries {well:.2e}; "
+          f"amplification max {amp.max():.1f}, worst error / allowance {over / tol:.2f})")
+    assert dt < tol and over < tol, (dt, dR, over)
 
 
 def test_device_matcher_equals_host_matcher(gpu):
