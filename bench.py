@@ -88,32 +88,67 @@ def gemm_flops_per_image(cfg):
     return enc + dec + heads + proj
 
 
-# HBM traffic per launch of a kernel family from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
-# WRITE_SIZE passes of this same command, profiles/collect_round1.sh): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the
-# gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when the family is not in the summary.
-# profile tag (poet_amd/ops.py) -> substring of the kernel symbols in profiles/round1_pmc_hbm.csv
+# HBM traffic per launch of a kernel family from the committed rocprofv3 PMC summary of THIS command (separate --pmc
+# FETCH_SIZE / WRITE_SIZE passes, profiles/collect.sh -> profiles/round<N>_<config>_pmc_hbm.csv, latest round for the
+# config): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when
+# the family is not in the summary.
+# profile tag (poet_amd/ops.py) -> substring of the kernel symbols in the summaries
 _PMC_NAMES = {"msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_kernel<", "msda_fused_fwd": "msda_fwd_kernel",
-              "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws_kernel<", "gemm_stream_fwd": "gemm_ws_kernel<",
+              "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws", "gemm_stream_fwd": "gemm_ws",
               "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
               "gemm_small_fwd": "gemm_small_kernel<false", "gemm_small_dX": "gemm_small_kernel<true", "gemm_small_dW": "gemm_small_dw_kernel",
-              "ln_fwd": "ln_fwd_kernel<bf16", "ln_bwd": "ln_bwd_kernel<bf16"}
+              "ln_fwd": "ln_fwd_kernel<", "ln_bwd": "ln_bwd_kernel<"}
 _PMC_FILTER = {"gemm_stream_dX": ", true,", "gemm_stream_fwd": ", false,"}     # ws kernels: W stored [K][N] (dX) or not
 
 
-def pmc_traffic_bytes(tag):
-    path = os.path.join(ROOT, "profiles", "round1_pmc_hbm.csv")
+def _pmc_rows(config, kind):
+    import csv, glob, re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{config}_pmc_{kind}.csv")),
+                   key=lambda p: int(re.search(r"round(\d+)_", os.path.basename(p)).group(1)))
+    if not paths:
+        return None, []
+    rows = [r for r in csv.reader(l for l in open(paths[-1]) if not l.startswith("#"))]
+    return os.path.basename(paths[-1]), rows
+
+
+def pmc_traffic_bytes(tag, config="ycbv"):
     key = _PMC_NAMES.get(tag)
-    if key is None or not os.path.exists(path):
+    _, rows = _pmc_rows(config, "hbm")
+    if key is None or len(rows) < 2:
         return None
-    import csv
-    rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))][1:]
     flt = _PMC_FILTER.get(tag, "")
     tot = n = 0.0
-    for r in rows:                                      # launch-weighted mean over the symbols of the family
+    for r in rows[1:]:                                  # launch-weighted mean over the symbols of the family
         if key in r[0] and flt in r[0]:
             tot += float(r[1]) * (2 * float(r[2]) + float(r[4])) * 1024
             n += float(r[1])
     return int(tot / n) if n else None
+
+
+def pmc_mfma_summary(config="ycbv"):
+    """Matrix-pipe view of the GEMM kernels from the committed SQ counter summary (profiles/round<N>_<config>_pmc_sq.csv):
+    time-weighted MFMA rate (SQ_INSTS_MFMA * flop per instruction / kernel-trace duration) and the share of the busy CU
+    cycles the matrix pipe was busy.  None when no summary for this config is committed."""
+    src, rows = _pmc_rows(config, "sq")
+    if len(rows) < 2:
+        return None
+    h = {c: i for i, c in enumerate(rows[0])}
+    us = tf = busy = 0.0
+    top = None
+    for r in rows[1:]:
+        if not r[0].startswith("gemm") or float(r[h["SQ_INSTS_MFMA"]]) == 0:
+            continue
+        w = float(r[h["avg_us"]])                       # per-launch time; launches per step are in the kernel_stats summary
+        us += w
+        tf += w * float(r[h["mfma_TFLOPs"]])
+        busy += w * float(r[h["mfma_busy_share"]])
+        if top is None or float(r[h["mfma_TFLOPs"]]) > top[1]:
+            top = (r[0], float(r[h["mfma_TFLOPs"]]), float(r[h["mfma_busy_share"]]))
+    if not us:
+        return None
+    return {"source": "profiles/" + src, "gemm_kernels_mean_TFLOPs": round(tf / us, 1), "gemm_kernels_mean_frac_of_peak": round(tf / us / MFMA_BF16_PEAK_TFS, 4),
+            "gemm_kernels_mean_matrix_pipe_busy_share": round(busy / us, 3),
+            "best_kernel": {"kernel": top[0], "TFLOPs": top[1], "frac_of_peak": round(top[1] / MFMA_BF16_PEAK_TFS, 4), "matrix_pipe_busy_share": top[2]}}
 
 
 def build_model(cfg, feats, precision, device):
@@ -336,7 +371,15 @@ def main():
         }
         if prof is not None:
             out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)
-            out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"])
+            out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"], args.config)
+            # the step's matrix work next to the dominant (HBM / LDS-atomic bound) kernel: algorithmic GEMM flops of the
+            # step over the MFMA kernels' own time, and what the SQ counters say about them
+            gemm_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("gemm")) / prof_steps
+            out["roofline"]["mfma"] = {"peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                                       "gemm_kernels_ms_per_step": round(gemm_ms, 3),
+                                       "achieved_over_gemm_kernel_time": round(fl / 1e12 / (gemm_ms / 1e3), 1) if gemm_ms else None,
+                                       "frac": round(fl / 1e12 / (gemm_ms / 1e3) / MFMA_BF16_PEAK_TFS, 4) if gemm_ms else None,
+                                       "pmc": pmc_mfma_summary(args.config)}
             if out["roofline"]["kernel"].startswith("msda_bwd_dvalue_scatter"):
                 # the contract's two bounds do not name this kernel's real limiter; say so next to the HBM fraction
                 out["roofline"]["limiter"] = "the LDS atomic unit (26 M ds_add_u32 wave-instructions per launch at ~8 clk each), not HBM: DESIGN.md section 5/9"

@@ -366,6 +366,203 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
     }
 }
 
+// ---- shared-geometry gathers: the encoder's shape (M = 16 heads x D = 16, L = 4 levels x P = 4 points, bf16) --------------
+// The general gather kernels above are VALU bound, and half of their VALU time is sample GEOMETRY computed redundantly: the 4
+// lanes [x corner][channel half] of a (query, head) each redo floor / range tests / clamps / 24-bit address multiplies / weights
+// of all 16 points (~130 issue cycles per point: on gfx950 v_cvt, v_floor, v_cmp, v_cndmask, v_med3, v_mad_u32_u24, v_lshlrev
+// and every DPP / SGPR-operand form issue at 4 cycles per wave-instruction against 2 for v_fma / v_and / v_add -- measured,
+// scratch/valu_probe.hip).  Here one wave = one query row (16 heads x 4 lanes) and the 4 lanes of a head split the geometry by
+// LEVEL: lane o prepares the 4 points of level o for BOTH x corners (softmax over the quad with DPP) and leaves one 16-byte record
+//     { byte offset of the upper corner pixel, of the lower one, weight of the upper, of the lower }
+// per (x corner, point, head) in LDS; the gather loop then reads its corner's record with one ds_read_b128 (LDS pipe, no
+// VALU) and spends VALU only on bf16 unpack + FMA.  The backward's per-point reductions go the other way through the same
+// slots: each gather lane leaves its two partial dot products (v_dot2c_f32_bf16 on the packed operands: no unpack at all) in
+// the slot it just consumed, and the level's owner lane adds the 4 partials of a point and forms d(offsets) / d(logits) for
+// its level -- 8 + 4 contiguous bf16 per lane -- instead of three 4-lane shuffle reductions per point on every lane.
+// What is left is the L1 path: 32 gather instructions of 1 KB per wave, each touching 16 half-used 128-byte lines.
+// (Tried: preparing level by level with 2.3 KB of records per wave and 7-8 waves per SIMD instead of 4 -- slower, 208 / 296 us
+// against 178 / 247: eight narrow loads per lane instead of three, four serialized prepare -> LDS -> gather chains.)
+constexpr int SH_PLANE = 16 * 16 * 16 + 128;     // bytes per x-corner plane of a wave: [point 16][head 16] x 16 B (+ pad: the two
+                                                 // planes sit on opposite bank halves)
+constexpr int SH_WAVE = 2 * SH_PLANE;
+constexpr int SH_WAVES = 4;                       // waves (= query rows) per workgroup
+
+struct ShGeo {                                    // what the owner lane keeps for the backward (its level's 4 points)
+    float aw[4], fx[4], fy[4];
+    uint32_t valid[4];                            // bit0 vx0, bit1 vx1, bit2 vy0, bit3 vy1
+};
+
+__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)); }
+__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)); }
+
+// sum over 8 channels of a[ch] * b[ch], both operands packed bf16 pairs
+__device__ __forceinline__ float dot8_packed(const u32x4_t& a, const u32x4_t& b) {
+    float d = 0.f;
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(a[0]), "v"(b[0]));
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(a[1]), "v"(b[1]));
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(a[2]), "v"(b[2]));
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(a[3]), "v"(b[3]));
+    return d;
+}
+
+// LDS traffic between lanes of ONE wave needs no s_barrier (the LDS ops of a wave execute in order); this only stops the
+// compiler from moving accesses across
+__device__ __forceinline__ void sh_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// phase A: lane (head m, level o) -> records of its 4 points; returns what the backward needs.  `row` is wave-uniform.
+template <bool KEEP>
+__device__ __forceinline__ void sh_prepare(const MsdaP& p, int row, int n, int q, int lane, char* wlds, ShGeo& gk) {
+    const int m = lane >> 2, o = lane & 3;
+    const bf16_t* qrow = reinterpret_cast<const bf16_t*>(p.q1) + (int64_t)row * p.ldq;
+    float lg[4], off[8];
+    vec<bf16_t, 4>::ld(qrow + p.logit_col + m * 16 + o * 4, lg);
+    vec<bf16_t, 8>::ld(qrow + (m * 4 + o) * 8, off);
+    const float2 rf = *reinterpret_cast<const float2*>(p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * 4 + o) * 2);
+    // softmax over the 16 logits of (query, head): 4 per lane, quad reductions
+    float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    mx = fmaxf(mx, quad_xor1(mx)); mx = fmaxf(mx, quad_xor2(mx));
+    float e[4], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e[i] = __expf(lg[i] - mx); sum += e[i]; }
+    sum += quad_xor1(sum); sum += quad_xor2(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum);                  // 1 ulp
+    int Wl = p.W[0], Hl = p.H[0], Sl = p.start[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (o == k) { Wl = p.W[k]; Hl = p.H[k]; Sl = p.start[k]; }
+    const float rx = rf.x * (float)Wl - 0.5f, ry = rf.y * (float)Hl - 0.5f;
+    const uint32_t pix_bytes = (uint32_t)p.vs_s * 2u;
+    const uint32_t base = (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m) * 2) + (uint32_t)Sl * pix_bytes;
+    char* rec = wlds + (o * 4) * 256 + m * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float aw = e[i] * inv;
+        const float px = off[2 * i] + rx, py = off[2 * i + 1] + ry;
+        const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
+        const int x0 = (int)x0f, y0 = (int)y0f;                                   // v_cvt saturates; every use is a range test or a clamp
+        const int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);
+        const bool vx0 = (unsigned)x0 < (unsigned)Wl, vx1 = (unsigned)x1 < (unsigned)Wl;
+        const bool vy0 = (unsigned)y0 < (unsigned)Hl, vy1 = (unsigned)y1 < (unsigned)Hl;
+        const uint32_t r0 = mad24(clamp0(y0, Hl - 1), Wl, 0u), r1 = mad24(clamp0(y1, Hl - 1), Wl, 0u);
+        const uint32_t c0 = (uint32_t)clamp0(x0, Wl - 1), c1 = (uint32_t)clamp0(x1, Wl - 1);
+        const float wy0 = vy0 ? (1.f - fy) * aw : 0.f, wy1 = vy1 ? fy * aw : 0.f;
+        const float wx0 = vx0 ? 1.f - fx : 0.f, wx1 = vx1 ? fx : 0.f;
+        uint4 a, b;
+        a.x = mad24(r0 + c0, pix_bytes, base); a.y = mad24(r1 + c0, pix_bytes, base);
+        a.z = __float_as_uint(wy0 * wx0);      a.w = __float_as_uint(wy1 * wx0);
+        b.x = mad24(r0 + c1, pix_bytes, base); b.y = mad24(r1 + c1, pix_bytes, base);
+        b.z = __float_as_uint(wy0 * wx1);      b.w = __float_as_uint(wy1 * wx1);
+        *reinterpret_cast<uint4*>(rec + i * 256) = a;
+        *reinterpret_cast<uint4*>(rec + i * 256 + SH_PLANE) = b;
+        if constexpr (KEEP) {
+            gk.aw[i] = aw; gk.fx[i] = fx; gk.fy[i] = fy;
+            gk.valid[i] = (vx0 ? 1u : 0u) | (vx1 ? 2u : 0u) | (vy0 ? 4u : 0u) | (vy1 ? 8u : 0u);
+        }
+    }
+    sh_wave_sync();              // the records are read by other lanes of THIS wave only
+}
+
+__global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const MsdaP p) {
+    __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rows = (int64_t)p.N * p.Lq;
+    const int64_t row64 = xcd_contiguous_block(blockIdx.x, gridDim.x) * SH_WAVES + wave;
+    if (row64 >= rows) return;                                      // wave-uniform
+    const int row = __builtin_amdgcn_readfirstlane((int)row64);
+    const int n = row / p.Lq, q = row - n * p.Lq;
+    char* wlds = lds + wave * SH_WAVE;
+    ShGeo unused;
+    sh_prepare<false>(p, row, n, q, lane, wlds, unused);
+    // gather lanes: [head m][x corner xc][channel half]
+    const int m = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
+    const char* rd = wlds + xc * SH_PLANE + m * 16;
+    const uint32_t lane_off = (uint32_t)dsub * 16u;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        uint4 r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(rd + (l * 4 + i) * 256);
+        Raw8<bf16_t> v0[4], v1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float w0 = __uint_as_float(r[i].z), w1 = __uint_as_float(r[i].w);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[i].f(ch), acc[ch]);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) acc[ch] += quad_xor2(acc[ch]);   // the two x corners
+    if (xc) return;
+    bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (int64_t)row * 256 + m * 16 + dsub * 8;
+    vec<bf16_t, 8>::st(op, acc);
+}
+
+__global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const MsdaP p) {
+    __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rows = (int64_t)p.N * p.Lq;
+    const int64_t row64 = xcd_contiguous_block(blockIdx.x, gridDim.x) * SH_WAVES + wave;
+    if (row64 >= rows) return;
+    const int row = __builtin_amdgcn_readfirstlane((int)row64);
+    const int n = row / p.Lq, q = row - n * p.Lq;
+    char* wlds = lds + wave * SH_WAVE;
+    ShGeo gk;
+    sh_prepare<true>(p, row, n, q, lane, wlds, gk);
+    const int m = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
+    char* slot = wlds + xc * SH_PLANE + m * 16;
+    const uint32_t lane_off = (uint32_t)dsub * 16u;
+    // grad_out stays packed: <grad_out, value> over a lane's 8 channels is 4 v_dot2c_f32_bf16 (exact bf16 products, fp32 sum)
+    const u32x4_t g = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.grad_out) + (int64_t)row * 256 + m * 16 + dsub * 8);
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        uint2 r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint2*>(slot + (l * 4 + i) * 256);
+        Raw8<bf16_t> v0[4], v1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)     // this lane's partial <grad_out, value> of the upper / lower corner, into its half of the slot it consumed
+            *reinterpret_cast<float2*>(slot + (l * 4 + i) * 256 + dsub * 8) = make_float2(dot8_packed(g, v0[i].v), dot8_packed(g, v1[i].v));
+    }
+    sh_wave_sync();
+    // owner lane (head m, level o): d(offsets) and d(attention) of its 4 points
+    const int o = lane & 3;
+    const char* own = wlds + (o * 4) * 256 + m * 16;
+    float dxy[8], da[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(own + i * 256);                 // x corner 0: (d0, d1) of the two channel halves
+        const float4 b = *reinterpret_cast<const float4*>(own + i * 256 + SH_PLANE);      // x corner 1
+        const uint32_t v = gk.valid[i];
+        const float D00 = ((v & 5u) == 5u) ? a.x + a.z : 0.f, D10 = ((v & 9u) == 9u) ? a.y + a.w : 0.f;
+        const float D01 = ((v & 6u) == 6u) ? b.x + b.z : 0.f, D11 = ((v & 10u) == 10u) ? b.y + b.w : 0.f;
+        const float fx = gk.fx[i], fy = gk.fy[i], aw = gk.aw[i];
+        const float e0 = D10 - D00, e1 = D11 - D01;
+        const float T0 = fmaf(fy, e0, D00), T1 = fmaf(fy, e1, D01);
+        da[i] = fmaf(fx, T1 - T0, T0);                                // (1-fx) T0 + fx T1
+        dxy[2 * i] = aw * (T1 - T0);                                  // d/d(offset) = (dpx, dpy): the W,H factors cancel
+        dxy[2 * i + 1] = aw * fmaf(fx, e1 - e0, e0);                  // aw ((1-fx) e0 + fx e1)
+        dot = fmaf(aw, da[i], dot);
+    }
+    dot += quad_xor1(dot); dot += quad_xor2(dot);                     // softmax Jacobian over the 16 points of (query, head)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) da[i] = gk.aw[i] * (da[i] - dot);
+    bf16_t* grow = reinterpret_cast<bf16_t*>(p.g1) + (int64_t)row * p.ldq;
+    vec<bf16_t, 8>::st(grow + (m * 4 + o) * 8, dxy);
+    vec<bf16_t, 4>::st(grow + p.logit_col + m * 16 + o * 4, da);
+}
+
 // d(value): pure scatter, no value loads.  One lane per channel: the D lanes of a (query, head) add D consecutive
 // floats, so every atomic wave-instruction covers whole contiguous 4*D-byte segments (coalesced into a few L2 atomic
 // requests) instead of 64 scattered dwords.  The softmax / corner arithmetic is recomputed per lane (it is tiny).
@@ -1020,6 +1217,21 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     if (BWD && !(p.parts & 1)) return;
     if constexpr (FUSED) {
         if (launch_win<TV, TQ, L, BWD>(p, P, st)) return;
+    }
+    if constexpr (FUSED && L == 4 && sizeof(TV) == 2 && sizeof(TQ) == 2) {
+        // the encoder's shape: shared-geometry gathers (POET_MSDA_NO_SHARED=1: the general kernels below)
+        const char* ns_ = getenv("POET_MSDA_NO_SHARED");
+        const bool no_shared = ns_ && atoi(ns_);
+        const int64_t rows = (int64_t)p.N * p.Lq;
+        if (!no_shared && P == 4 && p.M == 16 && p.D == 16 && rows < (1ll << 31) && (p.ldq % 8) == 0 && (p.logit_col % 4) == 0 &&
+            (p.ref_bs % 2) == 0) {
+            const dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES)), blk(SH_WAVES * 64);
+            const char* pad_ = getenv("POET_SH_PADLDS");          // experiment: extra LDS per workgroup (lowers the occupancy)
+            const size_t dyn = pad_ ? (size_t)atoi(pad_) : 0;
+            if (BWD) hipLaunchKernelGGL(msda_bwd_shared_kernel, grid, blk, dyn, st, p);
+            else hipLaunchKernelGGL(msda_fwd_shared_kernel, grid, blk, dyn, st, p);
+            return;
+        }
     }
     if (P == 4) {
         if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);

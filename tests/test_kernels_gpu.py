@@ -607,6 +607,18 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     dqw = goa_w.double().cpu()
     assert ((dqw[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs() * (~kink)).max().item() / doa_ref[..., : 2 * mlp].abs().max().item() < 8e-3
     assert (dqw[..., 2 * mlp:] - doa_ref[..., 2 * mlp:]).abs().max().item() / doa_ref[..., 2 * mlp:].abs().max().item() < 8e-3
+    # the general gather kernels (every lane of a (query, head) computes the sample geometry itself), same problem: the default
+    # at this shape are the shared-geometry kernels (one lane per level prepares the points, LDS records)
+    monkeypatch.setenv("POET_MSDA_NO_SHARED", "1")
+    out_g, goa_g = torch.empty_like(out), torch.empty_like(dev(oa))
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_g, n, m, d, p, S, grid_queries=True)
+    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), torch.zeros(n, m, S, d, device="cuda"), goa_g,
+                       n, m, d, p, S, grid_queries=True, parts=1)
+    monkeypatch.delenv("POET_MSDA_NO_SHARED")
+    assert (out_g.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item() < 6e-3
+    dqg = goa_g.double().cpu()
+    assert ((dqg[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs() * (~kink)).max().item() / doa_ref[..., : 2 * mlp].abs().max().item() < 8e-3
+    assert (dqg[..., 2 * mlp:] - doa_ref[..., 2 * mlp:]).abs().max().item() / doa_ref[..., 2 * mlp:].abs().max().item() < 8e-3
     gv = torch.zeros(n, m, S, d, device="cuda")
     goa = torch.empty_like(dev(oa))
     ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv, goa, n, m, d, p, S, grid_queries=True)

@@ -535,14 +535,16 @@ def test_frozen_backbone_padded_images_full_size(gpu, precision, tol):
     omodel.rotation_head[-1].register_forward_hook(lambda m, i, o: cap.__setitem__("r6", o.detach()))
     with torch.no_grad():
         oout, onb = omodel(osamples, targets)
-    # conditioning of the reference's 6D -> R map per query, as in _rotation_amplification (a random backbone over noise
-    # images leaves one or two of the 40 queries above 8x)
+    # conditioning of the reference's 6D -> R map per query, as in _rotation_amplification.  A random backbone over noise
+    # images puts several of the 40 queries between 3x and 13x, and the rotation error follows the amplification query by
+    # query (7.5x on a 1.7e-3 error of the 6D vector -- the translation error of the same run -- is 1.3e-2): the allowance
+    # starts at AMP0_AUX here, not at the AMP0 of the goldens' conditioned heads
     cls = oout["pred_classes"].clamp(min=0).view(-1)
     r6 = cap["r6"].reshape(-1, omodel.n_classes, 6)[torch.arange(cls.numel()), cls]
     a1, a2 = r6[:, :3], r6[:, 3:]
     x = a1 / a1.norm(dim=1, keepdim=True)
     amp = 1.0 / torch.minimum(a1.norm(dim=1), (a2 - (a2 * x).sum(1, keepdim=True) * x).norm(dim=1))
-    allow = torch.clamp(amp / AMP0, min=1.0).view(len(images), -1, 1, 1)
+    allow = torch.clamp(amp / AMP0_AUX, min=1.0).view(len(images), -1, 1, 1)
     vr = otr.valid_ratio(osamples.mask)
     assert float(vr[1].max()) < 0.9                                    # the masks really are non-trivial
     # product (GPU)
@@ -562,7 +564,7 @@ def test_frozen_backbone_padded_images_full_size(gpu, precision, tol):
     dt = (out["pred_translation"].cpu() - oout["pred_translation"]).abs().max().item()
     eR = (out["pred_rotation"].cpu() - oout["pred_rotation"]).abs()
     dR, over = eR.max().item(), (eR / allow).max().item()
-    well = eR[(amp.view(len(images), -1) <= AMP0)].max().item()
+    well = eR[(amp.view(len(images), -1) <= AMP0_AUX)].max().item()
     print(f"frozen backbone, padded batch, {precision}: max|dt| {dt:.2e} max|dR| {dR:.2e} (well-conditioned queries {well:.2e}; "
           f"amplification max {amp.max():.1f}, worst error / allowance {over / tol:.2f})")
     assert dt < tol and over < tol, (dt, dR, over)
