@@ -93,11 +93,11 @@ def gemm_flops_per_image(cfg):
 # config): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when
 # the family is not in the summary.
 # profile tag (poet_amd/ops.py) -> substring of the kernel symbols in the summaries
-_PMC_NAMES = {"msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_kernel<", "msda_fused_fwd": "msda_fwd_kernel",
+_PMC_NAMES = {"msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_shared_kernel|msda_bwd_kernel<bf16, bf16", "msda_fused_fwd": "msda_fwd_shared_kernel|msda_fwd_kernel<bf16, bf16",
               "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws", "gemm_stream_fwd": "gemm_ws",
               "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
               "gemm_small_fwd": "gemm_small_kernel<false", "gemm_small_dX": "gemm_small_kernel<true", "gemm_small_dW": "gemm_small_dw_kernel",
-              "ln_fwd": "ln_fwd_kernel<", "ln_bwd": "ln_bwd_kernel<"}
+              "ln_fwd": "ln_fwd_kernel<float, float, bf16>|ln_fwd_kernel<bf16", "ln_bwd": "ln_bwd_kernel<bf16"}
 _PMC_FILTER = {"gemm_stream_dX": ", true,", "gemm_stream_fwd": ", false,"}     # ws kernels: W stored [K][N] (dX) or not
 
 
@@ -111,17 +111,32 @@ def _pmc_rows(config, kind):
     return os.path.basename(paths[-1]), rows
 
 
+def _pmc_key(tag):
+    """profile tag -> kernel-symbol substring (GEMM tags carry a _<N>x<K> shape suffix: longest prefix wins)"""
+    best = None
+    if tag.endswith("_small"):
+        return None
+    for k in _PMC_NAMES:
+        if tag.startswith(k) and (best is None or len(k) > len(best)):
+            best = k
+    return best
+
+
 def pmc_traffic_bytes(tag, config="ycbv"):
+    tag = _pmc_key(tag)
     key = _PMC_NAMES.get(tag)
     _, rows = _pmc_rows(config, "hbm")
     if key is None or len(rows) < 2:
         return None
     flt = _PMC_FILTER.get(tag, "")
     tot = n = 0.0
-    for r in rows[1:]:                                  # launch-weighted mean over the symbols of the family
-        if key in r[0] and flt in r[0]:
-            tot += float(r[1]) * (2 * float(r[2]) + float(r[4])) * 1024
-            n += float(r[1])
+    for alt in key.split("|"):                          # first alternative present in the summary; launch-weighted mean over
+        for r in rows[1:]:                              # its symbols
+            if alt in r[0] and flt in r[0]:
+                tot += float(r[1]) * (2 * float(r[2]) + float(r[4])) * 1024
+                n += float(r[1])
+        if n:
+            break
     return int(tot / n) if n else None
 
 

@@ -244,7 +244,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
         for extra in (add_src, gate_ref):                     # epilogue operands the kernel also streams
             if extra is not None:
                 nb += batch * M * N * _esz(extra)
-        PROFILE.end(f"gemm_{path}_{role}", e0, 2.0 * M * N * K * batch, nb)
+        # one tag per kernel family, role AND shape: "the dominant kernel" of the roofline line is one kernel on one shape,
+        # not 26 launches of five different GEMMs that happen to share a symbol
+        shape = f"_{N}x{K}" if M >= 4096 else ""
+        PROFILE.end(f"gemm_{path}_{role}{shape}", e0, 2.0 * M * N * K * batch, nb)
         return Cout
     _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
     return Cout
@@ -385,7 +388,7 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
         e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2)
         PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype == torch.bfloat16) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * 4)
         e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1)
-        PROFILE.end("msda_bwd_dq", e0, 0.0, nb_q)
+        PROFILE.end("msda_bwd_dq" + ("_small" if N * Lq < 4096 else ""), e0, 0.0, nb_q)
         return
     _lib.check(lib.poet_msda_fused_bwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
                                        offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, grad_out.data_ptr(),
@@ -605,7 +608,10 @@ def _instrument(name, tag):
         e0 = PROFILE.begin()
         r = fn(*a, **k)
         nb = sum(t.numel() * t.element_size() for t in list(a) + list(k.values()) if torch.is_tensor(t))
-        PROFILE.end(tag, e0, 0.0, nb)
+        # the 320-row decoder launches of a kernel are a different regime (launch latency) from its 102k-row encoder launches:
+        # separate families, so that an average launch time means something
+        small = (a[9] * a[13] < 4096) if name == "msda_fused_fwd" else nb < (1 << 22)
+        PROFILE.end(tag + ("_small" if small else ""), e0, 0.0, nb)
         return r
 
     wrapped.__name__ = name
