@@ -379,7 +379,7 @@ def main():
                                    f"bs={batch} per GPU, dropout {cfg['dropout']}, AdamW + clip 0.1, random init",
                        "global_batch": world * batch, "tokens_per_image": sum(h * w for h, w in cfg["level_hw"]),
                        "parallelism": f"dp{world}", "precision_policy": args.precision,
-                       "launch": "eager" if args.no_graphs else "hipGraph replay (fwd graph, bwd+opt graph)",
+                       "launch": "eager" if args.no_graphs else ("hipGraph replay (fwd + matcher + loss graph, bwd + clip + AdamW graph)" if getattr(trainer, "graph_loss", False) else "hipGraph replay (fwd graph, eager loss, bwd+opt graph)"),
                        "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
                        "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4),
                        "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 3)},

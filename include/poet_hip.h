@@ -294,10 +294,13 @@ int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* 
  * 'rotation' terms of SetCriterion): trans (L, NQ, 3), rot (L, NQ, 3, 3) fp32 predictions; the n_obj matched pairs are
  * (query_idx[i] in [0, NQ) = image*Q + query, tgt_trans[i] (3), tgt_rot[i] (3,3)).  losses (L, 2) =
  * [mean ||t - t_gt||_2, mean acos(clamp((tr(R R_gt^T) - 1)/2, -1+1e-6, 1-1e-6))]; grad_trans / grad_rot (same shapes as
- * the predictions, fully written) = d losses[l][0] / d trans[l] and d losses[l][1] / d rot[l]. */
+ * the predictions, fully written) = d losses[l][0] / d trans[l] and d losses[l][1] / d rot[l].
+ * n_obj_dev (optional, device int32): the pair count is read from device memory instead of n_obj -- the count
+ * poet_match_gather leaves behind, so that matcher + loss can sit inside a captured HIP graph (the match arrays then
+ * have capacity NQ). */
 int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_idx, const float* tgt_trans,
                    const float* tgt_rot, int n_obj, int L, int NQ, float* losses, float* grad_trans, float* grad_rot,
-                   void* stream);
+                   const int32_t* n_obj_dev, void* stream);
 
 /* Batched on-device assignment, models/matcher.py:158-229 in 'gt' mode: per image the L1 cost between the first n_pred[i]
  * query boxes (pred_boxes (N,Q,4) fp32) and the image's targets (tgt_boxes rows [tgt_off[i], tgt_off[i+1]), fp32 (T,4)),

@@ -313,8 +313,10 @@ __global__ __launch_bounds__(256) void pose_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict__ trans, const float* __restrict__ rot,
                                                         const int64_t* __restrict__ qi, const float* __restrict__ tt,
                                                         const float* __restrict__ tr, int n_obj, int NQ,
-                                                        float* __restrict__ losses, float* __restrict__ gt, float* __restrict__ gr) {
+                                                        float* __restrict__ losses, float* __restrict__ gt, float* __restrict__ gr,
+                                                        const int32_t* __restrict__ n_obj_dev) {
     const int l = blockIdx.x, tid = threadIdx.x;
+    if (n_obj_dev) n_obj = min(max(*n_obj_dev, 0), NQ);
     const float* T = trans + (int64_t)l * NQ * 3;
     const float* Rm = rot + (int64_t)l * NQ * 9;
     float* GT = gt + (int64_t)l * NQ * 3;
@@ -766,11 +768,11 @@ extern "C" int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, co
 
 extern "C" int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_idx, const float* tgt_trans,
                               const float* tgt_rot, int n_obj, int L, int NQ, float* losses, float* grad_trans, float* grad_rot,
-                              void* stream) {
+                              const int32_t* n_obj_dev, void* stream) {
     POET_CHECK(trans && rot && losses && grad_trans && grad_rot && L > 0 && NQ > 0 && n_obj >= 0, POET_ERR_ARG, "pose_loss: bad args");
-    POET_CHECK(n_obj == 0 || (query_idx && tgt_trans && tgt_rot), POET_ERR_ARG, "pose_loss: null match arrays");
+    POET_CHECK((n_obj == 0 && !n_obj_dev) || (query_idx && tgt_trans && tgt_rot), POET_ERR_ARG, "pose_loss: null match arrays");
     hipLaunchKernelGGL(pose_loss_kernel, dim3(L), dim3(256), 0, ST, trans, rot, query_idx, tgt_trans, tgt_rot, n_obj, NQ, losses,
-                       grad_trans, grad_rot);
+                       grad_trans, grad_rot, n_obj_dev);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -701,6 +701,17 @@ def segment_tags(arena: ParamArena):
     return [b[0] for b in arena.buckets]
 
 
+def _vec_dict(vec):
+    """LossDict over the rows of a stacked (L, 2) loss tensor (last row = the model output, rows 0..L-2 the auxiliary layers)."""
+    L = vec.shape[0]
+    d = LossDict({"loss_trans": vec[L - 1, 0], "loss_rot": vec[L - 1, 1]})
+    for i in range(L - 1):
+        d[f"loss_trans_{i}"] = vec[i, 0]
+        d[f"loss_rot_{i}"] = vec[i, 1]
+    d.vec = vec
+    return d
+
+
 class _Replay(torch.autograd.Function):
     """Autograd shim around the two captured graphs: forward replays the model-forward graph and hands out its static
     outputs; backward copies the loss gradients into the static grad buffers and replays backward (+ optimiser)."""
@@ -716,6 +727,11 @@ class _Replay(torch.autograd.Function):
         t = ctx.trainer
         t.s_drot.copy_(drot)
         t.s_dtrans.copy_(dtrans)
+        _Replay.replay_backward(t)
+        return None, None
+
+    @staticmethod
+    def replay_backward(t):
         if t.segs is None:
             t.g_bwd.replay()                 # backward + clip + AdamW in one graph (single GPU)
             return None, None
@@ -766,6 +782,45 @@ class GraphedTrainer(Trainer):
         boxes, classes, valid, n_boxes = m.host_queries(targets)
         return features, boxes, classes, valid, n_boxes
 
+    def _stage_targets(self, targets, queries=False):
+        """Compacted target boxes / translations / rotations and the per-image offsets + query counts into the static
+        buffers the captured matcher reads (device-resident targets: device-side cat + copy; host targets: H2D).
+        queries=True (targets on the device): the padded query boxes / classes / valid flags of PoET.host_queries are
+        scattered into their static buffers on the device as well -- the host reads shapes only, never tensor contents, so it
+        does not wait for the GPU and can run ahead of it."""
+        N, Q = self.s_boxes.shape[:2]
+        counts = [int(t["boxes"].shape[0]) for t in targets]
+        n = sum(counts)
+        if len(counts) != N or n > self.s_tb.shape[0] or max(counts, default=0) > Q:
+            raise ValueError(f"GraphedTrainer: {n} targets in {len(counts)} images (max {max(counts, default=0)}) exceed the captured "
+                             f"capacity ({N} images x {Q} queries; the reference assumes n <= num_queries in gt mode)")
+        meta = np.zeros(2 * N + 1 + (n if queries else 0), np.int64)
+        meta[1:N + 1] = np.cumsum(counts)
+        meta[N + 1:2 * N + 1] = np.asarray(counts, np.int64)            # gt mode: one query per target box
+        if queries and n:
+            meta[2 * N + 1:] = np.concatenate([i * Q + np.arange(c, dtype=np.int64) for i, c in enumerate(counts)])
+        if not hasattr(self, "_meta_ring"):
+            self._meta_ring = _PinnedRing()
+        meta_d = self._meta_ring.stage(meta, self.s_meta.device)
+        self.s_meta.copy_(meta_d[: 2 * N + 1], non_blocking=True)
+        dev = self.s_tb.device
+        tb = None
+        if n:
+            tb = torch.cat([t["boxes"].reshape(-1, 4) for t in targets], 0).to(dev, non_blocking=True).float()
+            self.s_tb[:n].copy_(tb, non_blocking=True)
+            self.s_tpos[:n].copy_(torch.cat([t["relative_position"] for t in targets], 0).to(dev, non_blocking=True), non_blocking=True)
+            self.s_trot[:n].copy_(torch.cat([t["relative_rotation"] for t in targets], 0).to(dev, non_blocking=True), non_blocking=True)
+        if queries:
+            self.s_boxes.fill_(-1.0)
+            self.s_cls.fill_(-1)
+            self.s_valid.zero_()
+            if n:
+                idx = meta_d[2 * N + 1:]
+                self.s_boxes.view(-1, 4).index_copy_(0, idx, tb)
+                self.s_cls.view(-1).index_copy_(0, idx, torch.cat([t["labels"].reshape(-1) for t in targets], 0).to(dev, non_blocking=True).to(self.s_cls.dtype))
+                self.s_valid.view(-1).index_fill_(0, idx, 1)
+        return counts
+
     def _capture(self, samples, targets):
         m, dev = self.model, self.arena.flat.device
         features, boxes, classes, valid, _ = self._static_inputs(samples, targets)
@@ -789,13 +844,50 @@ class GraphedTrainer(Trainer):
         ops.SEED_DEV[0] = self.seed_word
         set_reducer(None)
         torch.cuda.synchronize()
+        # 'gt' mode with the on-device matcher and the default loss pair: assignment + loss + their gradients are part of the
+        # forward graph (no eager launches between the two replays: that stretch was 0.45 ms of the step, two thirds of it
+        # idle GPU waiting for the host).  Targets travel compacted in static buffers of capacity N*Q.
+        crit = self.criterion
+        self.graph_loss = bool(getattr(crit, "default_terms", False) and getattr(getattr(crit, "matcher", None), "device_assign", False)
+                               and getattr(m, "bbox_mode", "gt") == "gt" and hasattr(crit, "total") and getattr(m, "aux_loss", True)
+                               and os.environ.get("POET_EAGER_LOSS", "0") in ("", "0"))
+        if self.graph_loss:
+            N, Q = self.s_boxes.shape[:2]
+            cap = N * Q
+            z = lambda *sh, dt=torch.float32: torch.zeros(sh, dtype=dt, device=dev)
+            self.s_tb, self.s_tpos, self.s_trot = z(cap, 4), z(cap, 3), z(cap, 3, 3)
+            self.s_meta = z(2 * N + 1, dt=torch.int32)
+            self.s_col, self.s_qi = z(N, Q, dt=torch.int32), z(cap, dt=torch.int64)
+            self.s_tt, self.s_tr, self.s_nobj = z(cap, 3), z(cap, 3, 3), z(1, dt=torch.int32)
+            if not hasattr(crit, "_lsa_status") or crit._lsa_status.device != dev:
+                crit._lsa_status = torch.zeros(1, dtype=torch.int32, device=dev)
+            n_dec = len(m.transformer.decoder.layers)
+            crit.total(_vec_dict(torch.zeros((n_dec, 2), device=dev)))      # builds crit._w, the (L, 2) weight table, outside the capture
+            self._stage_targets(targets)
         self.g_fwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fwd, **_CAPTURE):
             with ops.pinned_stream():
                 ops.counter_add(self.seed_word, 1)
                 rot, trans, hs = m.forward_core(self.s_feats, self.s_fmasks, self.s_imask, self.s_boxes, self.s_valid, self.s_cls)
+                if self.graph_loss:
+                    N = self.s_boxes.shape[0]
+                    L = trans.shape[0]
+                    ops.lsa_boxes(self.s_boxes, self.s_tb, self.s_meta[: N + 1], self.s_meta[N + 1:], self.s_col, crit._lsa_status,
+                                  crit.matcher.cost_bbox)
+                    ops.match_gather(self.s_col, self.s_meta[: N + 1], self.s_tpos, self.s_trot, self.s_qi, self.s_tt, self.s_tr,
+                                     n_out=self.s_nobj)
+                    self.s_lossvec = torch.empty((L, 2), dtype=torch.float32, device=dev)
+                    gt_, gr_ = torch.empty_like(trans), torch.empty_like(rot)
+                    ops.pose_loss(trans.detach(), rot.detach(), self.s_qi, self.s_tt, self.s_tr, 0, self.s_lossvec, gt_, gr_,
+                                  n_obj_dev=self.s_nobj)
+                    w = crit._w
+                    assert w.shape[0] == L, (w.shape, L)
+                    self.s_total = (self.s_lossvec * w).sum()
+                    self.s_dtrans = gt_ * w[:, 0].reshape(L, *([1] * (gt_.dim() - 1)))
+                    self.s_drot = gr_ * w[:, 1].reshape(L, *([1] * (gr_.dim() - 1)))
         self.s_rot, self.s_trans = rot, trans
-        self.s_drot, self.s_dtrans = torch.zeros_like(rot), torch.zeros_like(trans)
+        if not self.graph_loss:
+            self.s_drot, self.s_dtrans = torch.zeros_like(rot), torch.zeros_like(trans)
         self.segs = None
         if self.segment_backward:
             # Backward captured as one graph per autograd node (= one gradient bucket each: heads, decoder, every encoder layer,
@@ -856,13 +948,22 @@ class GraphedTrainer(Trainer):
                 return super().step(samples, targets)        # eager warm-up (also fills every lazy cache)
             self._capture(samples, targets)
         m = self.model
-        features, boxes, classes, valid, n_boxes = self._static_inputs(samples, targets)
+        on_device = self.graph_loss and all(t["boxes"].is_cuda and t["labels"].is_cuda for t in targets)
+        if on_device:
+            features = m.backbone(samples)[0]
+        else:
+            features, boxes, classes, valid, n_boxes = self._static_inputs(samples, targets)
         for f, sf, sm in zip(features, self.s_feats, self.s_fmasks):
             if f.tensors.data_ptr() != sf.data_ptr():
                 sf.copy_(f.tensors, non_blocking=True)
             sm.copy_(f.mask.view(torch.uint8) if f.mask.dtype == torch.bool else f.mask, non_blocking=True)
         im = samples.mask                                   # the extra levels' masks / valid ratios / sine encodings derive from it
         self.s_imask.copy_(im.view(torch.uint8) if im.dtype == torch.bool else im, non_blocking=True)
+        if on_device:
+            self._stage_targets(targets, queries=True)
+            self.g_fwd.replay()
+            _Replay.replay_backward(self)
+            return self.s_total.clone(), _vec_dict(self.s_lossvec.clone())      # (the static buffers are overwritten by the next replay)
         slot = self.ring[self.ring_pos]
         self.ring_pos = (self.ring_pos + 1) % len(self.ring)
         if slot["ev"] is not None:
@@ -873,6 +974,12 @@ class GraphedTrainer(Trainer):
         self.s_valid.copy_(slot["valid"], non_blocking=True)
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
+        if self.graph_loss:
+            self._stage_targets(targets)
+            self.g_fwd.replay()
+            _Replay.replay_backward(self)
+            vec = self.s_lossvec.clone()                         # the static buffers are overwritten by the next replay
+            return self.s_total.clone(), _vec_dict(vec)
         rot, trans = _Replay.apply(self, self.handle)
         out = m.make_outputs(rot, trans, self.s_boxes, self.s_cls, boxes)
         loss_dict = self.criterion(out, targets, n_boxes)

@@ -66,12 +66,15 @@ class EncoderLayerFn(torch.autograd.Function):
         if y16 is y or y16.data_ptr() == y.data_ptr():
             y16 = y.detach()
         ctx.mark_non_differentiable(y16, q_next)
+        ctx.set_materialize_grads(False)                  # else autograd zero-fills two (N*S,d) bf16 gradients per layer for y16 / q_next
         return y, y16, q_next
 
     @staticmethod
     def backward(ctx, dy, _unused=None, _unused2=None):
         cfg, geom, names, params, i = ctx.cfg, ctx.geom, ctx.names, ctx.params, ctx.idx
         N, S = cfg["N"], geom.S
+        if dy is None:
+            raise RuntimeError("EncoderLayerFn.backward: no gradient for the layer output")
         G = B.GradSink(list(names) + ["level_embed"], list(params) + [ctx.level_embed])
         g_level = G("level_embed") if ctx.level_embed.requires_grad else None
         dx = B.enc_layer_bwd(dy.contiguous(), ctx.saved, _pdict(names, params, ""), G, "", ctx.ref, S * geom.L * 2, ctx.mask, geom,

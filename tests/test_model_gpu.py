@@ -444,6 +444,50 @@ def test_graphed_trainer_matches_eager(gpu):
     assert worst < 1e-3, worst                    # same kernels in the same order (fp32 atomics make runs differ at ~1e-4 after AdamW)
 
 
+def test_graphed_trainer_captures_matcher_and_loss(gpu):
+    """With the on-device matcher ('gt' mode, default loss pair) assignment + loss + their gradients are part of the forward
+    graph: no eager launch between the replays.  Same trajectory as the eager trainer with the HOST (SciPy) matcher across
+    steps whose targets, object counts and assignments change -- and as the graphed trainer with the eager loss."""
+    import poet_amd
+    from oracle.formula import CONFIGS, make_inputs
+    cfg = CONFIGS["tiny"]
+    runs = {}
+    for mode in ("eager_host", "graph_eager_loss", "graph_loss", "graph_loss_segmented", "graph_loss_host_boxes"):
+        r = gpu("tiny", 2, True, "bf16", dropout=0.0)
+        r["model"].train()
+        crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(device_assign=(mode != "eager_host")), poet_amd.build_weight_dict(cfg["dec_layers"]))
+        if mode == "eager_host":
+            tr = poet_amd.Trainer(r["model"], crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+        else:
+            os.environ["POET_EAGER_LOSS"] = "1" if mode == "graph_eager_loss" else "0"
+            tr = poet_amd.GraphedTrainer(r["model"], crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1,
+                                         segment_backward=(mode == "graph_loss_segmented"))
+        losses, terms = [], []
+        try:
+            for step in range(6):
+                _, _, targets = make_inputs(cfg, seed=300 + step, batch=2, pad=True)
+                if step == 4:                                         # duplicate boxes: ties in the assignment
+                    targets[0]["boxes"][1] = targets[0]["boxes"][0]
+                # boxes / labels on the device: the queries are assembled there too (the host never reads tensor contents);
+                # on the host (what DataPrefetcher(keep_on_host=...) hands over): packed on the host, uploaded
+                on_host = ("boxes", "labels") if mode == "graph_loss_host_boxes" else ()
+                gt = [{k: (v if k in on_host else v.cuda()) for k, v in t.items()} for t in targets]
+                total, ld = tr.step(r["samples"], gt)
+                losses.append(float(total))
+                terms.append(sorted((k, round(float(v), 5)) for k, v in ld.items()))
+        finally:
+            os.environ.pop("POET_EAGER_LOSS", None)
+        if mode.startswith("graph"):
+            assert tr.graph_loss == (mode != "graph_eager_loss")
+            assert crit.device_match_status() == 0
+        runs[mode] = (losses, terms, {n: p.detach().float().cpu().clone() for n, p in r["model"].named_parameters()})
+    for mode in ("graph_eager_loss", "graph_loss", "graph_loss_segmented", "graph_loss_host_boxes"):
+        assert runs[mode][0] == pytest.approx(runs["eager_host"][0], rel=2e-3, abs=2e-3), (mode, runs[mode][0], runs["eager_host"][0])
+        assert [k for k, _ in runs[mode][1][0]] == [k for k, _ in runs["eager_host"][1][0]]
+        worst = max((runs[mode][2][n] - runs["eager_host"][2][n]).abs().max().item() for n in runs["eager_host"][2])
+        assert worst < 1e-3, (mode, worst)
+
+
 def test_graphed_trainer_follows_changing_padding(gpu):
     """The captured graphs read the IMAGE mask (the extra feature level's mask, valid ratios and sine encoding derive from
     it) from a static buffer: it must be refreshed on every replay.  Steps alternate between two paddings; graph == eager."""
