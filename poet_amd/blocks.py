@@ -155,7 +155,7 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
 
 
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
-def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=None):
+def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=None, y_out=None):
     """Returns (y, y16, saved): y in the residual-stream dtype; y16 = bf16 copy for the next GEMM when the stream is
     fp32 but the branch is bf16 (else y itself).  With split weights the projection hands its fp32 accumulators to the
     LayerNorm unrounded (the branch is never stored in bf16); only the pre-norm sum saved for backward is bf16."""
@@ -164,7 +164,7 @@ def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=Non
     Wt, sp = Wf(W, x_in, split)
     tmp = empty((rows, d), torch.float32 if (sp and mixed) else x_in.dtype, res)
     ops.linear_fwd(x_in, Wt, b, tmp, split=sp)
-    y = torch.empty_like(res)                        # residual-stream dtype
+    y = torch.empty_like(res) if y_out is None else y_out      # residual-stream dtype (y_out: the caller's buffer, e.g. a row of hs)
     z = empty((rows, d), x_in.dtype, res)            # branch dtype
     mean = empty((rows,), torch.float32, res)
     rstd = empty((rows,), torch.float32, res)
@@ -195,7 +195,7 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
 
 
 # ---- (d) FFN block -------------------------------------------------------------------------------
-def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False, pos_next=None):
+def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False, pos_next=None, y_out=None):
     """x: residual stream; x16: the GEMM operand copy of it (== x in the pure modes)."""
     rows = x.shape[0]
     Hd = empty((rows, W1.shape[0]), act or x.dtype, x)
@@ -204,7 +204,7 @@ def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=N
     if pos_next is not None:
         y, y16, ln_saved, q_next = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, pos_next=pos_next)
         return y, y16, (Hd, ln_saved), q_next
-    y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split)
+    y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, y_out=y_out)
     return y, y16, (Hd, ln_saved)
 
 
@@ -301,7 +301,7 @@ DEC_PARAMS = ("cross_attn.sampling_offsets.weight", "cross_attn.sampling_offsets
               "norm3.weight", "norm3.bias")
 
 
-def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training):
+def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training, y_out=None):
     """tgt,qpos (N*Q,d) fp32; V head-major value map of the encoder memory for this layer."""
     d = tgt.shape[1]
     D, rows = d // M, N * Q
@@ -325,7 +325,7 @@ def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training):
     t2, _, ln1 = proj_ln_fwd(out_m, P_["cross_attn.output_proj.weight"], P_["cross_attn.output_proj.bias"], t1,
                              P_["norm1.weight"], P_["norm1.bias"], pd, seeds[2])
     t3, _, ffn = ffn_fwd(t2, t2, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                         P_["norm3.weight"], P_["norm3.bias"], pd, pd, seeds[3], seeds[4])
+                         P_["norm3.weight"], P_["norm3.bias"], pd, pd, seeds[3], seeds[4], y_out=y_out)
     saved = dict(tgt=tgt, qk=qk, packed=packed, att=att, ln2=ln2, t1=t1, q2=q2, OA=OA, out_m=out_m, ln1=ln1, t2=t2,
                  ffn=ffn, seeds=seeds, pd=pd, V=V)
     return t3, saved

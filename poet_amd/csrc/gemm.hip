@@ -392,7 +392,8 @@ static void launch_layout(const GemmK& p, hipStream_t st) {
 // 1/16-rate f32 matrix pipe of more than a handful of CUs is used)
 static int tile_choice(const PoetGemmDesc& d) {
     const int64_t big_blocks = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * d.batch * d.splitk;
-    if (d.M >= 256 && d.N >= 128 && !(d.compute == POET_F32 && big_blocks < 128)) return 0;
+    // (fewer than 48 big tiles leave most of the 256 CUs idle: the 3x3 stride-2 conv of the extra level is 1280 x 256 x 2304)
+    if (d.M >= 256 && d.N >= 128 && !(d.compute == POET_F32 && big_blocks < 128) && !(d.compute != POET_F32 && big_blocks < 48)) return 0;
     if (d.compute == POET_F32 && (int64_t)cdiv(d.M, 64) * cdiv(d.N, 64) * d.batch * d.splitk < 256)
         return (d.splitk == 1) ? 3 : 2;       // 3: whole-K stages (K=256 fp32 in one), the latency-bound 320-row decoder GEMMs
     return 1;

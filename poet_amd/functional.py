@@ -150,8 +150,8 @@ class DecoderFn(torch.autograd.Function):
             else:
                 V = B.value_proj_fwd(mem2, P_["cross_attn.value_proj.weight"], P_["cross_attn.value_proj.bias"], mask, N, S, M, D,
                                      cfg.get("act"), cfg.get("split", False))
-            x, sv = B.dec_layer_fwd(x, qp, V, P_, ref_in, geom, N, Q, M, cfg["P"], cfg["p"], cfg["training"])
-            ops.cast(x, hs[i])
+            # the layer's last LayerNorm writes its row of hs directly (hs[i] is also the next layer's input)
+            x, sv = B.dec_layer_fwd(x, qp, V, P_, ref_in, geom, N, Q, M, cfg["P"], cfg["p"], cfg["training"], y_out=hs[i].view(N * Q, d))
             saved.append(sv)
         ctx.vstack = vs if V_all is not None else None
         ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params
