@@ -184,15 +184,25 @@ __global__ __launch_bounds__(256) void pos_sine_kernel(const uint8_t* __restrict
         ex[x] = ((float)cx - 0.5f) / ((float)tx + 1e-6f) * two_pi;
     }
     __syncthreads();
-    const int C2 = 2 * F;
-    for (int i = threadIdx.x; i < W * C2; i += 256) {
-        const int x = i / C2, c = i - x * C2;
-        const int cc = (c < F) ? c : c - F;
-        const float e = (c < F) ? ey[x] : ex[x];
-        const float arg = e / dim_t[cc];
-        float v = (cc & 1) ? cosf(arg) : sinf(arg);
-        if (level_embed) v += level_embed[c];
-        io<T>::st(out + ((int64_t)n * tok_stride + tok_off + (int64_t)y * W + x) * C2 + c, v);
+    // one thread per (sin, cos) PAIR: channels 2k and 2k+1 share dim_t (position_encoding.py:52-57), so the angle, its
+    // division and its range reduction are done once.  Normalised positions are <= 2 pi: the hardware sine / cosine
+    // (v_sin_f32 on revolutions, abs error ~1e-6) serves them; the huge arguments of fully masked rows / columns
+    // ((c - 0.5) / 1e-6) keep the exact full-range path, where 1 ulp of the argument decides the value.
+    const int C2 = 2 * F, HP = F / 2;                          // pairs per half (y features | x features)
+    for (int i = threadIdx.x; i < W * F; i += 256) {
+        const int x = i / F, pr = i - x * F;                   // pair index 0 .. F-1 over both halves
+        const bool ypart = pr < HP;
+        const int k = ypart ? pr : pr - HP;                    // pair inside the half: channels 2k, 2k+1 of it
+        const float e = ypart ? ey[x] : ex[x];
+        const float arg = e / dim_t[2 * k];
+        float sv, cv;
+        if (fabsf(arg) <= 8.f) { sv = __sinf(arg); cv = __cosf(arg); }
+        else { sv = sinf(arg); cv = cosf(arg); }
+        const int c = (ypart ? 0 : F) + 2 * k;
+        if (level_embed) { sv += level_embed[c]; cv += level_embed[c + 1]; }
+        T* o = out + ((int64_t)n * tok_stride + tok_off + (int64_t)y * W + x) * C2 + c;
+        io<T>::st(o, sv);
+        io<T>::st(o + 1, cv);
     }
 }
 
