@@ -397,7 +397,7 @@ def main():
                                        "pmc": pmc_mfma_summary(args.config)}
             if out["roofline"]["kernel"].startswith("msda_bwd_dvalue_scatter"):
                 # the contract's two bounds do not name this kernel's real limiter; say so next to the HBM fraction
-                out["roofline"]["limiter"] = "the LDS atomic unit (26 M ds_add_u32 wave-instructions per launch at ~8 clk each), not HBM: DESIGN.md section 5/9"
+                out["roofline"]["limiter"] = "two on-CU pipes loaded equally, not HBM: the LDS atomic unit (26 M ds_add_u32 wave-instructions per launch at ~5.2 clk: 219 us floor) and the VALU (3 half-rate instructions per corner and lane: ~228 us): DESIGN.md section 5/9"
             out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
                                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         if world == 1 and not args.no_cpu_baseline:
