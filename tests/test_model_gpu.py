@@ -468,6 +468,8 @@ def test_graphed_trainer_captures_matcher_and_loss(gpu):
                 _, _, targets = make_inputs(cfg, seed=300 + step, batch=2, pad=True)
                 if step == 4:                                         # duplicate boxes: ties in the assignment
                     targets[0]["boxes"][1] = targets[0]["boxes"][0]
+                if step == 2:                                         # an image without objects
+                    targets[1] = {k: v[:0] for k, v in targets[1].items()}
                 # boxes / labels on the device: the queries are assembled there too (the host never reads tensor contents);
                 # on the host (what DataPrefetcher(keep_on_host=...) hands over): packed on the host, uploaded
                 on_host = ("boxes", "labels") if mode == "graph_loss_host_boxes" else ()
