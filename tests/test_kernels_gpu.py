@@ -546,7 +546,7 @@ def _explicit_from_fused(shapes, value_nsmd, oa, ref_pts, gout, m, p):
     return torch.from_numpy(out), torch.from_numpy(dv), doa, kink
 
 
-@pytest.mark.parametrize("case", ["ycbv_init_like", "ycbv_wide_offsets", "hires_tiles", "one_pixel_pileup"])
+@pytest.mark.parametrize("case", ["ycbv_init_like", "ycbv_wide_offsets", "hires_tiles", "one_pixel_pileup", "odd_small", "lmo_whole_image_windows"])
 def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     """The kernels the benchmark runs -- fused forward, d(offsets|logits), and the LDS-tiled int32 fixed-point d(value)
     scatter -- at the benchmark's geometry (M = 16 heads, D = 16, bf16 storage, grid queries, bs 2) against the float64
@@ -555,10 +555,17 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
       ycbv_wide_offsets the same with 10 % of the samples thrown 10-40 px away (out of window -> global-atomic pass, out of image)
       hires_tiles       (120,160)..(15,20) at bs 1: the 16x16-tile plan with halo-dominated windows (BASELINE configs[4])
       one_pixel_pileup  every sample of every query aims at ONE pixel per level with same-sign gradients: the worst case for
-                        the int32 windows (n_queries_in_tile x 2^18 per word; the tile plan keeps that below 2^31)."""
+                        the int32 windows (n_queries_in_tile x 2^18 per word; the tile plan keeps that below 2^31).
+      odd_small         (7,9)..(1,2) at bs 3: 273 query rows (not a multiple of the 4 rows of a shared-geometry workgroup), odd
+                        map sizes, levels of one and two pixels where most samples leave the map
+      lmo_whole_image_windows  (30,40)..(4,5): the tile planner's 1 x 1 plan (every level whole in LDS, no halo, no far pass)"""
     m, d, p = 16, 16, 4
     if case == "hires_tiles":
         shapes, n = [(120, 160), (60, 80), (30, 40), (15, 20)], 1
+    elif case == "odd_small":
+        shapes, n = [(7, 9), (4, 5), (2, 3), (1, 2)], 3
+    elif case == "lmo_whole_image_windows":
+        shapes, n = [(30, 40), (15, 20), (8, 10), (4, 5)], 2
     else:
         shapes, n = [(60, 80), (30, 40), (15, 20), (8, 10)], 2
     L = len(shapes)
