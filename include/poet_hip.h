@@ -154,7 +154,10 @@ int poet_msda_bwd(const void* value, const int64_t* spatial_shapes_host, const i
  * the upstream (N,S,M,D) and the head-major (N,M,S,D) layouts are accepted.  out (N,Lq,M*D) q_dtype.
  * Limit (all msda entry points): the gather kernels use 32-bit byte offsets and 24-bit pixel arithmetic, so a value map
  * must span < 4 GiB, S < 2^24 and vs_s * sizeof(element) < 2^24; larger calls return POET_ERR_UNSUPPORTED.
- * Backward: grad_value fp32, same strides as value, accumulated atomically (caller zero-fills);
+ * Backward: grad_value (gv_dtype: POET_F32, or POET_BF16 for the LDS-tiled scatter of grid queries only), same element
+ * strides as value, accumulated atomically (caller zero-fills).  bf16: the per-tile int32 windows are exact and leave
+ * through packed bf16x2 atomics -- half the memory-side atomics, half the zero-fill and half the read of the consumer, which
+ * rounds the value gradient to bf16 anyway; a pixel on a tile border receives up to 4 rounded partial sums.
  * grad_offattn (N,Lq,ldq) q_dtype receives d/d(offsets) and d/d(logits) (softmax backward folded). */
 int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m,
                         const int64_t* spatial_shapes_host, const int64_t* level_start_host,
@@ -169,9 +172,9 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
                         const int64_t* spatial_shapes_host, const int64_t* level_start_host,
                         const void* offattn, int64_t ldq, int logit_col,
                         const float* ref, int64_t ref_batch_stride, const void* grad_out,
-                        float* grad_value, void* grad_offattn,
+                        void* grad_value, void* grad_offattn,
                         int N, int S, int M, int D, int L, int P, int Lq,
-                        int v_dtype, int q_dtype,
+                        int v_dtype, int q_dtype, int gv_dtype,
                         int grid_queries /* 1: query q is pixel q of the flattened levels (encoder self-attention):
                                             enables the LDS-privatised value-gradient scatter */,
                         int parts /* 3 (or 0) = everything; 1 = only d(offsets|logits); 2 = only the d(value) scatter
@@ -254,10 +257,10 @@ int poet_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtyp
  * seg_start_host (nseg+1) row boundaries inside one batch item.  out fp32 (nseg, cols) accumulated. */
 int poet_colsum(const void* x, int64_t ld, float* out, int batch, int64_t rows_per_batch, int cols,
                 const int64_t* seg_start_host, int nseg, int dtype, void* stream);
-/* fp32 value-gradient maps (addressed by strides, see fused MSDA) -> (N*S, M*D) row-major `dtype`,
+/* value-gradient maps (gv_dtype fp32 or bf16; addressed by element strides, see fused MSDA) -> (N*S, M*D) row-major `dtype`,
  * rows with row_mask != 0 zeroed (masked_fill backward). */
-int poet_vgrad_to_rows(const float* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
-                       void* out, int N, int S, int M, int D, int dtype, void* stream);
+int poet_vgrad_to_rows(const void* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
+                       void* out, int N, int S, int M, int D, int gv_dtype, int dtype, void* stream);
 /* NCHW (N,C,H,W) <-> token-major rows [tok_off, tok_off+H*W) of (N, tok_stride, C). */
 int poet_nchw_to_tokens(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
                         int src_dtype, int dst_dtype, void* stream);

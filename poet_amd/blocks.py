@@ -272,7 +272,11 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
     dsrc, d_out_m = proj_ln_bwd(dx1, sv["out_m"], P_["self_attn.output_proj.weight"], P_["norm1.weight"], sv["ln1"], pd,
                                 seeds[0], g("self_attn.output_proj.weight"), g("self_attn.output_proj.bias"),
                                 g("norm1.weight"), g("norm1.bias"))
-    dV = torch.zeros(sv["V"].shape, dtype=torch.float32, device=dx2.device)
+    # grid queries + bf16 storage + D = 16: the LDS-tiled scatter can hand over the value gradient in bf16 (packed bf16x2
+    # atomics; its consumer, the value projection's backward, rounds it to bf16 anyway) -- half the atomics, zero-fill and read
+    gv16 = (sv["V"].dtype == torch.bfloat16 and sv["OA"].dtype == torch.bfloat16 and D == 16 and npts == 4 and geom.L * npts <= 16
+            and ops.tiled_scatter_bf16())
+    dV = torch.zeros(sv["V"].shape, dtype=torch.bfloat16 if gv16 else torch.float32, device=dx2.device)
     mlp = M * geom.L * npts
     seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
     sample_bwd(d_out_m, sv["q"], sv["OA"], P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"],

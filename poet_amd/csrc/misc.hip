@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumP p) {
 }
 
 // ---- fp32 value-gradient maps -> row-major activations -------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void vgrad_rows_kernel(const float* __restrict__ gv, int64_t vs_n, int64_t vs_s, int64_t vs_m,
+template <typename T, typename TG = float>
+__global__ __launch_bounds__(256) void vgrad_rows_kernel(const TG* __restrict__ gv, int64_t vs_n, int64_t vs_s, int64_t vs_m,
                                                          const uint8_t* __restrict__ mask, T* __restrict__ out,
                                                          int S, int M, int D, int64_t total) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void vgrad_rows_kernel(const float* __restrict
     const int ch = c8 * 8, m = ch / D, d = ch - m * D;
     const int n = (int)(row / S), s = (int)(row - (int64_t)n * S);
     float v[8];
-    vec<float, 8>::ld(gv + (int64_t)n * vs_n + (int64_t)s * vs_s + (int64_t)m * vs_m + d, v);
+    vec<TG, 8>::ld(gv + (int64_t)n * vs_n + (int64_t)s * vs_s + (int64_t)m * vs_m + d, v);
     if (mask && mask[row]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -657,13 +657,15 @@ extern "C" int poet_colsum(const void* x, int64_t ld, float* out, int batch, int
     return POET_OK;
 }
 
-extern "C" int poet_vgrad_to_rows(const float* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
-                                  void* out, int N, int S, int M, int D, int dtype, void* stream) {
+extern "C" int poet_vgrad_to_rows(const void* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
+                                  void* out, int N, int S, int M, int D, int gv_dtype, int dtype, void* stream) {
     POET_CHECK(gv && out && D % 8 == 0, POET_ERR_ARG, "vgrad_to_rows: bad args");
+    POET_CHECK(gv_dtype == POET_F32 || (gv_dtype == POET_BF16 && dtype == POET_BF16), POET_ERR_UNSUPPORTED, "vgrad_to_rows: bf16 maps go to bf16 rows");
     const int64_t total = (int64_t)N * S * M * D / 8;
     dim3 grid(cdiv(total, 256)), block(256);
-    if (dtype == POET_BF16) hipLaunchKernelGGL(vgrad_rows_kernel<bf16_t>, grid, block, 0, ST, gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, S, M, D, total);
-    else hipLaunchKernelGGL(vgrad_rows_kernel<float>, grid, block, 0, ST, gv, vs_n, vs_s, vs_m, row_mask, (float*)out, S, M, D, total);
+    if (gv_dtype == POET_BF16) hipLaunchKernelGGL((vgrad_rows_kernel<bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, S, M, D, total);
+    else if (dtype == POET_BF16) hipLaunchKernelGGL((vgrad_rows_kernel<bf16_t, float>), grid, block, 0, ST, (const float*)gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, S, M, D, total);
+    else hipLaunchKernelGGL((vgrad_rows_kernel<float, float>), grid, block, 0, ST, (const float*)gv, vs_n, vs_s, vs_m, row_mask, (float*)out, S, M, D, total);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

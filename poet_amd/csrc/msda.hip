@@ -41,6 +41,7 @@ struct MsdaP {
     int groups, tpg;     // channel groups per row, per head
     int grid_queries;    // queries are the pixels of the flattened levels, in order (encoder self-attention)
     int parts;           // backward: bit0 = d(offsets|logits)/d(loc,attn) kernel, bit1 = d(value) scatter kernel
+    int gv_bf16;         // grad_value is bf16 (LDS-tiled scatter only): windows and far corners leave through packed bf16x2 atomics
 };
 
 template <typename TQ, int P>
@@ -654,6 +655,19 @@ __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// packed bf16x2 memory-side atomic add (global_atomic_pk_add_bf16): `p2` = the even channel of a pair (4-byte aligned)
+typedef short gv_short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gv16_add2(bf16_t* p2, float lo, float hi) {
+    const uint32_t w = pack_bf2(lo, hi);
+    const gv_short2_t v = {(short)(w & 0xffffu), (short)(w >> 16)};
+    (void)__builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) gv_short2_t*)(p2), v);
+}
+// ... of ONE channel c (its pair partner receives +0)
+__device__ __forceinline__ void gv16_add(bf16_t* pc, int c, float v) {
+    if (c & 1) gv16_add2(pc - 1, 0.f, v);
+    else gv16_add2(pc, v, 0.f);
+}
+
 // D == 16, P == 4 (one DPP row of 16 lanes = the 16 channels of a head = the <= 16 sample points of a query).
 template <typename TQ, int L>
 __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP p, const TileP tp) {
@@ -732,6 +746,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     const float scale = ldexpf(1.f, 18 - ex), inv = ldexpf(1.f, ex - 18);
 
     float* gvb = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;
+    bf16_t* gvb16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;       // (gv_bf16)
     const int lane_off = c * 4;
     // One dummy pixel per DPP row of the wave, behind the windows.  (The LDS atomic unit works through a ds_add 16 lanes
     // = one pixel = 16 consecutive banks at a time, so the 4 rows of a wave never conflict with each other: measured, a
@@ -846,7 +861,11 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfar[k]), src));
-                        if (mine && wv != 0.f) atomicAdd(gvb + (int64_t)(gpb + (k & 1) + (k >> 1) * wlr) * p.vs_s, wv * gsi);
+                        if (mine && wv != 0.f) {
+                            const int64_t pe = (int64_t)(gpb + (k & 1) + (k >> 1) * wlr) * p.vs_s;
+                            if (p.gv_bf16) gv16_add(gvb16 + pe, c, wv * gsi);
+                            else atomicAdd(gvb + pe, wv * gsi);
+                        }
                     }
                 }
             }
@@ -865,6 +884,19 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
         const int ay = max((tyf * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((tyf + 1) * H, tp.TY) + tp.HALO, H);
         const int wpf = bx - ax, cnt = wpf * (by - ay) * D;
         const float inv_wp = 1.f / (float)wpf;
+        if (p.gv_bf16) {                                      // channel PAIRS: one packed bf16x2 atomic per nonzero pair
+            bf16_t* gl16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)start * p.vs_s;
+            const int2* w2 = reinterpret_cast<const int2*>(win + lofff * D);
+            for (int i = tid; i < (cnt >> 1); i += TILED_NT) {
+                const int2 v = w2[i];
+                if (v.x | v.y) {
+                    const int cc = (i & 7) * 2, pix = i >> 3;
+                    const int py = idiv_small(pix, wpf, inv_wp);
+                    const int xx = ax + pix - py * wpf, yy = ay + py;
+                    gv16_add2(gl16 + (int64_t)(yy * W + xx) * p.vs_s + cc, (float)v.x * inv, (float)v.y * inv);
+                }
+            }
+        } else {
         float* gl = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)start * p.vs_s;
         for (int i = tid; i < cnt; i += TILED_NT) {
             const int v = win[lofff * D + i];
@@ -874,6 +906,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
                 const int xx = ax + pix - py * wpf, yy = ay + py;
                 atomicAdd(gl + (int64_t)(yy * W + xx) * p.vs_s + cc, (float)v * inv);
             }
+        }
         }
         lofff += wpf * (by - ay);
     };
@@ -1395,18 +1428,29 @@ extern "C" int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s
 
 extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m, const int64_t* shapes,
                                    const int64_t* starts, const void* offattn, int64_t ldq, int logit_col,
-                                   const float* ref, int64_t ref_bs, const void* grad_out, float* grad_value,
+                                   const float* ref, int64_t ref_bs, const void* grad_out, void* grad_value,
                                    void* grad_offattn, int N, int S, int M, int D, int L, int P, int Lq,
-                                   int v_dtype, int q_dtype, int grid_queries, int parts, void* stream) {
+                                   int v_dtype, int q_dtype, int gv_dtype, int grid_queries, int parts, void* stream) {
     MsdaP p{};
     int rc = fill_common(p, shapes, starts, N, S, M, D, L, P, Lq);
     if (rc) return rc;
     rc = fused_args(p, value, vs_n, vs_s, vs_m, offattn, ldq, logit_col, ref, ref_bs, M, L, P);
     if (rc) return rc;
     POET_CHECK(grad_out && grad_value && grad_offattn, POET_ERR_ARG, "msda_fused_bwd: null pointer");
-    p.grad_out = grad_out; p.grad_value = grad_value; p.g1 = grad_offattn;
+    POET_CHECK(gv_dtype == POET_F32 || gv_dtype == POET_BF16, POET_ERR_ARG, "msda_fused_bwd: gv_dtype");
+    p.grad_out = grad_out; p.grad_value = reinterpret_cast<float*>(grad_value); p.g1 = grad_offattn;
+    p.gv_bf16 = gv_dtype == POET_BF16;
     p.grid_queries = grid_queries;
     p.parts = (parts & 3) ? (parts & 3) : 3;
+    if (p.gv_bf16) {                                          // only the LDS-tiled scatter writes bf16 maps: refuse what would take the plain one
+        TileP tp_{};
+        const char* e_ = getenv("POET_NO_TILED_SCATTER");
+        const int64_t rows_ = (int64_t)N * Lq;                 // (the conditions of launch_dv_tiled)
+        POET_CHECK(grid_queries && Lq == S && q_dtype == POET_BF16 && P == 4 && L * P <= 16 && D == 16 && !(e_ && atoi(e_)) && plan_tiles(p, L, tp_) &&
+                   (vs_n % 2 == 0) && (vs_m % 2 == 0) && (vs_s % 2 == 0) && rows_ * M * D * 2 < (1ll << 32) && rows_ * ldq * 2 < (1ll << 32) &&
+                   !(ldq & 1) && !(ref_bs & 1) && ((int64_t)(N - 1) * ref_bs + (int64_t)Lq * L * 2) * 4 < (1ll << 32),
+                   POET_ERR_UNSUPPORTED, "msda_fused_bwd: a bf16 grad_value needs the LDS-tiled scatter (grid queries, D = 16, P = 4, bf16 offsets)");
+    }
     rc = dispatch<true, true>(p, L, P, v_dtype, q_dtype, (hipStream_t)stream);
     if (rc) return rc;
     POET_LAUNCH_CHECK();

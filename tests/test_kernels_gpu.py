@@ -640,6 +640,18 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     # only the bf16 rounding of the stored outputs (out, d(off|logit): 2^-9 relative) and the fixed point remain
     assert e_out < 6e-3 and e_off < 8e-3 and e_lg < 8e-3, (e_out, e_off, e_lg)
     assert e_dv < 1e-3, e_dv
+    # the same scatter into a bf16 map (what the encoder's backward uses: packed bf16x2 atomics, the consumer rounds to bf16
+    # anyway): exact windows, one bf16 rounding per (tile, pixel, channel), at most 4 tiles per pixel
+    gv16 = torch.zeros(n, m, S, d, dtype=torch.bfloat16, device="cuda")
+    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv16, torch.empty_like(dev(oa)), n, m, d, p, S,
+                       grid_queries=True, parts=2)
+    dv16 = gv16.double().cpu().permute(0, 2, 1, 3)
+    e_dv16 = (dv16 - dv_ref).abs().max().item() / dv_ref.abs().max().item()
+    print(f"   bf16 value-gradient map: rel max err {e_dv16:.2e}")
+    assert e_dv16 < 2e-2, e_dv16            # a pixel on a tile border: <= 4 partial sums, each rounded to bf16 (<= 2^-8 relative)
+    rows16 = torch.empty(n * S, m * d, dtype=torch.bfloat16, device="cuda")
+    ops.vgrad_to_rows(gv16, vstr, None, rows16, n, S, m, d)
+    assert torch.equal(rows16.view(n, S, m, d).cpu(), gv16.permute(0, 2, 1, 3).cpu())
 
 
 # ------------------------------------------------------------------------- streaming (weight-stationary) GEMM
