@@ -173,6 +173,8 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
                         const void* offattn, int64_t ldq, int logit_col,
                         const float* ref, int64_t ref_batch_stride, const void* grad_out,
                         void* grad_value, void* grad_offattn,
+                        int64_t ld_grad /* row stride of grad_offattn in elements (0: ldq); wider when the gradient rows are
+                                           a column block of a larger buffer, e.g. [d(offsets|logits) | d(value) rows] */,
                         int N, int S, int M, int D, int L, int P, int Lq,
                         int v_dtype, int q_dtype, int gv_dtype,
                         int grid_queries /* 1: query q is pixel q of the flattened levels (encoder self-attention):
@@ -257,10 +259,10 @@ int poet_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtyp
  * seg_start_host (nseg+1) row boundaries inside one batch item.  out fp32 (nseg, cols) accumulated. */
 int poet_colsum(const void* x, int64_t ld, float* out, int batch, int64_t rows_per_batch, int cols,
                 const int64_t* seg_start_host, int nseg, int dtype, void* stream);
-/* value-gradient maps (gv_dtype fp32 or bf16; addressed by element strides, see fused MSDA) -> (N*S, M*D) row-major `dtype`,
- * rows with row_mask != 0 zeroed (masked_fill backward). */
+/* value-gradient maps (gv_dtype fp32 or bf16; addressed by element strides, see fused MSDA) -> (N*S, M*D) row-major `dtype`
+ * with row stride ld_out (0: M*D), rows with row_mask != 0 zeroed (masked_fill backward). */
 int poet_vgrad_to_rows(const void* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
-                       void* out, int N, int S, int M, int D, int gv_dtype, int dtype, void* stream);
+                       void* out, int64_t ld_out, int N, int S, int M, int D, int gv_dtype, int dtype, void* stream);
 /* NCHW (N,C,H,W) <-> token-major rows [tok_off, tok_off+H*W) of (N, tok_stride, C). */
 int poet_nchw_to_tokens(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
                         int src_dtype, int dst_dtype, void* stream);

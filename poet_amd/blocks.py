@@ -88,14 +88,16 @@ def value_proj_fwd(inp2d, W, b, row_mask, N, S, M, D, act=None, split=False):
     return V
 
 
-def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate, act=None, wb_is_operand=False):
-    """wb_is_operand: W is already the GEMM operand (a stacked view chosen by the caller), not a parameter to look a shadow up for"""
+def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate, act=None, wb_is_operand=False, dVr=None):
+    """wb_is_operand: W is already the GEMM operand (a stacked view chosen by the caller), not a parameter to look a shadow up for.
+    dVr: optional caller-owned (rows, M*D) buffer for the gradient rows (a column block of a wider one)."""
     rows, d = N * S, M * D
-    dVr = empty((rows, d), act or inp2d.dtype, inp2d)
-    ops.vgrad_to_rows(dV, vstrides(M, S, D), row_mask, dVr, N, S, M, D)
-    ops.linear_dw(dVr, inp2d, gW, rows=rows, db=gb)
+    if dVr is None:
+        dVr = empty((rows, d), act or inp2d.dtype, inp2d)
+    ops.vgrad_to_rows(dV, vstrides(M, S, D), row_mask, dVr, N, S, M, D, ld_out=dVr.stride(0))
+    ops.linear_dw(dVr, inp2d, gW, rows=rows, ldy=dVr.stride(0), db=gb)
     if dinp is not None:
-        ops.linear_dx(dVr, W if wb_is_operand else Wb(W, dVr), dinp, rows=rows, add_src=dinp if accumulate else None)
+        ops.linear_dx(dVr, W if wb_is_operand else Wb(W, dVr), dinp, rows=rows, ldy=dVr.stride(0), add_src=dinp if accumulate else None)
 
 
 # ---- (b) offsets/logits projection + fused deformable sampling ----------------------------------
@@ -129,29 +131,33 @@ def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P
 
 
 def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P, dV, g_so_w, g_so_b, g_aw_w, g_aw_b,
-               dq, dq_accumulate, seg_sums=None, grid_queries=False):
+               dq, dq_accumulate, seg_sums=None, grid_queries=False, dOA=None):
+    """dOA: optional caller-owned (rows, >= 3 M L P) buffer for d(offsets | logits) (a column block of a wider one: row stride
+    dOA.stride(0)); with dq=None the input-gradient product is left to the caller."""
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
-    dOA = torch.empty_like(OA)
+    if dOA is None:
+        dOA = torch.empty_like(OA)
+    ldg = dOA.stride(0)
     ops.msda_fused_bwd(V, vstrides_of(V), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
-                       grid_queries=grid_queries)
+                       grid_queries=grid_queries, ld_grad=ldg)
     plain = seg_sums is None
     pr = _pair(so_w, dOA)
     if pr is not None and pr[2].data_ptr() == g_so_w.data_ptr():      # (the gradient sink is the arena: stacked dW + db)
-        ops.linear_dw(dOA, q2d, pr[2], rows=rows, db=pr[3] if plain else None)
+        ops.linear_dw(dOA, q2d, pr[2], rows=rows, ldy=ldg, db=pr[3] if plain else None)
     else:
-        ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldq, db=g_so_b if plain else None)
-        ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldq, db=g_aw_b if plain else None)
+        ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldg, db=g_so_b if plain else None)
+        ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldg, db=g_aw_b if plain else None)
     if seg_sums is not None:      # per-level column sums (encoder): feeds both the biases and level_embed
-        ops.colsum(dOA, ldq, seg_sums, N, Lq, ldq, geom.c_segs, geom.L)
+        ops.colsum(dOA, ldg, seg_sums, N, Lq, ldq, geom.c_segs, geom.L)
         ops.colsum(seg_sums, ldq, g_so_b, 1, geom.L, 2 * mlp)
         ops.colsum(seg_sums[:, 2 * mlp:], ldq, g_aw_b, 1, geom.L, mlp)
     if dq is not None:
         if pr is not None:                    # d(query) (+)= dOA [W_so ; W_aw]: one product with K = 3 M L P
-            ops.linear_dx(dOA, pr[0], dq, rows=rows, add_src=dq if dq_accumulate else None)
+            ops.linear_dx(dOA, pr[0], dq, rows=rows, ldy=ldg, add_src=dq if dq_accumulate else None)
         else:
-            ops.linear_dx(dOA, Wb(so_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq if dq_accumulate else None)
-            ops.linear_dx(dOA[:, 2 * mlp:], Wb(aw_w, dOA), dq, rows=rows, ldy=ldq, add_src=dq)
+            ops.linear_dx(dOA, Wb(so_w, dOA), dq, rows=rows, ldy=ldg, add_src=dq if dq_accumulate else None)
+            ops.linear_dx(dOA[:, 2 * mlp:], Wb(aw_w, dOA), dq, rows=rows, ldy=ldg, add_src=dq)
 
 
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
@@ -279,18 +285,33 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
     dV = torch.zeros(sv["V"].shape, dtype=torch.bfloat16 if gv16 else torch.float32, device=dx2.device)
     mlp = M * geom.L * npts
     seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
-    sample_bwd(d_out_m, sv["q"], sv["OA"], P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"],
+    so_w = P_["self_attn.sampling_offsets.weight"]
+    tri = getattr(so_w, "_triple", None) if sv["OA"].dtype == torch.bfloat16 and sv["V"].dtype == torch.bfloat16 else None
+    if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d):
+        tri = None
+    G2 = None
+    if tri is not None:
+        # d(src) += [d(offsets|logits) | d(value) rows] [W_so ; W_aw ; W_v]: both gradient blocks are written into ONE
+        # (rows, 3 M L P + d) buffer and the two input-gradient products (K = 768 and K = 256, each a read-modify-write of the
+        # fp32 stream) become one with K = 1024
+        G2 = torch.empty((N * S, 3 * mlp + d), dtype=torch.bfloat16, device=dx2.device)
+    sample_bwd(d_out_m, sv["q"], sv["OA"], so_w, P_["self_attn.attention_weights.weight"],
                sv["V"], geom, ref, ref_bs, N, S, M, D, npts, dV,
                g("self_attn.sampling_offsets.weight"), g("self_attn.sampling_offsets.bias"),
                g("self_attn.attention_weights.weight"), g("self_attn.attention_weights.bias"),
-               dsrc, True, seg_sums=seg, grid_queries=True)
+               None if G2 is not None else dsrc, True, seg_sums=seg, grid_queries=True, dOA=None if G2 is None else G2[:, : 3 * mlp])
     # d(level_embed)[l] += colsum_l(dOA) @ [W_so ; W_aw]   (pos = sine + level_embed, q = src + pos)
     if g_level is not None:
         so_w, aw_w = P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"]
         ops.gemm(seg, so_w, g_level, geom.L, d, 2 * mlp, lda=3 * mlp, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
         ops.gemm(seg[:, 2 * mlp:], aw_w, g_level, geom.L, d, mlp, lda=3 * mlp, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
-    value_proj_bwd(dV, sv["src"], P_["self_attn.value_proj.weight"], mask, N, S, M, D,
-                   g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), dsrc, True, sv["V"].dtype)
+    if G2 is not None:
+        value_proj_bwd(dV, sv["src"], P_["self_attn.value_proj.weight"], mask, N, S, M, D,
+                       g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), None, True, sv["V"].dtype, dVr=G2[:, 3 * mlp:])
+        ops.linear_dx(G2, tri["w16"], dsrc, rows=N * S, add_src=dsrc)
+    else:
+        value_proj_bwd(dV, sv["src"], P_["self_attn.value_proj.weight"], mask, N, S, M, D,
+                       g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), dsrc, True, sv["V"].dtype)
     return dsrc
 
 

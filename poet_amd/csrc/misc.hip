@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumP p) {
 // ---- fp32 value-gradient maps -> row-major activations -------------------------------------------
 template <typename T, typename TG = float>
 __global__ __launch_bounds__(256) void vgrad_rows_kernel(const TG* __restrict__ gv, int64_t vs_n, int64_t vs_s, int64_t vs_m,
-                                                         const uint8_t* __restrict__ mask, T* __restrict__ out,
+                                                         const uint8_t* __restrict__ mask, T* __restrict__ out, int64_t ld_out,
                                                          int S, int M, int D, int64_t total) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void vgrad_rows_kernel(const TG* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
-    vec<T, 8>::st(out + row * ((int64_t)M * D) + ch, v);
+    vec<T, 8>::st(out + row * ld_out + ch, v);
 }
 
 // ---- NCHW <-> token-major (LDS tile transpose) ---------------------------------------------------
@@ -658,14 +658,15 @@ extern "C" int poet_colsum(const void* x, int64_t ld, float* out, int batch, int
 }
 
 extern "C" int poet_vgrad_to_rows(const void* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
-                                  void* out, int N, int S, int M, int D, int gv_dtype, int dtype, void* stream) {
-    POET_CHECK(gv && out && D % 8 == 0, POET_ERR_ARG, "vgrad_to_rows: bad args");
+                                  void* out, int64_t ld_out, int N, int S, int M, int D, int gv_dtype, int dtype, void* stream) {
+    if (ld_out <= 0) ld_out = (int64_t)M * D;
+    POET_CHECK(gv && out && D % 8 == 0 && ld_out >= (int64_t)M * D && ld_out % 8 == 0, POET_ERR_ARG, "vgrad_to_rows: bad args");
     POET_CHECK(gv_dtype == POET_F32 || (gv_dtype == POET_BF16 && dtype == POET_BF16), POET_ERR_UNSUPPORTED, "vgrad_to_rows: bf16 maps go to bf16 rows");
     const int64_t total = (int64_t)N * S * M * D / 8;
     dim3 grid(cdiv(total, 256)), block(256);
-    if (gv_dtype == POET_BF16) hipLaunchKernelGGL((vgrad_rows_kernel<bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, S, M, D, total);
-    else if (dtype == POET_BF16) hipLaunchKernelGGL((vgrad_rows_kernel<bf16_t, float>), grid, block, 0, ST, (const float*)gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, S, M, D, total);
-    else hipLaunchKernelGGL((vgrad_rows_kernel<float, float>), grid, block, 0, ST, (const float*)gv, vs_n, vs_s, vs_m, row_mask, (float*)out, S, M, D, total);
+    if (gv_dtype == POET_BF16) hipLaunchKernelGGL((vgrad_rows_kernel<bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, ld_out, S, M, D, total);
+    else if (dtype == POET_BF16) hipLaunchKernelGGL((vgrad_rows_kernel<bf16_t, float>), grid, block, 0, ST, (const float*)gv, vs_n, vs_s, vs_m, row_mask, (bf16_t*)out, ld_out, S, M, D, total);
+    else hipLaunchKernelGGL((vgrad_rows_kernel<float, float>), grid, block, 0, ST, (const float*)gv, vs_n, vs_s, vs_m, row_mask, (float*)out, ld_out, S, M, D, total);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -26,7 +26,7 @@ struct MsdaP {
     int64_t vs_n, vs_s, vs_m;
     const void* q1;      // fused: offattn; plain: sampling_loc
     const void* q2;      // plain: attn_weight
-    int64_t ldq;
+    int64_t ldq, ldg;    // row strides (elements) of q1 and of g1 (fused: the gradient rows may sit in a wider buffer)
     int logit_col;
     const float* ref;
     int64_t ref_bs;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
         }
         if (rem == 0) {
             if constexpr (FUSED) {
-                TQ* gp = reinterpret_cast<TQ*>(p.g1) + row * p.ldq + (m * L + l) * P * 2;
+                TQ* gp = reinterpret_cast<TQ*>(p.g1) + row * p.ldg + (m * L + l) * P * 2;
                 store_p<TQ, P>(gp, dxy, 2 * P);          // d/d(offset) = (dpx, dpy): the W,H factors cancel
             } else {
 #pragma unroll
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
             for (int i = 0; i < LP; ++i) dot += a[i] * da[i];
 #pragma unroll
             for (int i = 0; i < LP; ++i) da[i] = a[i] * (da[i] - dot);
-            TQ* gp = reinterpret_cast<TQ*>(p.g1) + row * p.ldq + p.logit_col + m * LP;
+            TQ* gp = reinterpret_cast<TQ*>(p.g1) + row * p.ldg + p.logit_col + m * LP;
 #pragma unroll
             for (int l = 0; l < L; ++l) store_p<TQ, P>(gp + l * P, da + l * P, P);
         } else {
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
     dot += quad_xor1(dot); dot += quad_xor2(dot);                     // softmax Jacobian over the 16 points of (query, head)
 #pragma unroll
     for (int i = 0; i < 4; ++i) da[i] = gk.aw[i] * (da[i] - dot);
-    bf16_t* grow = reinterpret_cast<bf16_t*>(p.g1) + (int64_t)row * p.ldq;
+    bf16_t* grow = reinterpret_cast<bf16_t*>(p.g1) + (int64_t)row * p.ldg;
     vec<bf16_t, 8>::st(grow + (m * 4 + o) * 8, dxy);
     vec<bf16_t, 4>::st(grow + p.logit_col + m * 16 + o * 4, da);
 }
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(WIN_NT, 2) void msda_win_kernel(const MsdaP p, cons
                     }
                 }
                 if constexpr (BWD) {                      // d/d(offset) = (dpx, dpy): the W, H factors cancel
-                    bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldq + (m * L + l) * 8;
+                    bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldg + (m * L + l) * 8;
                     *reinterpret_cast<uint4*>(gp) = make_uint4(pack_bf2(dxy[0], dxy[1]), pack_bf2(dxy[2], dxy[3]), pack_bf2(dxy[4], dxy[5]), pack_bf2(dxy[6], dxy[7]));
                 }
             }
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(WIN_NT, 2) void msda_win_kernel(const MsdaP p, cons
                 for (int i = 0; i < LP; ++i) dot = fmaf(a[i], da[i], dot);
 #pragma unroll
                 for (int i = 0; i < LP; ++i) da[i] = a[i] * (da[i] - dot);
-                bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldq + p.logit_col + m * LP;
+                bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldg + p.logit_col + m * LP;
 #pragma unroll
                 for (int i = 0; i < LP; i += 8)
                     *reinterpret_cast<uint4*>(gp + i) = make_uint4(pack_bf2(da[i], da[i + 1]), pack_bf2(da[i + 2], da[i + 3]), pack_bf2(da[i + 4], da[i + 5]), pack_bf2(da[i + 6], da[i + 7]));
@@ -1429,7 +1429,7 @@ extern "C" int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s
 extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m, const int64_t* shapes,
                                    const int64_t* starts, const void* offattn, int64_t ldq, int logit_col,
                                    const float* ref, int64_t ref_bs, const void* grad_out, void* grad_value,
-                                   void* grad_offattn, int N, int S, int M, int D, int L, int P, int Lq,
+                                   void* grad_offattn, int64_t ld_grad, int N, int S, int M, int D, int L, int P, int Lq,
                                    int v_dtype, int q_dtype, int gv_dtype, int grid_queries, int parts, void* stream) {
     MsdaP p{};
     int rc = fill_common(p, shapes, starts, N, S, M, D, L, P, Lq);
@@ -1438,6 +1438,8 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
     if (rc) return rc;
     POET_CHECK(grad_out && grad_value && grad_offattn, POET_ERR_ARG, "msda_fused_bwd: null pointer");
     POET_CHECK(gv_dtype == POET_F32 || gv_dtype == POET_BF16, POET_ERR_ARG, "msda_fused_bwd: gv_dtype");
+    p.ldg = ld_grad > 0 ? ld_grad : ldq;
+    POET_CHECK(p.ldg >= (int64_t)3 * M * L * P && (p.ldg % 8) == 0, POET_ERR_ARG, "msda_fused_bwd: ld_grad %lld", (long long)p.ldg);
     p.grad_out = grad_out; p.grad_value = reinterpret_cast<float*>(grad_value); p.g1 = grad_offattn;
     p.gv_bf16 = gv_dtype == POET_BF16;
     p.grid_queries = grid_queries;

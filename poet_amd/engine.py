@@ -91,6 +91,11 @@ class ParamArena:
             if n.endswith("sampling_offsets.weight"):
                 pre = n[: -len("sampling_offsets.weight")]
                 quad = [pre + "sampling_offsets.weight", pre + "attention_weights.weight", pre + "sampling_offsets.bias", pre + "attention_weights.bias"]
+                # encoder self-attention: the value projection's weight follows the pair -- d(src) = [d(offsets|logits) | d(value)
+                # rows] [W_so ; W_aw ; W_v] is then ONE input-gradient product with K = 3 M L P + d (_link_projection_pairs: `_triple`)
+                vname = pre + "value_proj.weight"
+                if pre.startswith("transformer.encoder") and vname in byname and vname not in taken:
+                    quad.insert(2, vname)
                 if all(q in byname for q in quad):
                     for q in quad:
                         order.append((q, byname[q]))
@@ -191,6 +196,10 @@ class ParamArena:
             rows, d = w.shape[0] + aw_p.shape[0], w.shape[1]
             w._pair = dict(w=self.flat[o:o + rows * d].view(rows, d), w16=self.flat_bf16[o:o + rows * d].view(rows, d),
                            gw=self.grad[o:o + rows * d].view(rows, d), b=self.flat[sb_o:sb_o + rows], gb=self.grad[sb_o:sb_o + rows])
+            vp = pos.get(pre + "value_proj.weight")
+            if vp is not None and vp[1] == o + rows * d and vp[0].shape[1] == d:       # [W_so ; W_aw ; W_v]: bf16 operand of the merged dX
+                r3 = rows + vp[0].shape[0]
+                w._triple = dict(w16=self.flat_bf16[o:o + r3 * d].view(r3, d), w=self.flat[o:o + r3 * d].view(r3, d), n_oa=rows)
 
     def _link_value_stack(self, vstack):
         """Hang the stacked views of the decoder layers' value projections on layer 0's weight (`_vstack`: fp32 / bf16 /

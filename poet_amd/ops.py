@@ -380,19 +380,19 @@ def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 
 
 def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value,
-                   grad_offattn, N, M, D, P, Lq, grid_queries=False, parts=3):
+                   grad_offattn, N, M, D, P, Lq, grid_queries=False, parts=3, ld_grad=0):
     lib = _lib.load()
     if PROFILE.on and parts == 3:       # time the two kernels of the backward separately
         a = (value, vstrides, geom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value, grad_offattn, N, M, D, P, Lq)
         nb_q = offattn.numel() * offattn.element_size() * 2 + grad_out.numel() * grad_out.element_size() + value.numel() * value.element_size()
-        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2)
+        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2, ld_grad=ld_grad)
         PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype == torch.bfloat16) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * grad_value.element_size())
-        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1)
+        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1, ld_grad=ld_grad)
         PROFILE.end("msda_bwd_dq" + ("_small" if N * Lq < 4096 else ""), e0, 0.0, nb_q)
         return
     _lib.check(lib.poet_msda_fused_bwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
                                        offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, grad_out.data_ptr(),
-                                       grad_value.data_ptr(), grad_offattn.data_ptr(), N, geom.S, M, D, geom.L, P, Lq,
+                                       grad_value.data_ptr(), grad_offattn.data_ptr(), ld_grad, N, geom.S, M, D, geom.L, P, Lq,
                                        dcode(value), dcode(offattn), dcode(grad_value), int(grid_queries), parts, _stream()), "poet_msda_fused_bwd")
 
 
@@ -522,9 +522,9 @@ def tiled_scatter_bf16() -> bool:
     return os.environ.get("POET_DV_FP32", "0") in ("", "0") and os.environ.get("POET_NO_TILED_SCATTER", "0") in ("", "0")
 
 
-def vgrad_to_rows(gv, vstrides, row_mask, out, N, S, M, D):
+def vgrad_to_rows(gv, vstrides, row_mask, out, N, S, M, D, ld_out=0):
     lib = _lib.load()
-    _lib.check(lib.poet_vgrad_to_rows(_req(gv, "gv").data_ptr(), *vstrides, _ptr(row_mask), out.data_ptr(), N, S, M, D, dcode(gv), dcode(out),
+    _lib.check(lib.poet_vgrad_to_rows(_req(gv, "gv").data_ptr(), *vstrides, _ptr(row_mask), out.data_ptr(), ld_out, N, S, M, D, dcode(gv), dcode(out),
                                       _stream()), "poet_vgrad_to_rows")
 
 
