@@ -129,7 +129,8 @@ int poet_gemm(const PoetGemmDesc* desc, void* stream);
  * the weight / bias gradient of the same nn.Linear of every decoder layer (models/deformable_transformer.py:253-292). */
 int poet_gemm_dw_list(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n,
                       int n_out, int k_in, int rows, int64_t ldy, int64_t ldx, int64_t ldw, void* stream);
-enum { POET_GEMM_PATH_NONE = 0, POET_GEMM_PATH_TILED = 1, POET_GEMM_PATH_STREAM = 2, POET_GEMM_PATH_DW = 3, POET_GEMM_PATH_SMALL = 4 };
+enum { POET_GEMM_PATH_NONE = 0, POET_GEMM_PATH_TILED = 1, POET_GEMM_PATH_STREAM = 2, POET_GEMM_PATH_DW = 3, POET_GEMM_PATH_SMALL = 4,
+       POET_GEMM_PATH_LT = 5 /* hipBLASLt: plain bf16 x bf16 -> fp32 (+=) products with K >= 512 */ };
 int poet_gemm_last_path(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -497,6 +497,10 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     }
     POET_CHECK(d.batch == 1 || (!d.add_src && !d.gate_ref), POET_ERR_UNSUPPORTED,
                "poet_gemm: batched add_src / gate_ref only in the <= 1024-row kernels");
+    if (gemm_lt_try(p, st)) {                               // plain K >= 512 products: the vendor library (gemm_lt.hip)
+        g_last_path = POET_GEMM_PATH_LT;
+        return POET_OK;
+    }
     if (gemm_ws_try(p, st)) {
         g_last_path = POET_GEMM_PATH_STREAM;
         POET_LAUNCH_CHECK();

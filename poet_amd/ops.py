@@ -188,7 +188,7 @@ def _esz(t):
     return t.element_size()
 
 
-_GEMM_PATHS = {0: "none", 1: "tiled", 2: "stream", 3: "dw", 4: "small"}
+_GEMM_PATHS = {0: "none", 1: "tiled", 2: "stream", 3: "dw", 4: "small", 5: "lt"}
 
 
 class LevelGeom:
@@ -225,7 +225,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
     hm = head_major or (0, 0, 0)
-    ws = _workspace(Cout.device).data_ptr() if (atomic and a_kmajor and b_kmajor and batch == 1 and K >= 4096) else 0
+    # caller-owned scratch: partial tiles of the weight-gradient form; hipBLASLt's workspace for the plain K >= 512 products
+    ws = _workspace(Cout.device).data_ptr() if ((atomic and a_kmajor and b_kmajor and batch == 1 and K >= 4096) or
+                                                (M >= 4096 and K >= 512 and cd == F32 and ad == BF16 and bd == BF16 and batch == 1 and not atomic)) else 0
     d = _GEMM_DESC
     _GEMM_PACK.pack_into(_GEMM_BUF, 0, A.data_ptr(), 0, B.data_ptr(), Cout.data_ptr(),
                          0 if bias is None else bias.data_ptr(), 0 if add_src is None else add_src.data_ptr(),

@@ -1007,3 +1007,29 @@ def test_lsa_boxes_matches_scipy_including_ties(ops):
             r, cc = linear_sum_assignment(c)
             exp[r] = cc
         assert np.array_equal(col[i], exp), (i, n_pred[i], len(tgts[i]), col[i][:12], exp[:12])
+
+
+def test_gemm_plain_large_k_vendor_route(ops, monkeypatch):
+    """Plain tall-skinny products C (fp32) (+)= A (bf16) W (bf16) with K >= 512 -- the encoder's K = 768 / 1024 / 1280 input
+    gradients -- are routed to hipBLASLt (gemm_lt.hip); same result as the library's own tiled kernel (POET_GEMM_NO_LT is read
+    once per process, so the reference here is torch), for both weight layouts, written and accumulated."""
+    import poet_amd._lib as L
+    lib = L.load()
+    M = 5000 + 8
+    for K, N in ((1024, 256), (768, 256), (1280, 256), (512, 128)):
+        a = _rand(M, K, seed=300 + K).to(torch.bfloat16)
+        w_kn = _rand(K, N, seed=301 + K, scale=1 / math.sqrt(K)).to(torch.bfloat16)      # W[K][N]: the dX form (weight (n_out, k_in))
+        acc0 = _rand(M, N, seed=302 + K)
+        ref = a.float() @ w_kn.float()
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        ops.linear_dx(dev(a), dev(w_kn), out, rows=M)
+        assert lib.poet_gemm_last_path() == 5, lib.poet_gemm_last_path()                 # POET_GEMM_PATH_LT
+        assert (out.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+        acc = dev(acc0.clone())
+        ops.linear_dx(dev(a), dev(w_kn), acc, rows=M, add_src=acc)
+        assert lib.poet_gemm_last_path() == 5
+        assert (acc.cpu() - (ref + acc0)).abs().max().item() <= 2e-3 * (ref + acc0).abs().max().item()
+        # [N][K] weight (the forward form), plain fp32 output
+        out2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        ops.linear_fwd(dev(a), dev(w_kn.t().contiguous()), None, out2)
+        assert (out2.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
