@@ -324,10 +324,11 @@ int poet_match_gather(const int* col, const int* tgt_off, const float* tgt_pos, 
  * so the result is bit-reproducible (data-parallel replicas must derive identical clip factors from identical gradients).
  * poet_adamw: torch.optim.AdamW semantics on a flat fp32 range; grads are first multiplied by
  * clip = min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) when sqnorm != NULL; optionally writes the
- * bf16 shadow copy of the updated parameters.
+ * bf16 shadow copy of the updated parameters, and (p_bf16_lo) the bf16 residual lo = bf16(p - hi) that makes
+ * p = hi + lo to 16 mantissa bits (the two operands of a split-weight product run as two plain GEMMs).
  * ---------------------------------------------------------------------------------------------- */
 int poet_sqnorm(const float* g, int64_t n, float* out, void* stream);
-int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
+int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, uint16_t* p_bf16_lo, int64_t n,
                float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                const float* sqnorm, float max_norm, float grad_scale,
                const uint32_t* step_dev /* optional: the step count is read from this device word instead of `step` */,

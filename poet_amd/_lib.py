@@ -67,7 +67,7 @@ _PROTOS = {
     "poet_lsa_boxes": ([vp, vp, vp, vp, f32, i32, i32, vp, vp, vp], i32),
     "poet_match_gather": ([vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
     "poet_sqnorm": ([vp, i64, vp, vp], i32),
-    "poet_adamw": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp], i32),
+    "poet_adamw": ([vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp], i32),
     "poet_counter_add": ([vp, u32, vp], i32),
 }
 

@@ -33,7 +33,9 @@ struct LtState {
     hipblasLtHandle_t handle = nullptr;
     bool failed = false;
     std::mutex mu;
-    std::map<std::tuple<int, int, int, int64_t, int64_t, int64_t, int, size_t>, LtPlan> plans;   // (M, N, K, lda, ldb, ldc, b_kmajor, ws)
+    // (M, N, K, lda, ldb, ldc, b_kmajor, ws, bias pointer): a descriptor per bias vector -- re-pointing a cached descriptor at
+    // another bias after its algorithm was chosen did not take effect (measured: every layer got the first layer's bias)
+    std::map<std::tuple<int, int, int, int64_t, int64_t, int64_t, int, size_t, uintptr_t>, LtPlan> plans;
 };
 
 LtState& lt_state() {
@@ -50,6 +52,14 @@ LtPlan make_plan(LtState& s, const PoetGemmDesc& d, size_t ws_bytes) {
     const hipblasOperation_t opa = d.b_kmajor ? HIPBLAS_OP_N : HIPBLAS_OP_T, opb = HIPBLAS_OP_N;
     hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa));
     hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb));
+    if (d.bias) {                                               // fp32 [N] = one value per ROW of the column-major result (N x M)
+        const hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+        const hipDataType bt = HIP_R_32F;
+        if (hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep)) != HIPBLAS_STATUS_SUCCESS) return pl;
+        if (hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)) != HIPBLAS_STATUS_SUCCESS) return pl;
+        const void* bp = d.bias;
+        if (hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) != HIPBLAS_STATUS_SUCCESS) return pl;
+    }
     hipblasStatus_t st;
     if (d.b_kmajor) st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, d.N, d.K, d.ldb);
     else st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, d.K, d.N, d.ldb);
@@ -79,7 +89,8 @@ bool gemm_lt_try(const GemmK& p, hipStream_t st) {
     // plain products only: bf16 operands, fp32 result written or accumulated in place, nothing fused
     if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || d.c_dtype != POET_F32 || d.compute != POET_BF16) return false;
     if (d.a_kmajor || d.batch != 1 || d.splitk != 1 || d.atomic || d.A2 || d.b_split) return false;
-    if (d.bias || d.act || d.gate_ref || d.row_mask || d.drop_p != 0.f || d.out_mode != 0 || d.alpha != 1.f) return false;
+    if (d.act || d.gate_ref || d.row_mask || d.drop_p != 0.f || d.out_mode != 0 || d.alpha != 1.f) return false;
+    if (d.bias && d.add_src) return false;                              // (bias only on the writing form)
     if (d.add_src && (d.add_src != d.C || d.ld_add != d.ldc)) return false;
     if (d.M < 4096 || d.K < 512 || d.N % 16 != 0 || d.K % 16 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B) | reinterpret_cast<uintptr_t>(d.C)) & 15) return false;
@@ -92,7 +103,7 @@ bool gemm_lt_try(const GemmK& p, hipStream_t st) {
         if (s.failed) return false;
         if (!s.handle && hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) { s.failed = true; return false; }
         const size_t ws_bytes = d.workspace && (reinterpret_cast<uintptr_t>(d.workspace) & 255) == 0 ? (size_t)d.workspace_bytes : 0;
-        const auto key = std::make_tuple(d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.b_kmajor, ws_bytes);
+        const auto key = std::make_tuple(d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.b_kmajor, ws_bytes, reinterpret_cast<uintptr_t>(d.bias));
         auto it = s.plans.find(key);
         if (it == s.plans.end()) it = s.plans.emplace(key, make_plan(s, d, ws_bytes)).first;
         pl = it->second;

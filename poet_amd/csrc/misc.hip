@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, uint16_t* __restrict__ pb, int64_t n, float lr,
+                                                    float* __restrict__ v, uint16_t* __restrict__ pb, uint16_t* __restrict__ pb_lo, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2s,
                                                     const float* __restrict__ sqnorm, float max_norm, float gscale,
                                                     const uint32_t* __restrict__ step_dev, const float* __restrict__ lr_scale) {
@@ -470,7 +470,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float denom = sqrtf(vi) / bc2s + eps;
     pi -= (lr / bc1) * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
-    if (pb) pb[i] = f2bf(pi);
+    if (pb) {
+        const bf16_t hi = f2bf(pi);
+        pb[i] = hi;
+        if (pb_lo) pb_lo[i] = f2bf(pi - bf2f(hi));          // the split-bf16 residual: W = hi + lo to 16 mantissa bits
+    }
 }
 
 
@@ -818,13 +822,14 @@ extern "C" int poet_sqnorm(const float* g, int64_t n, float* out, void* stream) 
     return POET_OK;
 }
 
-extern "C" int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, float lr, float beta1,
+extern "C" int poet_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, uint16_t* p_bf16_lo, int64_t n, float lr, float beta1,
                           float beta2, float eps, float weight_decay, int step, const float* sqnorm, float max_norm,
                           float grad_scale, const uint32_t* step_dev, const float* lr_scale, void* stream) {
     POET_CHECK(p && g && m && v && n > 0 && (step >= 1 || step_dev), POET_ERR_ARG, "adamw: bad args");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps,
+    POET_CHECK(!p_bf16_lo || p_bf16, POET_ERR_ARG, "adamw: the lo shadow needs the hi shadow");
+    hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, p, g, m, v, p_bf16, p_bf16_lo, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2s, sqnorm, max_norm, grad_scale, step_dev, lr_scale);
     POET_LAUNCH_CHECK();
     return POET_OK;

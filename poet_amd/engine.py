@@ -128,6 +128,9 @@ class ParamArena:
         self.sq = torch.zeros(1 + 1024, dtype=torch.float32, device=dev)       # [0] = sum of squares, [1:] = poet_sqnorm's partials
         # bf16 shadow of every weight: the second MFMA operand of the bf16 GEMMs; rewritten by the AdamW kernel
         self.flat_bf16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        # ... and its bf16 residual (W = hi + lo to 16 mantissa bits): lets a split-weight product with a long K run as two
+        # plain bf16 GEMMs, C = A hi^T then C += A lo^T (blocks.proj_ln_fwd)
+        self.flat_bf16_lo = torch.zeros(off, dtype=torch.bfloat16, device=dev)
         for n, p, o in self.entries:
             k = p.numel()
             self.flat[o:o + k].copy_(p.data.reshape(-1))
@@ -135,6 +138,7 @@ class ParamArena:
             p._grad_view = self.grad[o:o + k].view(p.shape)
             p.grad = p._grad_view
             p._bf16 = self.flat_bf16[o:o + k].view(p.shape)
+            p._bf16_lo = self.flat_bf16_lo[o:o + k].view(p.shape)
         self.refresh_shadow()
         # Learning rate = base_lr (a host scalar baked into captured graphs) x this per-64-element DEVICE table: the table
         # carries the 0.1x group of sampling_offsets AND the schedule (set_lr rescales it in place, so a replayed graph
@@ -224,6 +228,7 @@ class ParamArena:
             ops.cast(self.flat, self.flat_bf16)
         else:
             self.flat_bf16.copy_(self.flat)
+        self.flat_bf16_lo.copy_(self.flat - self.flat_bf16.float())
 
     def zero_grad(self):
         self.grad.zero_()
@@ -242,7 +247,8 @@ class ParamArena:
             if b > a:
                 ops.adamw(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b], b - a, lr, self.betas[0], self.betas[1],
                           self.eps, self.weight_decay, self.step_count, sqnorm_buf=sq, max_norm=max_norm, grad_scale=gs,
-                          p_bf16=self.flat_bf16[a:b], step_dev=step_dev, lr_scale=self.lr_scale[a // ALIGN:])
+                          p_bf16=self.flat_bf16[a:b], step_dev=step_dev, lr_scale=self.lr_scale[a // ALIGN:],
+                          p_bf16_lo=self.flat_bf16_lo[a:b])
 
     def grad_norm(self) -> torch.Tensor:
         return torch.sqrt(self.sq[0]) / self.world

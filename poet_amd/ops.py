@@ -519,6 +519,11 @@ def colsum(x, ld, out, batch, rows_per_batch, cols, segs=None, nseg=1):
                                _stream()), "poet_colsum")
 
 
+def two_pass_split() -> bool:
+    """long-K split-weight products as two plain GEMMs (POET_NO_TWO_PASS_SPLIT=1 or POET_GEMM_NO_LT=1: the split-weight kernel)."""
+    return os.environ.get("POET_NO_TWO_PASS_SPLIT", "0") in ("", "0") and os.environ.get("POET_GEMM_NO_LT", "0") in ("", "0")
+
+
 def tiled_scatter_bf16() -> bool:
     """bf16 value-gradient maps out of the encoder's LDS-tiled scatter (POET_DV_FP32=1 or POET_NO_TILED_SCATTER=1: fp32)."""
     return os.environ.get("POET_DV_FP32", "0") in ("", "0") and os.environ.get("POET_NO_TILED_SCATTER", "0") in ("", "0")
@@ -595,9 +600,9 @@ def sqnorm(g, out):
 
 
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, sqnorm_buf=None, max_norm=0.0, grad_scale=1.0, p_bf16=None, step_dev=None,
-          lr_scale=None):
+          lr_scale=None, p_bf16_lo=None):
     lib = _lib.load()
-    _lib.check(lib.poet_adamw(_req(p, "p").data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), n, lr, beta1, beta2,
+    _lib.check(lib.poet_adamw(_req(p, "p").data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), _ptr(p_bf16_lo), n, lr, beta1, beta2,
                               eps, wd, step, _ptr(sqnorm_buf), max_norm, grad_scale, _ptr(step_dev), _ptr(lr_scale), _stream()), "poet_adamw")
 
 

@@ -1033,3 +1033,21 @@ def test_gemm_plain_large_k_vendor_route(ops, monkeypatch):
         out2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
         ops.linear_fwd(dev(a), dev(w_kn.t().contiguous()), None, out2)
         assert (out2.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+        # a split-weight product as two plain ones on the bf16 shadows (hi, lo = bf16(W - hi)), bias on the first:
+        # == the split-weight kernel on the fp32 master, and both == the fp32 weight to 2^-16
+        w32 = _rand(N, K, seed=303 + K, scale=1 / math.sqrt(K))
+        bias = _rand(N, seed=304 + K)
+        hi = w32.to(torch.bfloat16)
+        lo = (w32 - hi.float()).to(torch.bfloat16)
+        two = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        ops.linear_fwd(dev(a), dev(hi), dev(bias), two)
+        assert lib.poet_gemm_last_path() == 5
+        ops.linear_fwd(dev(a), dev(lo), None, two, add_src=two)
+        assert lib.poet_gemm_last_path() == 5
+        one = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        ops.linear_fwd(dev(a), dev(w32), dev(bias), one, split=True)
+        exact = a.double() @ w32.double().t() + bias.double()
+        sc = exact.abs().max().item()
+        assert (two.double().cpu() - exact).abs().max().item() <= 1e-4 * sc
+        assert (one.double().cpu() - exact).abs().max().item() <= 1e-4 * sc
+        assert (two.cpu() - one.cpu()).abs().max().item() <= 2e-5 * sc

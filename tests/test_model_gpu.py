@@ -332,14 +332,16 @@ def test_arena_trainer_matches_oracle_step(gpu):
 
 def test_arena_paths_match_plain_model_at_full_size(gpu):
     """Everything that only exists with the flat parameter arena -- the stacked [offsets | logits] Linear, the K = 1024 input
-    gradient over [W_so ; W_aw ; W_v] with its shared gradient-row buffer, the decoder's stacked value projections, gradients
-    written straight into arena views -- at YCB-V geometry (6380 token rows per image: the streaming / vendor-route kernels
-    the benchmark runs), against the SAME model without an arena (whose gradients the goldens of the real reference pin):
-    identical losses, gradient checksums within the bf16 bound."""
+    gradient over [W_so ; W_aw ; W_v] with its shared gradient-row buffer, the decoder's stacked value projections, the
+    two-pass split FFN2 on the hi / lo shadows, gradients written straight into arena views -- at YCB-V geometry (6380 token rows
+    per image: the streaming / vendor-route kernels the benchmark runs).  Two bf16 programs whose forwards differ by one
+    rounding somewhere differ by a few percent in their gradients (that IS the bf16 noise floor: GRAD_TOL_BF16), so the
+    yardstick is the fp32 policy of the same model (whose gradients the goldens of the real reference pin): the arena's bf16
+    gradients must be as close to it as the plain model's bf16 gradients are."""
     import poet_amd
     grads, losses = {}, {}
-    for mode in ("plain", "arena"):
-        r = gpu("ycbv", 2, False, "bf16", dropout=0.0)
+    for mode in ("fp32", "plain", "arena"):
+        r = gpu("ycbv", 2, False, "fp32" if mode == "fp32" else "bf16", dropout=0.0)
         model, crit = r["model"], r["crit"]
         model.train()
         if mode == "arena":
@@ -348,22 +350,27 @@ def test_arena_paths_match_plain_model_at_full_size(gpu):
         out, nb = model(r["samples"], r["targets"])
         ls = crit(out, r["targets"], nb)
         total = sum(ls[k] * crit.weight_dict[k] for k in ls if k in crit.weight_dict)
-        if mode == "plain":
+        if mode != "arena":
             model.zero_grad()
         total.backward()
         torch.cuda.synchronize()
-        losses[mode] = float(total)
+        losses[mode] = float(total.detach())
         gof = lambda p: getattr(p, "_grad_view", None) if getattr(p, "_grad_view", None) is not None else p.grad
         grads[mode] = {n: gof(p).detach().float().cpu().clone() for n, p in model.named_parameters() if gof(p) is not None}
-    assert abs(losses["arena"] - losses["plain"]) < 1e-3 * max(1.0, abs(losses["plain"])), losses
-    assert set(grads["arena"]) == set(grads["plain"])
-    bad = []
-    for n, g in grads["plain"].items():
-        scale = max(g.abs().max().item(), 1e-6)
-        err = (grads["arena"][n] - g).abs().max().item() / scale
-        if err > 3e-2:                       # two bf16 programs with different GEMM groupings (bf16 operands, fp32 accumulation)
-            bad.append((n, err))
-    print(f"arena vs plain at YCB-V size: loss {losses['arena']:.5f} / {losses['plain']:.5f}; {len(bad)} of {len(grads['plain'])} gradients above 3e-2")
+    assert abs(losses["arena"] - losses["fp32"]) < 2e-3 * max(1.0, abs(losses["fp32"])), losses
+    assert set(grads["arena"]) == set(grads["plain"]) == set(grads["fp32"])
+    # per-tensor max-norm errors are dominated by single rounding flips (0.5 for one offset-bias tensor in EITHER program), so
+    # the comparison is in the L2 norm: over all gradients together, and per tensor with a wide margin
+    def l2(mode, names):
+        num = sum(float(((grads[mode][n] - grads["fp32"][n]).double() ** 2).sum()) for n in names)
+        den = sum(float((grads["fp32"][n].double() ** 2).sum()) for n in names)
+        return (num / max(den, 1e-30)) ** 0.5
+    names = sorted(grads["fp32"])
+    ga, gp = l2("arena", names), l2("plain", names)
+    bad = [(n, l2("arena", [n]), l2("plain", [n])) for n in names if l2("arena", [n]) > 3.0 * l2("plain", [n]) + 2e-2]
+    print(f"bf16 gradients vs the fp32 policy at YCB-V size, relative L2 over all {len(names)} tensors: arena {ga:.4f}, plain {gp:.4f}; "
+          f"losses fp32 {losses['fp32']:.5f} plain {losses['plain']:.5f} arena {losses['arena']:.5f}")
+    assert ga < 1.3 * gp + 2e-3, (ga, gp)
     assert not bad, bad[:8]
 
 
