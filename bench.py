@@ -93,7 +93,7 @@ def gemm_flops_per_image(cfg):
 # config): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when
 # the family is not in the summary.
 # profile tag (poet_amd/ops.py) -> substring of the kernel symbols in the summaries
-_PMC_NAMES = {"msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_shared_kernel|msda_bwd_kernel<bf16, bf16", "msda_fused_fwd": "msda_fwd_shared_kernel|msda_fwd_kernel<bf16, bf16",
+_PMC_NAMES = {"gemm_lt": "hipblaslt_Cijk", "msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_shared_kernel|msda_bwd_kernel<bf16, bf16", "msda_fused_fwd": "msda_fwd_shared_kernel|msda_fwd_kernel<bf16, bf16",
               "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws", "gemm_stream_fwd": "gemm_ws",
               "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
               "gemm_small_fwd": "gemm_small_kernel<false", "gemm_small_dX": "gemm_small_kernel<true", "gemm_small_dW": "gemm_small_dw_kernel",
@@ -151,7 +151,7 @@ def pmc_mfma_summary(config="ycbv"):
     us = tf = busy = 0.0
     top = None
     for r in rows[1:]:
-        if not r[0].startswith("gemm") or float(r[h["SQ_INSTS_MFMA"]]) == 0:
+        if not r[0].startswith(("gemm", "hipblaslt")) or float(r[h["SQ_INSTS_MFMA"]]) == 0:
             continue
         w = float(r[h["avg_us"]])                       # per-launch time; launches per step are in the kernel_stats summary
         us += w

@@ -16,6 +16,10 @@ rnd = "round" + tag.lstrip("r")
 
 
 def short(name):
+    if name.startswith("Cijk_"):                               # hipBLASLt / Tensile kernel: keep the macro tile, the MFMA shape and the stream-K tag
+        m = re.search(r"(MT\d+x\d+x\d+)_(MI\d+x\d+x\d+)", name)
+        sk = re.search(r"_(SK\d+)_", name)
+        return "hipblaslt_Cijk_" + ("_".join(m.groups()) if m else "") + ("_" + sk.group(1) if sk else "")
     name = name.replace("unsigned short", "bf16").replace("void ", "").replace("poet::", "").replace("(anonymous namespace)::", "")
     return re.sub(r"\(.*$", "", name)
 
@@ -45,7 +49,7 @@ def per_kernel(path, counters):
 stats = find("trace", "kernel_stats.csv")
 shutil.copy(stats, os.path.join(here, f"{rnd}_{cfg}_kernel_stats.csv"))
 avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(stats))}
-keep = lambda k: k.startswith(("gemm", "msda", "ln_", "gn_", "colsum", "lsa", "adamw", "vgrad", "add_", "mha"))
+keep = lambda k: k.startswith(("gemm", "hipblaslt", "msda", "ln_", "gn_", "colsum", "lsa", "adamw", "vgrad", "add_", "mha"))
 
 fa, fn = per_kernel(find("pmc_fetch", "counter_collection.csv"), {"FETCH_SIZE"})
 wa, wn = per_kernel(find("pmc_write", "counter_collection.csv"), {"WRITE_SIZE"})
