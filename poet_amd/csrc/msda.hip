@@ -414,15 +414,26 @@ __device__ __forceinline__ void sh_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// phase A: lane (head m, level o) -> records of its 4 points; returns what the backward needs.  `row` is wave-uniform.
-template <bool KEEP>
-__device__ __forceinline__ void sh_prepare(const MsdaP& p, int row, int n, int q, int lane, char* wlds, ShGeo& gk) {
-    const int m = lane >> 2, o = lane & 3;
+// phase A: lane (pair = lane >> 2: its (query row, head m); level o = lane & 3) -> records of its 4 points at slot index `pair`;
+// returns what the backward needs.
+struct ShRaw { uint2 lg; uint4 off; };                         // packed logits (4) and offsets (4 x (dx, dy)) of (row, head m, level o)
+__device__ __forceinline__ ShRaw sh_load(const MsdaP& p, int row, int m, int o) {
     const bf16_t* qrow = reinterpret_cast<const bf16_t*>(p.q1) + (int64_t)row * p.ldq;
+    ShRaw r;
+    r.lg = *reinterpret_cast<const uint2*>(qrow + p.logit_col + m * 16 + o * 4);
+    r.off = *reinterpret_cast<const uint4*>(qrow + (m * 4 + o) * 8);
+    return r;
+}
+template <bool KEEP>
+__device__ __forceinline__ void sh_prepare(const MsdaP& p, const ShRaw& raw, float2 rf, int n, int m, int lane, char* wlds, ShGeo& gk) {
+    const int pair = lane >> 2, o = lane & 3;
     float lg[4], off[8];
-    vec<bf16_t, 4>::ld(qrow + p.logit_col + m * 16 + o * 4, lg);
-    vec<bf16_t, 8>::ld(qrow + (m * 4 + o) * 8, off);
-    const float2 rf = *reinterpret_cast<const float2*>(p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * 4 + o) * 2);
+    lg[0] = __uint_as_float(raw.lg.x << 16); lg[1] = __uint_as_float(raw.lg.x & 0xffff0000u);
+    lg[2] = __uint_as_float(raw.lg.y << 16); lg[3] = __uint_as_float(raw.lg.y & 0xffff0000u);
+    off[0] = __uint_as_float(raw.off.x << 16); off[1] = __uint_as_float(raw.off.x & 0xffff0000u);
+    off[2] = __uint_as_float(raw.off.y << 16); off[3] = __uint_as_float(raw.off.y & 0xffff0000u);
+    off[4] = __uint_as_float(raw.off.z << 16); off[5] = __uint_as_float(raw.off.z & 0xffff0000u);
+    off[6] = __uint_as_float(raw.off.w << 16); off[7] = __uint_as_float(raw.off.w & 0xffff0000u);
     // softmax over the 16 logits of (query, head): 4 per lane, quad reductions
     float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
     mx = fmaxf(mx, quad_xor1(mx)); mx = fmaxf(mx, quad_xor2(mx));
@@ -438,7 +449,7 @@ __device__ __forceinline__ void sh_prepare(const MsdaP& p, int row, int n, int q
     const float rx = rf.x * (float)Wl - 0.5f, ry = rf.y * (float)Hl - 0.5f;
     const uint32_t pix_bytes = (uint32_t)p.vs_s * 2u;
     const uint32_t base = (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m) * 2) + (uint32_t)Sl * pix_bytes;
-    char* rec = wlds + (o * 4) * 256 + m * 16;
+    char* rec = wlds + (o * 4) * 256 + pair * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float aw = e[i] * inv;
@@ -467,101 +478,140 @@ __device__ __forceinline__ void sh_prepare(const MsdaP& p, int row, int n, int q
     sh_wave_sync();              // the records are read by other lanes of THIS wave only
 }
 
+// Which (query row, head) a lane group of 4 works on.  QG = 1: the 16 groups of a wave are the 16 heads of ONE query.  QG = 4:
+// they are 4 CONSECUTIVE queries x 4 heads, and the wave makes 4 passes over the head quarters: neighbouring queries of the
+// encoder are neighbouring pixels whose samples fall into the same 128-byte lines of a head's value map, so a gather
+// instruction touches ~6-8 distinct lines instead of 16 (the L1 works through a wave's request line by line).
+template <int QG>
+struct ShMap {
+    int row, n, q, hh;
+    bool live;
+    __device__ __forceinline__ ShMap(const MsdaP& p, int64_t unit, int lane, int64_t rows) {
+        const int pair = lane >> 2;
+        const int qq = QG == 1 ? 0 : pair / (16 / QG);
+        hh = QG == 1 ? pair : pair % (16 / QG);
+        const int64_t r64 = unit * QG + qq;
+        live = r64 < rows;
+        row = (int)(live ? r64 : rows - 1);
+        n = row / p.Lq;
+        q = row - n * p.Lq;
+    }
+};
+
+template <int QG>
 __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const MsdaP p) {
     __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t rows = (int64_t)p.N * p.Lq;
-    const int64_t row64 = xcd_contiguous_block(blockIdx.x, gridDim.x) * SH_WAVES + wave;
-    if (row64 >= rows) return;                                      // wave-uniform
-    const int row = __builtin_amdgcn_readfirstlane((int)row64);
-    const int n = row / p.Lq, q = row - n * p.Lq;
+    const int64_t unit = xcd_contiguous_block(blockIdx.x, gridDim.x) * SH_WAVES + wave;      // QG consecutive query rows
+    if (unit * QG >= rows) return;                                  // wave-uniform
+    const ShMap<QG> mp(p, unit, lane, rows);
     char* wlds = lds + wave * SH_WAVE;
-    ShGeo unused;
-    sh_prepare<false>(p, row, n, q, lane, wlds, unused);
-    // gather lanes: [head m][x corner xc][channel half]
-    const int m = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
-    const char* rd = wlds + xc * SH_PLANE + m * 16;
+    // gather lanes: [pair][x corner xc][channel half]
+    const int pair = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
+    const char* rd = wlds + xc * SH_PLANE + pair * 16;
     const uint32_t lane_off = (uint32_t)dsub * 16u;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the reference point of (row, level o) serves every pass.  (Requesting the NEXT pass's packed logits / offsets before this
+    // pass's gathers was slower, 164 / 218 us against 156 / 200: memory returns in order, and an HBM-latency stream load ahead of
+    // the L2-served gathers delays all of them.)
+    const float2 rf = *reinterpret_cast<const float2*>(p.ref + (int64_t)mp.n * p.ref_bs + ((int64_t)mp.q * 4 + (lane & 3)) * 2);
 #pragma unroll 1
-    for (int l = 0; l < 4; ++l) {
-        uint4 r[4];
+    for (int pass = 0; pass < QG; ++pass) {
+        const int m = pass * (16 / QG) + mp.hh;
+        ShGeo unused;
+        const ShRaw raw = sh_load(p, mp.row, m, lane & 3);
+        sh_prepare<false>(p, raw, rf, mp.n, m, lane, wlds, unused);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) {
+            uint4 r[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(rd + (l * 4 + i) * 256);
-        Raw8<bf16_t> v0[4], v1[4];
+            for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(rd + (l * 4 + i) * 256);
+            Raw8<bf16_t> v0[4], v1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
+            for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float w0 = __uint_as_float(r[i].z), w1 = __uint_as_float(r[i].w);
+            for (int i = 0; i < 4; ++i) {
+                const float w0 = __uint_as_float(r[i].z), w1 = __uint_as_float(r[i].w);
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[i].f(ch), acc[ch]);
+                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[i].f(ch), acc[ch]);
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
+                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
+            }
+        }
+        sh_wave_sync();                                             // (the next pass overwrites the records)
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) acc[ch] += quad_xor2(acc[ch]);   // the two x corners
+        if (!xc && mp.live) {
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (int64_t)mp.row * 256 + m * 16 + dsub * 8;
+            vec<bf16_t, 8>::st(op, acc);
         }
     }
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) acc[ch] += quad_xor2(acc[ch]);   // the two x corners
-    if (xc) return;
-    bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (int64_t)row * 256 + m * 16 + dsub * 8;
-    vec<bf16_t, 8>::st(op, acc);
 }
 
+template <int QG>
 __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const MsdaP p) {
     __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t rows = (int64_t)p.N * p.Lq;
-    const int64_t row64 = xcd_contiguous_block(blockIdx.x, gridDim.x) * SH_WAVES + wave;
-    if (row64 >= rows) return;
-    const int row = __builtin_amdgcn_readfirstlane((int)row64);
-    const int n = row / p.Lq, q = row - n * p.Lq;
+    const int64_t unit = xcd_contiguous_block(blockIdx.x, gridDim.x) * SH_WAVES + wave;
+    if (unit * QG >= rows) return;
+    const ShMap<QG> mp(p, unit, lane, rows);
     char* wlds = lds + wave * SH_WAVE;
-    ShGeo gk;
-    sh_prepare<true>(p, row, n, q, lane, wlds, gk);
-    const int m = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
-    char* slot = wlds + xc * SH_PLANE + m * 16;
+    const int pair = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1, o = lane & 3;
+    char* slot = wlds + xc * SH_PLANE + pair * 16;
+    const char* own = wlds + (o * 4) * 256 + pair * 16;
     const uint32_t lane_off = (uint32_t)dsub * 16u;
-    // grad_out stays packed: <grad_out, value> over a lane's 8 channels is 4 v_dot2c_f32_bf16 (exact bf16 products, fp32 sum)
-    const u32x4_t g = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.grad_out) + (int64_t)row * 256 + m * 16 + dsub * 8);
+    bf16_t* grow = reinterpret_cast<bf16_t*>(p.g1) + (int64_t)mp.row * p.ldg;
+    const float2 rf = *reinterpret_cast<const float2*>(p.ref + (int64_t)mp.n * p.ref_bs + ((int64_t)mp.q * 4 + o) * 2);
 #pragma unroll 1
-    for (int l = 0; l < 4; ++l) {
-        uint2 r[4];
+    for (int pass = 0; pass < QG; ++pass) {
+        const int m = pass * (16 / QG) + mp.hh;
+        ShGeo gk;
+        const ShRaw raw = sh_load(p, mp.row, m, o);
+        sh_prepare<true>(p, raw, rf, mp.n, m, lane, wlds, gk);
+        // grad_out stays packed: <grad_out, value> over a lane's 8 channels is 4 v_dot2c_f32_bf16 (exact bf16 products, fp32 sum)
+        const u32x4_t g = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.grad_out) + (int64_t)mp.row * 256 + m * 16 + dsub * 8);
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) {
+            uint2 r[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint2*>(slot + (l * 4 + i) * 256);
-        Raw8<bf16_t> v0[4], v1[4];
+            for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint2*>(slot + (l * 4 + i) * 256);
+            Raw8<bf16_t> v0[4], v1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
+            for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)     // this lane's partial <grad_out, value> of the upper / lower corner, into its half of the slot it consumed
-            *reinterpret_cast<float2*>(slot + (l * 4 + i) * 256 + dsub * 8) = make_float2(dot8_packed(g, v0[i].v), dot8_packed(g, v1[i].v));
+            for (int i = 0; i < 4; ++i)     // this lane's partial <grad_out, value> of the upper / lower corner, into its half of the slot it consumed
+                *reinterpret_cast<float2*>(slot + (l * 4 + i) * 256 + dsub * 8) = make_float2(dot8_packed(g, v0[i].v), dot8_packed(g, v1[i].v));
+        }
+        sh_wave_sync();
+        // owner lane (pair, level o): d(offsets) and d(attention) of its 4 points
+        float dxy[8], da[4];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 a = *reinterpret_cast<const float4*>(own + i * 256);                 // x corner 0: (d0, d1) of the two channel halves
+            const float4 b = *reinterpret_cast<const float4*>(own + i * 256 + SH_PLANE);      // x corner 1
+            const uint32_t v = gk.valid[i];
+            const float D00 = ((v & 5u) == 5u) ? a.x + a.z : 0.f, D10 = ((v & 9u) == 9u) ? a.y + a.w : 0.f;
+            const float D01 = ((v & 6u) == 6u) ? b.x + b.z : 0.f, D11 = ((v & 10u) == 10u) ? b.y + b.w : 0.f;
+            const float fx = gk.fx[i], fy = gk.fy[i], aw = gk.aw[i];
+            const float e0 = D10 - D00, e1 = D11 - D01;
+            const float T0 = fmaf(fy, e0, D00), T1 = fmaf(fy, e1, D01);
+            da[i] = fmaf(fx, T1 - T0, T0);                                // (1-fx) T0 + fx T1
+            dxy[2 * i] = aw * (T1 - T0);                                  // d/d(offset) = (dpx, dpy): the W,H factors cancel
+            dxy[2 * i + 1] = aw * fmaf(fx, e1 - e0, e0);                  // aw ((1-fx) e0 + fx e1)
+            dot = fmaf(aw, da[i], dot);
+        }
+        sh_wave_sync();                                                   // (the next pass overwrites the slots)
+        dot += quad_xor1(dot); dot += quad_xor2(dot);                     // softmax Jacobian over the 16 points of (query, head)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) da[i] = gk.aw[i] * (da[i] - dot);
+        if (mp.live) {
+            vec<bf16_t, 8>::st(grow + (m * 4 + o) * 8, dxy);
+            vec<bf16_t, 4>::st(grow + p.logit_col + m * 16 + o * 4, da);
+        }
     }
-    sh_wave_sync();
-    // owner lane (head m, level o): d(offsets) and d(attention) of its 4 points
-    const int o = lane & 3;
-    const char* own = wlds + (o * 4) * 256 + m * 16;
-    float dxy[8], da[4];
-    float dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 a = *reinterpret_cast<const float4*>(own + i * 256);                 // x corner 0: (d0, d1) of the two channel halves
-        const float4 b = *reinterpret_cast<const float4*>(own + i * 256 + SH_PLANE);      // x corner 1
-        const uint32_t v = gk.valid[i];
-        const float D00 = ((v & 5u) == 5u) ? a.x + a.z : 0.f, D10 = ((v & 9u) == 9u) ? a.y + a.w : 0.f;
-        const float D01 = ((v & 6u) == 6u) ? b.x + b.z : 0.f, D11 = ((v & 10u) == 10u) ? b.y + b.w : 0.f;
-        const float fx = gk.fx[i], fy = gk.fy[i], aw = gk.aw[i];
-        const float e0 = D10 - D00, e1 = D11 - D01;
-        const float T0 = fmaf(fy, e0, D00), T1 = fmaf(fy, e1, D01);
-        da[i] = fmaf(fx, T1 - T0, T0);                                // (1-fx) T0 + fx T1
-        dxy[2 * i] = aw * (T1 - T0);                                  // d/d(offset) = (dpx, dpy): the W,H factors cancel
-        dxy[2 * i + 1] = aw * fmaf(fx, e1 - e0, e0);                  // aw ((1-fx) e0 + fx e1)
-        dot = fmaf(aw, da[i], dot);
-    }
-    dot += quad_xor1(dot); dot += quad_xor2(dot);                     // softmax Jacobian over the 16 points of (query, head)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) da[i] = gk.aw[i] * (da[i] - dot);
-    bf16_t* grow = reinterpret_cast<bf16_t*>(p.g1) + (int64_t)row * p.ldg;
-    vec<bf16_t, 8>::st(grow + (m * 4 + o) * 8, dxy);
-    vec<bf16_t, 4>::st(grow + p.logit_col + m * 16 + o * 4, da);
 }
 
 // d(value): pure scatter, no value loads.  One lane per channel: the D lanes of a (query, head) add D consecutive
@@ -1291,11 +1341,17 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
         const int64_t rows = (int64_t)p.N * p.Lq;
         if (!no_shared && P == 4 && p.M == 16 && p.D == 16 && rows < (1ll << 31) && (p.ldq % 8) == 0 && (p.logit_col % 4) == 0 &&
             (p.ref_bs % 2) == 0) {
-            const dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES)), blk(SH_WAVES * 64);
+            // POET_SH_QGROUP=1: one query x 16 heads per wave; default 4 consecutive queries x 4 heads, 4 passes
+            const char* qg_ = getenv("POET_SH_QGROUP");
+            const int qg = qg_ && atoi(qg_) == 1 ? 1 : 4;          // (2 and 8 measured within 5 % of 4, 16 no better than 1)
+            const dim3 grid((unsigned)((rows + SH_WAVES * qg - 1) / (SH_WAVES * qg))), blk(SH_WAVES * 64);
             const char* pad_ = getenv("POET_SH_PADLDS");          // experiment: extra LDS per workgroup (lowers the occupancy)
             const size_t dyn = pad_ ? (size_t)atoi(pad_) : 0;
-            if (BWD) hipLaunchKernelGGL(msda_bwd_shared_kernel, grid, blk, dyn, st, p);
-            else hipLaunchKernelGGL(msda_fwd_shared_kernel, grid, blk, dyn, st, p);
+#define POET_SH_LAUNCH(Q) do { if (BWD) hipLaunchKernelGGL(msda_bwd_shared_kernel<Q>, grid, blk, dyn, st, p); \
+                               else hipLaunchKernelGGL(msda_fwd_shared_kernel<Q>, grid, blk, dyn, st, p); } while (0)
+            if (qg == 1) POET_SH_LAUNCH(1);
+            else POET_SH_LAUNCH(4);
+#undef POET_SH_LAUNCH
             return;
         }
     }
