@@ -821,10 +821,16 @@ class GraphedTrainer(Trainer):
         dev = self.s_tb.device
         tb = None
         if n:
-            tb = torch.cat([t["boxes"].reshape(-1, 4) for t in targets], 0).to(dev, non_blocking=True).float()
-            self.s_tb[:n].copy_(tb, non_blocking=True)
-            self.s_tpos[:n].copy_(torch.cat([t["relative_position"] for t in targets], 0).to(dev, non_blocking=True), non_blocking=True)
-            self.s_trot[:n].copy_(torch.cat([t["relative_rotation"] for t in targets], 0).to(dev, non_blocking=True), non_blocking=True)
+            def gather(key, dst, shape):                        # device-resident fp32 fields: concatenated straight into the static buffer
+                parts = [t[key].reshape(shape) for t in targets]
+                if all(x.is_cuda and x.dtype == dst.dtype for x in parts):
+                    torch.cat(parts, 0, out=dst[:n])
+                else:
+                    dst[:n].copy_(torch.cat(parts, 0).to(dev, non_blocking=True), non_blocking=True)
+                return dst[:n]
+            tb = gather("boxes", self.s_tb, (-1, 4))
+            gather("relative_position", self.s_tpos, (-1, 3))
+            gather("relative_rotation", self.s_trot, (-1, 3, 3))
         if queries:
             self.s_boxes.fill_(-1.0)
             self.s_cls.fill_(-1)
@@ -840,10 +846,11 @@ class GraphedTrainer(Trainer):
         m, dev = self.model, self.arena.flat.device
         features, boxes, classes, valid, _ = self._static_inputs(samples, targets)
         self.s_feats = [f.tensors for f in features]
-        self.s_fmasks = [(f.mask.contiguous().view(torch.uint8) if f.mask.dtype == torch.bool else f.mask.contiguous()).clone()
-                         for f in features]
-        im = samples.mask
-        self.s_imask = (im.contiguous().view(torch.uint8) if im.dtype == torch.bool else im.contiguous()).clone()
+        # static mask buffers = the caller's own tensors (no clone): a backbone / loader that hands over the same buffers every
+        # step costs no copy at all (as for the feature maps); anything else is copied into them each step
+        u8 = lambda t: t.contiguous().view(torch.uint8) if t.dtype == torch.bool else t.contiguous()
+        self.s_fmasks = [u8(f.mask) for f in features]
+        self.s_imask = u8(samples.mask)
         # pinned staging ring: the host may run several steps ahead of the GPU, so a slot is only rewritten after the
         # H2D copies that read it have completed (event per slot)
         self.ring = [dict(boxes=torch.from_numpy(boxes.copy()).pin_memory(), cls=torch.from_numpy(classes.copy()).pin_memory(),
@@ -971,9 +978,11 @@ class GraphedTrainer(Trainer):
         for f, sf, sm in zip(features, self.s_feats, self.s_fmasks):
             if f.tensors.data_ptr() != sf.data_ptr():
                 sf.copy_(f.tensors, non_blocking=True)
-            sm.copy_(f.mask.view(torch.uint8) if f.mask.dtype == torch.bool else f.mask, non_blocking=True)
+            if f.mask.data_ptr() != sm.data_ptr():
+                sm.copy_(f.mask.view(torch.uint8) if f.mask.dtype == torch.bool else f.mask, non_blocking=True)
         im = samples.mask                                   # the extra levels' masks / valid ratios / sine encodings derive from it
-        self.s_imask.copy_(im.view(torch.uint8) if im.dtype == torch.bool else im, non_blocking=True)
+        if im.data_ptr() != self.s_imask.data_ptr():
+            self.s_imask.copy_(im.view(torch.uint8) if im.dtype == torch.bool else im, non_blocking=True)
         if on_device:
             self._stage_targets(targets, queries=True)
             self.g_fwd.replay()
