@@ -5,8 +5,10 @@
 // the tiled kernel.  Here one wave owns one 16x16 output tile and loads BOTH operands straight from global memory in
 // MFMA operand layout -- no LDS, no barrier, one memory round trip:
 //   v_mfma_f32_16x16x4_f32 takes A[i = lane&15][k = lane>>4]; the contraction is invariant under a permutation of k that
-//   is applied to both operands, so lane group g = lane>>4 is given the CONTIGUOUS k range [g*K/4, (g+1)*K/4) and MFMA
-//   number t consumes element t of that range: every lane reads K/4 consecutive floats of one row with 16-byte loads.
+//   is applied to both operands, so lane group g = lane>>4 is given the 16-byte pieces g, g+4, g+8, ... of a row: one load
+//   instruction of the wave then covers 64 contiguous bytes of each of its 16 rows -- 16 cache-line requests.  (Giving
+//   each group a contiguous quarter of K instead makes every load touch 64 different lines: measured 6.8 us for the
+//   320x256x256 Linear with everything in L2, the vector-memory unit's line rate, not latency, being the bound.)
 // Four accumulators (element x/y/z/w of each float4) break the 64-deep dependent MFMA chain.
 #include "gemm.cuh"
 
@@ -36,28 +38,28 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmK p) {
     __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
     const PoetGemmDesc& d = p.d;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int tn = (d.N + 15) >> 4, tile = SPLIT ? blockIdx.x : blockIdx.x * 4 + wid;
+    const int tn = (d.N + 15) >> 4, tile = SPLIT ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wid;
     const int m0 = (tile / tn) << 4, n0 = (tile % tn) << 4;
     if (m0 >= d.M) return;                                              // SPLIT: workgroup-uniform
     const int r = lane & 15, g = lane >> 4;
     const int kw = SPLIT ? d.K >> 2 : d.K, kbase = SPLIT ? wid * kw : 0; // this wave's K range
-    const int kq = kw >> 2;                                             // floats per lane group, multiple of 4
+    const int kq = kw >> 2;                                             // floats per lane group, multiple of 4: float4 j of group g = floats [16 j + 4 g, +4) of the range
     const int ncol = min(n0 + r, d.N - 1);                              // ragged N: clamp the operand, mask the store
     const int64_t zb = blockIdx.y;                                      // batch entry (independent problems of one shape)
-    const float* ap = reinterpret_cast<const float*>(d.A) + zb * d.strideA + (int64_t)min(m0 + r, d.M - 1) * d.lda + kbase + g * kq;
+    const float* ap = reinterpret_cast<const float*>(d.A) + zb * d.strideA + (int64_t)min(m0 + r, d.M - 1) * d.lda + kbase + g * 4;
     const float* wb = reinterpret_cast<const float*>(d.B) + zb * d.strideB;
-    const float* wp = BKM ? wb + (int64_t)(kbase + g * kq) * d.ldb + ncol : wb + (int64_t)ncol * d.ldb + kbase + g * kq;
+    const float* wp = BKM ? wb + (int64_t)(kbase + g * 4) * d.ldb + ncol : wb + (int64_t)ncol * d.ldb + kbase + g * 4;
     f32x4_t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int k0 = 0; k0 < kq; k0 += 64) {                               // 64 floats per operand per trip
         float4 a[16], w[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const bool ok = k0 + i * 4 < kq;
-            a[i] = ok ? *reinterpret_cast<const float4*>(ap + k0 + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[i] = ok ? *reinterpret_cast<const float4*>(ap + (k0 + i * 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (!BKM) {
-                w[i] = ok ? *reinterpret_cast<const float4*>(wp + k0 + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[i] = ok ? *reinterpret_cast<const float4*>(wp + (k0 + i * 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                const float* q = wp + (int64_t)(k0 + i * 4) * d.ldb;
+                const float* q = wp + (int64_t)((k0 + i * 4) * 4) * d.ldb;
                 w[i] = ok ? make_float4(q[0], q[d.ldb], q[2 * d.ldb], q[3 * d.ldb]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -227,13 +229,16 @@ bool gemm_small_try(const GemmK& p, hipStream_t st) {
     if (!d.b_kmajor && !p.b_vec) return false;
     const int tiles = ((d.M + 15) >> 4) * ((d.N + 15) >> 4);
     const bool split = d.K >= 512 && d.K % 64 == 0;                      // long reductions: 4 waves share one tile
-    const dim3 grid(split ? tiles : (tiles + 3) / 4, d.batch);
+    // whole-K tiles: one wave each; single-wave workgroups until every CU has a few (320 tiles = 80 4-wave workgroups would
+    // leave two thirds of the chip -- and of its L1s -- idle)
+    const int wpb = (split || (int64_t)tiles * d.batch > 2048) ? 4 : 1;
+    const dim3 grid(split ? tiles : (tiles + wpb - 1) / wpb, d.batch), block(64 * wpb);
     if (d.b_kmajor) {
-        if (split) hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, dim3(256), 0, st, p);
+        if (split) hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, block, 0, st, p);
     } else {
-        if (split) hipLaunchKernelGGL((gemm_small_kernel<false, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, dim3(256), 0, st, p);
+        if (split) hipLaunchKernelGGL((gemm_small_kernel<false, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, block, 0, st, p);
     }
     return true;
 }
