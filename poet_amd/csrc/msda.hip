@@ -690,12 +690,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int J>
 __device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false); }
 
+// sample J of the row's query: f(byte address of the left pixel of corner row k, weight of its left corner, of its right corner)
 template <int LP, int J = 0, typename F>
-__device__ __forceinline__ void row_points(const int (&cidx)[4], const float (&cw)[4], F&& f) {
+__device__ __forceinline__ void row_points(const int (&arow)[2], const float (&cw)[4], F&& f) {
     if constexpr (J < LP) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f(row_bcast<J>(cidx[k]), __int_as_float(row_bcast<J>(__float_as_int(cw[k]))));
-        row_points<LP, J + 1>(cidx, cw, f);
+        for (int k = 0; k < 2; ++k)
+            f(row_bcast<J>(arow[k]), __int_as_float(row_bcast<J>(__float_as_int(cw[2 * k]))), __int_as_float(row_bcast<J>(__float_as_int(cw[2 * k + 1]))));
+        row_points<LP, J + 1>(arow, cw, f);
     }
 }
 
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m = blockIdx.y, n = blockIdx.z;
     int wx0[L], wy0[L], ww[L], wh[L], wp[L], loff[L + 1];    // loff in pixels; wp = LDS row pitch of the window
-    loff[0] = 0;
+    loff[0] = 1;                                             // one pad pixel in front (see `arow` below)
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const int W = p.W[l], H = p.H[l];
@@ -798,10 +800,10 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     float* gvb = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;
     bf16_t* gvb16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;       // (gv_bf16)
     const int lane_off = c * 4;
-    // One dummy pixel per DPP row of the wave, behind the windows.  (The LDS atomic unit works through a ds_add 16 lanes
+    // Two dummy pixels per DPP row of the wave, behind the windows.  (The LDS atomic unit works through a ds_add 16 lanes
     // = one pixel = 16 consecutive banks at a time, so the 4 rows of a wave never conflict with each other: measured, a
-    // bank-quarter-aware corner order changes nothing.  The kernel is bound by the ~8 cycles the unit takes per ds_add.)
-    const int dummy = (loff[L] + r) * 64;
+    // bank-quarter-aware corner order changes nothing.)
+    const int dummy = (loff[L] + 2 * r) * 64;
 
     // ONE loop over the tile's queries of ALL levels (a flat index, the query's own level found by three compares): the
     // per-level loops cost a partly idle last round EACH -- at 640x480 a tile holds 300 + 75 + 20 + 6 queries, i.e. 5 + 2 + 1 + 1
@@ -868,11 +870,15 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             const bool iy_in[2] = {(unsigned)y0 < (unsigned)Hl, (unsigned)(y0 + 1) < (unsigned)Hl};
             const float wxv[2] = {1.f - fx, fx}, wyv[2] = {(1.f - fy) * aj, fy * aj};
             const int base = lo + ly0 * lwp + lx0;           // window slot corner 0 has (or would have)
-            // Per corner: window slot (>= 0) or -1 (nothing for the window: outside it, or outside the image -- at the coarse
-            // levels a +-4 px offset leaves an 8x10 map all the time).  Those go with weight 0 to a per-row dummy pixel behind
-            // the windows, so the accumulate loop below is branch-free; the rare in-image-but-outside-the-window corners are
-            // added with global atomics in a wave-voted second pass, and the result never depends on the halo.
-            int cidx[4];
+            // Per sample: the LDS byte address of the LEFT pixel of its upper and of its lower corner row, and corner weights
+            // that are 0 when the corner has nothing for the window (outside it, or outside the image -- at the coarse levels
+            // a +-4 px offset leaves an 8x10 map all the time).  The right corner is the next pixel in memory (+64 B, the
+            // ds_add's immediate offset: one address per corner ROW).  A zero weight adds nothing WHEREVER it lands, so the
+            // address only has to stay inside the allocation: a row with one corner in the window keeps its address (the
+            // other corner falls on the neighbouring pixel in memory -- the pad pixel in front of the windows when that is
+            // pixel -1), a row with none goes to the DPP row's two dummy pixels behind the windows.  The accumulate loop is
+            // branch-free; the rare in-image-but-outside-the-window corners are added with global atomics in a wave-voted
+            // second pass, and the result never depends on the halo.
             float cw[4], cfar[4];
             bool far = false;
 #pragma unroll
@@ -880,20 +886,20 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
                 const float wgt = wyv[k >> 1] * wxv[k & 1];
                 const bool inw = wx_in[k & 1] && wy_in[k >> 1] && has;
                 const bool inimg = ix_in[k & 1] && iy_in[k >> 1] && has;
-                cidx[k] = inw ? base + (k & 1) + (k >> 1) * lwp : -1;
                 cw[k] = inw ? wgt : 0.f;
                 cfar[k] = (inimg && !inw) ? wgt : 0.f;       // (the windows are clipped to the image: inw implies inimg)
                 far |= cfar[k] != 0.f;
             }
-            int coff[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) coff[k] = cidx[k] >= 0 ? cidx[k] * 64 : dummy;
-            // ---- broadcast point by point to the channel lanes; int32 LDS accumulate ----
-            // 3 VALU + 1 LDS op per corner: v_mul_f32_dpp (weight broadcast folded: row_newbcast, no ds_bpermute on the
-            // pipe the atomics use), v_cvt_rpi, v_add_u32_dpp (the owner lane ships BYTE offsets, so the index
-            // broadcast folds into the address add), ds_add_u32
-            row_points<LP>(coff, cw, [&](int off, float wv) {
-                atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (off + lane_off)), cvt_rpi(wv * gs));
+            const bool any_x = (wx_in[0] || wx_in[1]) && has;
+            const int arow[2] = {(wy_in[0] && any_x) ? base * 64 : dummy, (wy_in[1] && any_x) ? (base + lwp) * 64 : dummy};
+            // ---- broadcast sample by sample to the channel lanes; int32 LDS accumulate ----
+            // 5 VALU + 2 LDS ops per corner row: v_add_u32_dpp (the owner lane ships BYTE addresses, so the broadcast -- DPP
+            // row_newbcast, no ds_bpermute on the pipe the atomics use -- folds into the address add), and per corner
+            // v_mul_f32_dpp (weight broadcast folded), v_cvt_rpi, ds_add_u32
+            row_points<LP>(arow, cw, [&](int off, float w0, float w1) {
+                int* a = reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (off + lane_off));
+                atomicAdd(a, cvt_rpi(w0 * gs));
+                atomicAdd(a + 16, cvt_rpi(w1 * gs));
             });
             // In-image corners outside the window: global atomics, one far POINT at a time (its owner lane found by ballot, its
             // corner data read with v_readlane, applied by the 16 channel lanes of its row).  Cost is proportional to the number
@@ -927,7 +933,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     // live across the accumulate loop, its ~25 uniform values push the kernel past the SGPR file and into scratch memory.
     int txf = tx, tyf = ty;
     asm volatile("" : "+s"(txf), "+s"(tyf));
-    int lofff = 0;
+    int lofff = 1;                                            // (behind the pad pixel)
     // (explicit calls with constant level indices: see qgeo above)
     auto flush_level = [&, txf, tyf](int W, int H, int start) __attribute__((always_inline)) {
         const int ax = max((txf * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((txf + 1) * W, tp.TX) + tp.HALO, W);
@@ -1255,11 +1261,11 @@ static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
                     }
                     worst = max(worst, px);
                 }
-            if (worst + 4 <= (size_t)(150 * 1024 / 64)) { tp.TX = tx; tp.TY = ty; tp.HALO = halo; tp.skip = 0; return (worst + 4) * 64; }
+            if (worst + 9 <= (size_t)(150 * 1024 / 64)) { tp.TX = tx; tp.TY = ty; tp.HALO = halo; tp.skip = 0; return (worst + 9) * 64; }
         }
     }
-    // 150 KB of int32 windows (one 1024-thread workgroup per CU; 640x480 fits a 4x4 tiling) + 4 dummy pixels (see the kernel)
-    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 4) * 16 * 4;
+    // 150 KB of int32 windows (one 1024-thread workgroup per CU) + 1 pad pixel + 8 dummy pixels (see the kernel)
+    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 9) * 16 * 4;
 }
 
 template <typename TV, typename TQ, int L, bool BWD>
