@@ -829,19 +829,31 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     const int W0 = p.W[0], W1 = p.W[L > 1 ? 1 : 0], W2 = p.W[L > 2 ? 2 : 0], W3 = p.W[L > 3 ? 3 : 0];
     {
         const int nq = (tp.skip & 2) ? 0 : c4;
+        // The workgroup's 64 query slots sweep the flat order together (slot s takes queries s, s + 64, ...: 64 consecutive
+        // rows of grad_out / offsets / logits per iteration; per-wave or per-slot contiguous runs measured SLOWER at 1280x960).
+        // A lane keeps the constants of its current level (tile-row width and its reciprocal, first query, image row pitch) in
+        // registers and only re-derives them -- three compares and five 4-way selects, ~30 VALU instructions -- when it steps
+        // into the next level.
         // software prefetch: the operands of query i + NSLOT are in flight while query i is scattered
         float n_g = 0.f, n_lg = -3.0e38f, n_ox = 0.f, n_oy = 0.f, n_rx = 0.f, n_ry = 0.f;
-#define DV_FETCH(I)                                                                                                   \
+        int cbase = 0, cend = 0, cqw = 1, cqb = 0, cW = 0;      // cursor: flat range [cbase, cend) of the current level, ...
+        float ciw = 1.f;
+#define DV_LEVEL(I)                                                                                                   \
         do {                                                                                                          \
             const int fi_ = (I);                                                                                      \
             const bool s1_ = L > 1 && fi_ >= c1, s2_ = L > 2 && fi_ >= c2, s3_ = L > 3 && fi_ >= c3;                    \
-            const int li_ = fi_ - (s3_ ? c3 : s2_ ? c2 : s1_ ? c1 : 0);                                               \
-            const int qw_ = s3_ ? g3.qw : s2_ ? g2.qw : s1_ ? g1.qw : g0.qw;                                          \
-            const int qb_ = s3_ ? g3.qb : s2_ ? g2.qb : s1_ ? g1.qb : g0.qb;                                          \
-            const int Wq_ = s3_ ? W3 : s2_ ? W2 : s1_ ? W1 : W0;                                                      \
-            const float iw_ = s3_ ? g3.iw : s2_ ? g2.iw : s1_ ? g1.iw : g0.iw;                                        \
-            const int iy_ = idiv_small(li_, qw_, iw_);                                                                \
-            const int q_ = qb_ + iy_ * Wq_ + (li_ - iy_ * qw_);                                                       \
+            cbase = s3_ ? c3 : s2_ ? c2 : s1_ ? c1 : 0;                                                               \
+            cend = s3_ ? c4 : s2_ ? c3 : s1_ ? c2 : c1;                                                               \
+            cqw = s3_ ? g3.qw : s2_ ? g2.qw : s1_ ? g1.qw : g0.qw;                                                    \
+            cqb = s3_ ? g3.qb : s2_ ? g2.qb : s1_ ? g1.qb : g0.qb;                                                    \
+            cW = s3_ ? W3 : s2_ ? W2 : s1_ ? W1 : W0;                                                                 \
+            ciw = s3_ ? g3.iw : s2_ ? g2.iw : s1_ ? g1.iw : g0.iw;                                                    \
+        } while (0)
+#define DV_FETCH(I)                                                                                                   \
+        do {                                                                                                          \
+            const int li_ = (I) - cbase;                                                                              \
+            const int iy_ = idiv_small(li_, cqw, ciw);                                                                \
+            const int q_ = cqb + iy_ * cW + (li_ - iy_ * cqw);                                                        \
             const uint32_t row_ = (uint32_t)(row0 + q_);                                                              \
             n_g = bf2f(ldg32<TQ>(p.grad_out, row_ * g_row + g_lane));                                                 \
             const uint32_t oxy_ = ldg32<uint32_t>(p.q1, row_ * q_row + of_lane);   /* (off_x, off_y) bf16 pair */      \
@@ -851,11 +863,14 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             const float2 rf_ = ldg32<float2>(p.ref, (uint32_t)q_ * rf_q + rf_lane);                                   \
             n_rx = rf_.x; n_ry = rf_.y;                                                                               \
         } while (0)
-        if (slot < nq) DV_FETCH(slot);
+        if (slot < nq) { DV_LEVEL(slot); DV_FETCH(slot); }
 #pragma unroll 1
         for (int i = slot; i < nq; i += NSLOT) {
             const float gs = n_g * scale, lg = n_lg, ox = n_ox, oy = n_oy, rx = n_rx, ry = n_ry;
-            if (i + NSLOT < nq) DV_FETCH(i + NSLOT);
+            if (i + NSLOT < nq) {
+                if (i + NSLOT >= cend) DV_LEVEL(i + NSLOT);
+                DV_FETCH(i + NSLOT);
+            }
             // ---- lane j (< L*P) of the slot prepares sample point j: softmax over the DPP row, then its 4 corners ----
             const float mx = row16_max(lg);
             const float e = __expf(lg - mx);                             // lanes without a point carry -3e38: e = 0
