@@ -679,8 +679,16 @@ template <int N>
 __device__ __forceinline__ float row_ror(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
 }
+// (v_max_f32 with the rotation folded in as its DPP operand: written through fmaxf, every step costs a v_mov_dpp, the max
+// and two canonicalising v_max v, v, v -- 12 instructions for the 4 below.  s_nop 1: a DPP operand written by the previous
+// VALU instruction needs two wait states, and the hazard recogniser does not look inside inline assembly.)
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, row_ror<1>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<4>(v)); return fmaxf(v, row_ror<8>(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
     v += row_ror<1>(v); v += row_ror<2>(v); v += row_ror<4>(v); return v + row_ror<8>(v);
@@ -894,16 +902,14 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             // pixel -1), a row with none goes to the DPP row's two dummy pixels behind the windows.  The accumulate loop is
             // branch-free; the rare in-image-but-outside-the-window corners are added with global atomics in a wave-voted
             // second pass, and the result never depends on the halo.
-            float cw[4], cfar[4];
-            bool far = false;
+            float cw[4], wgt[4];
+            bool far = false;                                // (mask arithmetic only; the far weights are formed in the rare branch)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float wgt = wyv[k >> 1] * wxv[k & 1];
+                wgt[k] = wyv[k >> 1] * wxv[k & 1];
                 const bool inw = wx_in[k & 1] && wy_in[k >> 1] && has;
-                const bool inimg = ix_in[k & 1] && iy_in[k >> 1] && has;
-                cw[k] = inw ? wgt : 0.f;
-                cfar[k] = (inimg && !inw) ? wgt : 0.f;       // (the windows are clipped to the image: inw implies inimg)
-                far |= cfar[k] != 0.f;
+                cw[k] = inw ? wgt[k] : 0.f;
+                far |= ix_in[k & 1] && iy_in[k >> 1] && has && !inw;      // (the windows are clipped to the image: inw implies inimg)
             }
             const bool any_x = (wx_in[0] || wx_in[1]) && has;
             const int arow[2] = {(wy_in[0] && any_x) ? base * 64 : dummy, (wy_in[1] && any_x) ? (base + lwp) * 64 : dummy};
@@ -924,6 +930,10 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             if (fmask) {
                 const int gp0 = startl + y0 * Wl + x0;
                 const float gsi = gs * inv;
+                float cfar[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    cfar[k] = (ix_in[k & 1] && iy_in[k >> 1] && has && !(wx_in[k & 1] && wy_in[k >> 1])) ? wgt[k] : 0.f;
                 while (fmask) {
                     const int src = __ffsll((long long)fmask) - 1;
                     fmask &= fmask - 1;
