@@ -186,19 +186,41 @@ def test_rotation_modes_fp32_vs_reference_golden(gpu, golden_dir, rotation_mode,
         t2, _ = tr.step(r["samples"], r["targets"])
         assert np.isfinite(float(t1)) and np.isfinite(float(t2))
         return
-    # quaternion modes: HIP-graph replay (single and segmented backward) == eager, dropout off
-    runs = {}
+    # quaternion modes: HIP-graph replay (single and segmented backward) == eager, dropout off.
+    # Two training runs of ONE mode already differ (measured, scratch/seg_dbg4.py: eager vs eager lands on one of two
+    # trajectories just like eager vs graph): the fp32 atomics of the decoder's value-gradient scatter add in a different order
+    # every run, the parameters after the first AdamW step differ by ~1e-7, that flips a bf16 rounding of an activation in
+    # the next forward, the next gradients differ by ~1e-4 of their maximum in ~9 % of the elements, AdamW's m / sqrt(v)
+    # normalisation turns that into parameter differences of up to ~0.1 lr, and the log-shaped quaternion losses amplify it
+    # to ~1e-2 of the loss within three steps.  So the comparison is split:
+    #  (a) lr = 0: parameters never move -- every step of every mode must reproduce the same loss;
+    #  (b) one real update (eager warm-up step + the capture step): the parameters agree up to that noise -- every element
+    #      within the two steps' worst case, the mean within 2 % of one learning-rate step.
+    lr = 2e-4
+    runs, flats = {}, {}
     for mode in ("eager", "graph", "segmented"):
-        rr = gpu("tiny", 2, True, "bf16", dropout=0.0, rotation_mode=rotation_mode)
-        rr["model"].train()
-        if mode == "eager":
-            tr = poet_amd.Trainer(rr["model"], rr["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
-        else:
-            tr = poet_amd.GraphedTrainer(rr["model"], rr["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1,
-                                         segment_backward=(mode == "segmented"))
-        runs[mode] = [float(tr.step(rr["samples"], rr["targets"])[0]) for _ in range(4)]
-    assert runs["graph"] == pytest.approx(runs["eager"], rel=2e-3, abs=2e-3), runs
-    assert runs["segmented"] == pytest.approx(runs["eager"], rel=2e-3, abs=2e-3), runs
+        for key, use_lr, steps in (("frozen", 0.0, 4), ("update", lr, 2)):
+            rr = gpu("tiny", 2, True, "bf16", dropout=0.0, rotation_mode=rotation_mode)
+            rr["model"].train()
+            if mode == "eager":
+                tr = poet_amd.Trainer(rr["model"], rr["crit"], lr=use_lr, weight_decay=1e-4, max_norm=0.1)
+            else:
+                tr = poet_amd.GraphedTrainer(rr["model"], rr["crit"], lr=use_lr, weight_decay=1e-4, max_norm=0.1, warm=1,
+                                             segment_backward=(mode == "segmented"))
+            losses = [float(tr.step(rr["samples"], rr["targets"])[0]) for _ in range(steps)]
+            if key == "frozen":
+                runs[mode] = losses
+            else:
+                flats[mode] = tr.arena.flat.clone()
+                where = {n: (p.data.data_ptr() - tr.arena.flat.data_ptr()) // 4 for n, p in rr["model"].named_parameters() if hasattr(p, "_grad_view")}
+                sizes = {n: p.numel() for n, p in rr["model"].named_parameters()}
+    for mode in ("graph", "segmented"):
+        assert runs[mode] == pytest.approx(runs["eager"], rel=1e-4, abs=1e-4), runs
+        d = (flats[mode] - flats["eager"]).abs()
+        worst = sorted(((float(d[o:o + sizes[n]].max()), n) for n, o in where.items()), reverse=True)[:4]
+        assert d.max().item() <= 2 * 2 * lr * 1.05, (mode, d.max().item(), worst)                # two steps, at most +-lr each
+        assert d.mean().item() < 0.02 * lr, (mode, d.mean().item(), worst)
+    assert max(runs["eager"]) - min(runs["eager"]) < 1e-4 * max(1.0, abs(runs["eager"][0])), runs   # lr = 0: the loss does not move
 
 
 FULL_SIZE = [("ycbv", 1, False, False), ("ycbv", 1, False, True),          # BASELINE.json configs[1]: closed-form weights / the reference's own init
