@@ -22,9 +22,10 @@ struct MhaP {
 template <int HD>
 __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Q = p.Q, PH = HD + 1;
-    float* sk = smem;                 // [Q][HD+1]
-    float* sv = sk + Q * PH;          // [Q][HD+1]
+    const int Q = p.Q;
+    constexpr int PH = HD;            // rows are read by all lanes at once (broadcast): no padding, 16-byte LDS reads
+    float* sk = smem;                 // [Q][HD]
+    float* sv = sk + Q * PH;          // [Q][HD]
     float* sp = sv + Q * PH;          // [Q][Q+1]
     const int n = blockIdx.x / p.M, m = blockIdx.x % p.M;
     const int lane = threadIdx.x;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
 #pragma unroll
     for (int c = 0; c < HD; ++c) qr[c] = p.q[(rbase + lane) * p.ld + m * HD + c] * p.scale;
     float mx = -3.0e38f;
+#pragma unroll 2
     for (int j = 0; j < Q; ++j) {
         float s = 0.f;
 #pragma unroll
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
         mx = fmaxf(mx, s);
     }
     float sum = 0.f;
+#pragma unroll 2
     for (int j = 0; j < Q; ++j) {
         const float e = __expf(sp[lane * (Q + 1) + j] - mx);
         sp[lane * (Q + 1) + j] = e;
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
 #pragma unroll
     for (int c = 0; c < HD; ++c) acc[c] = 0.f;
     const uint32_t ibase = ((uint32_t)blockIdx.x * Q + lane) * Q;
+#pragma unroll 2
     for (int j = 0; j < Q; ++j) {
         float pj = sp[lane * (Q + 1) + j] * inv;
         if (p.thresh) pj = drop_keep(p.seed ^ (p.seed_dev ? *p.seed_dev * 0x9E3779B1u : 0u), ibase + j, p.thresh) ? pj * p.dscale : 0.f;
@@ -71,7 +75,8 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
 template <int HD>
 __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Q = p.Q, PH = HD + 1, PQ = Q + 1;
+    const int Q = p.Q, PQ = Q + 1;
+    constexpr int PH = HD;            // rows are read by all lanes at once (broadcast): no padding, 16-byte LDS reads
     float* sq = smem;                 // scaled q
     float* sk = sq + Q * PH;
     float* sv = sk + Q * PH;
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
 #pragma unroll
         for (int c = 0; c < HD; ++c) { qr[c] = sq[lane * PH + c]; dor[c] = sdo[lane * PH + c]; }
         float mx = -3.0e38f;
-        for (int j = 0; j < Q; ++j) {
+    #pragma unroll 2
+    for (int j = 0; j < Q; ++j) {
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < HD; ++c) s += qr[c] * sk[j * PH + c];
@@ -102,7 +108,8 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
             mx = fmaxf(mx, s);
         }
         float sum = 0.f;
-        for (int j = 0; j < Q; ++j) {
+    #pragma unroll 2
+    for (int j = 0; j < Q; ++j) {
             const float e = __expf(spd[lane * PQ + j] - mx);
             spd[lane * PQ + j] = e;
             sum += e;
@@ -110,7 +117,8 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         const float inv = 1.f / sum;
         const uint32_t ibase = ((uint32_t)blockIdx.x * Q + lane) * Q;
         float dot = 0.f;
-        for (int j = 0; j < Q; ++j) {
+    #pragma unroll 2
+    for (int j = 0; j < Q; ++j) {
             const float pj = spd[lane * PQ + j] * inv;
             float keep = 1.f;
             if (p.thresh) keep = drop_keep(p.seed ^ (p.seed_dev ? *p.seed_dev * 0x9E3779B1u : 0u), ibase + j, p.thresh) ? p.dscale : 0.f;
@@ -125,7 +133,8 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         float dqr[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) dqr[c] = 0.f;
-        for (int j = 0; j < Q; ++j) {
+    #pragma unroll 2
+    for (int j = 0; j < Q; ++j) {
             // recover p_j from the dropped value is not possible when keep == 0, so recompute it
             float s = 0.f;
 #pragma unroll
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         float dkr[HD], dvr[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) { dkr[c] = 0.f; dvr[c] = 0.f; }
+#pragma unroll 2
         for (int i = 0; i < Q; ++i) {
             const float ds = sds[i * PQ + lane], pd = spd[i * PQ + lane];
 #pragma unroll
@@ -184,7 +194,7 @@ extern "C" int poet_mha_fwd(const float* q, const float* k, const float* v, int6
     if (rc) return rc;
     POET_CHECK(q && k && v && out, POET_ERR_ARG, "mha_fwd: null pointer");
     p.q = q; p.k = k; p.v = v; p.out = out; p.ld = ld; p.ld_out = ld_out;
-    const size_t lds = sizeof(float) * (2 * Q * (hd + 1) + Q * (Q + 1));
+    const size_t lds = sizeof(float) * (2 * Q * hd + Q * (Q + 1));
     POET_CHECK(lds <= 64 * 1024, POET_ERR_UNSUPPORTED, "mha_fwd: LDS %zu > 64 KiB", lds);
     dim3 grid(N * M), block(64);
     hipStream_t st = (hipStream_t)stream;
@@ -203,7 +213,7 @@ extern "C" int poet_mha_bwd(const float* q, const float* k, const float* v, int6
     if (rc) return rc;
     POET_CHECK(q && k && v && dout && dq && dk && dv, POET_ERR_ARG, "mha_bwd: null pointer");
     p.q = q; p.k = k; p.v = v; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv; p.ld = ld; p.ld_out = ld_out; p.ld_d = ld_d;
-    const size_t lds = sizeof(float) * (4 * Q * (hd + 1) + 2 * Q * (Q + 1));
+    const size_t lds = sizeof(float) * (4 * Q * hd + 2 * Q * (Q + 1));
     POET_CHECK(lds <= 64 * 1024, POET_ERR_UNSUPPORTED, "mha_bwd: LDS %zu > 64 KiB", lds);
     dim3 grid(N * M), block(64);
     hipStream_t st = (hipStream_t)stream;
