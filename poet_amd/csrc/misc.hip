@@ -586,32 +586,32 @@ __global__ __launch_bounds__(64) void lsa_boxes_kernel(const float* __restrict__
 __global__ void match_gather_kernel(const int* __restrict__ col, const int* __restrict__ tgt_off, const float* __restrict__ tpos,
                                     const float* __restrict__ trot, int N, int Q, int64_t* __restrict__ qi, float* __restrict__ tt,
                                     float* __restrict__ trm, int* __restrict__ n_out) {
-    // one workgroup; a running count per image keeps the (b, s) order deterministic
+    // one workgroup; output slot of pair (b, s) = matched pairs of the images before b + matched rows before s in image b
+    // (the (b, s) order of the host matcher), every step parallel: the assignment sits in LDS, one thread per pair
     __shared__ int base[257];
-    const int tid = threadIdx.x;
-    if (tid == 0) {
+    extern __shared__ int scol[];                                // [N * Q]
+    const int tid = threadIdx.x, NQ = N * Q;
+    for (int i = tid; i < NQ; i += blockDim.x) scol[i] = col[i];
+    __syncthreads();
+    for (int b = tid; b <= N; b += blockDim.x) {                 // base[b] = pairs of images 0 .. b-1
         int acc = 0;
-        for (int b = 0; b < N; ++b) {
-            base[b] = acc;
-            for (int s = 0; s < Q; ++s) acc += col[b * Q + s] >= 0;
-        }
-        base[N] = acc;
-        if (n_out) *n_out = acc;
+        for (int i = 0; i < b * Q; ++i) acc += scol[i] >= 0;
+        base[b] = acc;
+        if (b == N && n_out) *n_out = acc;
     }
     __syncthreads();
-    for (int b = tid; b < N; b += blockDim.x) {
+    for (int i = tid; i < NQ; i += blockDim.x) {
+        const int c = scol[i];
+        if (c < 0) continue;
+        const int b = i / Q;
         int k = base[b];
-        for (int s = 0; s < Q; ++s) {
-            const int c = col[b * Q + s];
-            if (c < 0) continue;
-            const int g = tgt_off[b] + c;
-            qi[k] = (int64_t)b * Q + s;
+        for (int j = b * Q; j < i; ++j) k += scol[j] >= 0;
+        const int g = tgt_off[b] + c;
+        qi[k] = (int64_t)i;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) tt[k * 3 + e] = tpos[g * 3 + e];
+        for (int e = 0; e < 3; ++e) tt[k * 3 + e] = tpos[g * 3 + e];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) trm[k * 9 + e] = trot[g * 9 + e];
-            ++k;
-        }
+        for (int e = 0; e < 9; ++e) trm[k * 9 + e] = trot[g * 9 + e];
     }
 }
 
@@ -806,7 +806,7 @@ extern "C" int poet_match_gather(const int* col, const int* tgt_off, const float
                                  int64_t* query_idx, float* tgt_trans_out, float* tgt_rot_out, int* n_out, void* stream) {
     POET_CHECK(col && tgt_off && tgt_pos && tgt_rot && query_idx && tgt_trans_out && tgt_rot_out && N > 0 && N <= 256 && Q > 0, POET_ERR_ARG,
                "match_gather: bad args (N <= 256)");
-    hipLaunchKernelGGL(match_gather_kernel, dim3(1), dim3(256), 0, ST, col, tgt_off, tgt_pos, tgt_rot, N, Q, query_idx, tgt_trans_out,
+    hipLaunchKernelGGL(match_gather_kernel, dim3(1), dim3(256), (size_t)N * Q * sizeof(int), ST, col, tgt_off, tgt_pos, tgt_rot, N, Q, query_idx, tgt_trans_out,
                        tgt_rot_out, n_out);
     POET_LAUNCH_CHECK();
     return POET_OK;
