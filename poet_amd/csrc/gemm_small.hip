@@ -236,6 +236,82 @@ __device__ __forceinline__ void small_dw_body(const P& p, float* red, float (*re
     if (do_sum && g == 0 && m0 + r < d.M) const_cast<float*>(d.bias)[zb * d.stride_bias + m0 + r] += reds[0][r] + reds[1][r] + reds[2][r] + reds[3][r];
 }
 
+// ---- the same weight gradient with 16 x 64 tiles (n2 % 4 == 0): the structure of gemm_small_bkm_kernel with A = Y^T ----
+// 16 x 16 tiles re-read every 16-column strip of Y n2/16 times and of X n1/16 times (205 MB through the L1s for the 8 MB of the
+// decoder's 1024 x 256 FFN gradient).  Here lane (r, g) of a wave reads Y[k][m0 + r] (4 bytes; 16 lanes = 64 contiguous bytes of
+// a row) and X[k][n0 + 4 r .. + 3] (16 bytes) and feeds four column-permuted MFMA tiles; wave w reduces rows [64 w, 64 w + 64);
+// the partial tiles meet in LDS as in the input-gradient kernel and thread (row, column quad) adds 4 consecutive columns onto
+// the gradient with one 16-byte read-modify-write.  The bias gradient (column sums of Y) comes out of the same loads.
+template <typename P>
+__device__ __forceinline__ void small_dw64_body(const P& p, float* part, float* bsum) {
+    const auto& d = p.d;                                                // M = n1, N = n2, K = rows
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int tn = (d.N + BKM_TN - 1) / BKM_TN;
+    const int m0 = (blockIdx.x / tn) << 4, n0 = (blockIdx.x % tn) * BKM_TN;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t zb = blockIdx.y;
+    const int kb = wid * 64, kend = min(kb + 64, d.K);                  // this wave's rows
+    const int ycol = min(m0 + r, d.M - 1), xcol = min(n0 + 4 * r, d.N - 4);
+    const float* yp = reinterpret_cast<const float*>(d.A) + zb * d.strideA + ycol;
+    const float* xp = reinterpret_cast<const float*>(d.B) + zb * d.strideB + xcol;
+    f32x4_t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float y[16];
+    float4 x[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                                   // MFMA (i, c): lane group g brings row kb + 16 i + 4 g + c
+            const int row = kb + i * 16 + g * 4 + c;
+            const bool ok = row < kend;
+            const int rr = ok ? row : 0;
+            y[i * 4 + c] = ok ? yp[(int64_t)rr * d.lda] : 0.f;
+            x[i * 4 + c] = ok ? *reinterpret_cast<const float4*>(xp + (int64_t)rr * d.ldb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    float ysum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        acc[0] = mfma4(y[e], x[e].x, acc[0]);
+        acc[1] = mfma4(y[e], x[e].y, acc[1]);
+        acc[2] = mfma4(y[e], x[e].z, acc[2]);
+        acc[3] = mfma4(y[e], x[e].w, acc[3]);
+        ysum += y[e];
+    }
+    const bool do_sum = d.bias && n0 == 0;                              // workgroup-uniform
+    if (do_sum) {
+        ysum += __shfl_xor(ysum, 16, 64);
+        ysum += __shfl_xor(ysum, 32, 64);
+        if (g == 0) bsum[wid * 16 + r] = ysum;
+    }
+    float* mine = part + ((wid * 64 + lane) << 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(mine + t * 4) = make_float4(acc[0][t], acc[1][t], acc[2][t], acc[3][t]);
+    __syncthreads();
+    if (threadIdx.x >= 256) return;
+    const int row = threadIdx.x >> 4, r4 = threadIdx.x & 15;
+    const float* src = part + ((((row >> 2) << 4) + r4) << 4) + (row & 3) * 4;
+    float4 sum = *reinterpret_cast<const float4*>(src);
+    for (int w2 = 1; w2 < nw; ++w2) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (w2 << 10));
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const int grow = m0 + row, col = n0 + 4 * r4;
+    if (grow < d.M && col < d.N) {                                      // (n2 % 4 == 0: a quad is in or out as a whole)
+        float* cp = reinterpret_cast<float*>(d.C) + zb * d.strideC + (int64_t)grow * d.ldc + col;
+        cp[0] += sum.x; cp[1] += sum.y; cp[2] += sum.z; cp[3] += sum.w;
+    }
+    if (do_sum && threadIdx.x < 16 && m0 + (int)threadIdx.x < d.M) {
+        float t = 0.f;
+        for (int w2 = 0; w2 < nw; ++w2) t += bsum[w2 * 16 + threadIdx.x];
+        const_cast<float*>(d.bias)[zb * d.stride_bias + m0 + threadIdx.x] += t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void gemm_small_dw64_kernel(const GemmK p) {
+    extern __shared__ __attribute__((aligned(16))) float part[];
+    __shared__ float bsum[16 * 16];
+    small_dw64_body(p, part, bsum);
+}
+
 __global__ __launch_bounds__(256) void gemm_small_dw_kernel(const GemmK p) {
     __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
     __shared__ float reds[4][16];
@@ -282,12 +358,49 @@ __global__ __launch_bounds__(256) void gemm_small_dw_list_kernel(const DwList l)
 
 }  // namespace
 
+__global__ __launch_bounds__(1024) void gemm_small_dw64_list_kernel(const DwList l) {
+    extern __shared__ __attribute__((aligned(16))) float part[];
+    __shared__ float bsum[16 * 16];
+    typedef const __attribute__((address_space(4))) DwList* kernarg_t;
+    kernarg_t ka = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const int z = blockIdx.y;
+    DwOne one;
+    one.d.A = ka->Y[z]; one.d.B = ka->X[z]; one.d.C = ka->C[z]; one.d.bias = ka->ysum[z];
+    one.d.M = ka->M; one.d.N = ka->N; one.d.K = ka->K;
+    one.d.lda = ka->lda; one.d.ldb = ka->ldb; one.d.ldc = ka->ldc;
+    one.d.strideA = one.d.strideB = one.d.strideC = one.d.stride_bias = 0;
+    (void)l;
+    small_dw64_body(one, part, bsum);
+}
+
+// n2 a multiple of 4, X rows 16-byte aligned, <= 1024 rows (16 waves): the 16 x 64 tiling
+static bool dw64_ok(const void* X, int64_t ldx, int n2, int rows) {
+    static const int off = [] { const char* e = getenv("POET_SMALL_NO_DW64"); return e && atoi(e) ? 1 : 0; }();
+    return !off && n2 % 4 == 0 && n2 >= 4 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && rows <= 1024;
+}
+static void dw64_attr() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_dw64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_dw64_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+}
+
 bool gemm_small_dw_list(const float* const* Y, const float* const* X, float* const* C, float* const* ysum, int n, int n_out, int k_in,
                         int rows, int64_t ldy, int64_t ldx, int64_t ldc, hipStream_t st) {
     if (n < 1 || n > DW_LIST_MAX || rows > 1024) return false;
     DwList l{};
     for (int i = 0; i < n; ++i) { l.Y[i] = Y[i]; l.X[i] = X[i]; l.C[i] = C[i]; l.ysum[i] = ysum ? ysum[i] : nullptr; }
     l.M = n_out; l.N = k_in; l.K = rows; l.lda = ldy; l.ldb = ldx; l.ldc = ldc;
+    bool wide = dw64_ok(X[0], ldx, k_in, rows);
+    for (int i = 1; i < n && wide; ++i) wide = (reinterpret_cast<uintptr_t>(X[i]) & 15) == 0;
+    if (wide) {
+        const int nw = max(4, (rows + 63) / 64);       // (the fold and the store use 256 threads)
+        dw64_attr();
+        hipLaunchKernelGGL(gemm_small_dw64_list_kernel, dim3(((n_out + 15) >> 4) * ((k_in + BKM_TN - 1) / BKM_TN), n), dim3(64 * nw), (size_t)nw * 4096, st, l);
+        return true;
+    }
     const int tiles = ((n_out + 15) >> 4) * ((k_in + 15) >> 4);
     hipLaunchKernelGGL(gemm_small_dw_list_kernel, dim3(tiles, n), dim3(256), 0, st, l);
     return true;
@@ -302,6 +415,12 @@ bool gemm_small_try(const GemmK& p, hipStream_t st) {
     const bool dw_form = d.a_kmajor && d.b_kmajor && (d.atomic || d.splitk > 1);
     if (dw_form) {                                                      // M = n_out, N = k_in, K = rows
         if (d.K > 1024 || d.alpha != 1.f) return false;
+        if (dw64_ok(d.B, d.ldb, d.N, d.K) && d.strideB % 4 == 0) {
+            const int nw = max(4, (d.K + 63) / 64);     // (the fold and the store use 256 threads)
+            dw64_attr();
+            hipLaunchKernelGGL(gemm_small_dw64_kernel, dim3(((d.M + 15) >> 4) * ((d.N + BKM_TN - 1) / BKM_TN), d.batch), dim3(64 * nw), (size_t)nw * 4096, st, p);
+            return true;
+        }
         const int tiles = ((d.M + 15) >> 4) * ((d.N + 15) >> 4);
         hipLaunchKernelGGL(gemm_small_dw_kernel, dim3(tiles, d.batch), dim3(256), 0, st, p);
         return true;

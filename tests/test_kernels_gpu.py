@@ -875,7 +875,7 @@ def test_gemm_small_fwd_dx(ops, M, N, K):
     _close(dx, (dy @ w) * 1.5 * (gate > 0) + acc0, torch.float32, msg="small dX")
 
 
-@pytest.mark.parametrize("rows,n_out,k_in", [(320, 256, 256), (320, 132, 256), (320, 1024, 256), (333, 256, 1024), (1024, 48, 40)])
+@pytest.mark.parametrize("rows,n_out,k_in", [(320, 256, 256), (320, 132, 256), (320, 1024, 256), (333, 256, 1024), (1024, 48, 40), (20, 128, 64), (100, 40, 68), (700, 24, 256)])
 def test_gemm_small_dw_db(ops, rows, n_out, k_in):
     dy = _rand(rows, n_out, seed=140)
     x = _rand(rows, k_in, seed=141)
