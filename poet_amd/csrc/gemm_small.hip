@@ -426,7 +426,8 @@ bool gemm_small_try(const GemmK& p, hipStream_t st) {
         return true;
     }
     if (d.a_kmajor || d.splitk != 1 || d.atomic) return false;
-    if (d.M > 1024 || d.K % 16 != 0 || d.K > 4096 || !p.a_vec) return false;   // A rows: 16-byte loads
+    const bool bkm_form = d.b_kmajor && d.N % 4 == 0 && d.N >= 4 && p.b_vec;      // (2048 rows there: the pose heads of all decoder layers at once)
+    if (d.M > (bkm_form ? 2048 : 1024) || d.K % 16 != 0 || d.K > 4096 || !p.a_vec) return false;   // A rows: 16-byte loads
     if (!d.b_kmajor && !p.b_vec) return false;
     if (d.b_kmajor && d.N % 4 == 0 && d.N >= 4 && p.b_vec && (int64_t)d.M * d.lda < (1 << 29) && (int64_t)d.K * d.ldb < (1 << 29)) {            // weight rows along N: 16 x 64 tiles, K over 4..16 waves
         static const int no_bkm = [] { const char* e = getenv("POET_SMALL_NO_BKM"); return e && atoi(e) ? 1 : 0; }();

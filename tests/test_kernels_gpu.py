@@ -848,7 +848,7 @@ def test_pose_loss_fused_matches_torch(ops):
 
 
 # ------------------------------------------------------------------ latency-oriented fp32 kernels (gemm_small.hip)
-@pytest.mark.parametrize("M,N,K", [(320, 256, 256), (320, 132, 256), (320, 1024, 256), (320, 256, 1024), (37, 48, 512), (1000, 256, 768)])
+@pytest.mark.parametrize("M,N,K", [(320, 256, 256), (320, 132, 256), (320, 1024, 256), (320, 256, 1024), (37, 48, 512), (1000, 256, 768), (1600, 256, 256)])
 def test_gemm_small_fwd_dx(ops, M, N, K):
     """fp32, <= 1024 rows: poet_gemm routes forward and input-gradient products to gemm_small.hip (K >= 512 and a multiple
     of 64: reduction split over the 4 waves).  Dropout pattern against the tiled kernel (disabled by a K that is not a
