@@ -397,7 +397,7 @@ def main():
                                        "pmc": pmc_mfma_summary(args.config)}
             if out["roofline"]["kernel"].startswith("msda_bwd_dvalue_scatter"):
                 # the contract's two bounds do not name this kernel's real limiter; say so next to the HBM fraction
-                out["roofline"]["limiter"] = "two on-CU pipes loaded equally, not HBM: the LDS atomic unit (26 M ds_add_u32 wave-instructions per launch at ~5.2 clk: 219 us floor) and the VALU (3 half-rate instructions per corner and lane: ~228 us): DESIGN.md section 5/9"
+                out["roofline"]["limiter"] = "VALU issue, not HBM: ~310 instructions per 4 queries x 64 corners x 16 channels, 160 of them half-rate DPP / convert (2.5 per ds_add_u32 wave-instruction, 26 M of those per launch); with the LDS atomics compiled out the accumulate phase is only 7 % faster: DESIGN.md section 5/9"
             out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
                                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         if world == 1 and not args.no_cpu_baseline:
