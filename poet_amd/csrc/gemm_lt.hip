@@ -7,7 +7,7 @@
 // (d(src) += d(hidden) W1, d(src) += [d(offsets|logits) | d(value) rows] [W_so ; W_aw ; W_v], d(memory) = d(values) W_v:
 // models/deformable_transformer.py:193-208's Linears seen from backward), and for those the vendor library is simply
 // faster than the tiled kernel of gemm.hip: 75 us against 148 us at K = 1024 with beta = 1 (measured on MI355X,
-// scratch/lt_probe.cpp / scratch/dx_bench.py).  They go to hipblasLtMatmul with an algorithm picked once per shape by the library's
+// profiles/probes/lt_probe.cpp / profiles/probes/dx_bench.py).  They go to hipblasLtMatmul with an algorithm picked once per shape by the library's
 // own heuristic; everything else stays on the kernels of this directory.  POET_GEMM_NO_LT=1 disables the route (A/B).
 #include <hipblaslt/hipblaslt.h>
 

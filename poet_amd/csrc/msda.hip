@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
 // lanes [x corner][channel half] of a (query, head) each redo floor / range tests / clamps / 24-bit address multiplies / weights
 // of all 16 points (~130 issue cycles per point: on gfx950 v_cvt, v_floor, v_cmp, v_cndmask, v_med3, v_mad_u32_u24, v_lshlrev
 // and every DPP / SGPR-operand form issue at 4 cycles per wave-instruction against 2 for v_fma / v_and / v_add -- measured,
-// scratch/valu_probe.hip).  Here one wave = one query row (16 heads x 4 lanes) and the 4 lanes of a head split the geometry by
+// profiles/probes/valu_probe.hip).  Here one wave = one query row (16 heads x 4 lanes) and the 4 lanes of a head split the geometry by
 // LEVEL: lane o prepares the 4 points of level o for BOTH x corners (softmax over the quad with DPP) and leaves one 16-byte record
 //     { byte offset of the upper corner pixel, of the lower one, weight of the upper, of the lower }
 // per (x corner, point, head) in LDS; the gather loop then reads its corner's record with one ds_read_b128 (LDS pipe, no

@@ -187,7 +187,7 @@ def test_rotation_modes_fp32_vs_reference_golden(gpu, golden_dir, rotation_mode,
         assert np.isfinite(float(t1)) and np.isfinite(float(t2))
         return
     # quaternion modes: HIP-graph replay (single and segmented backward) == eager, dropout off.
-    # Two training runs of ONE mode already differ (measured, scratch/seg_dbg4.py: eager vs eager lands on one of two
+    # Two training runs of ONE mode already differ (measured, tests/tools/run_to_run_noise.py: eager vs eager lands on one of two
     # trajectories just like eager vs graph): the fp32 atomics of the decoder's value-gradient scatter add in a different order
     # every run, the parameters after the first AdamW step differ by ~1e-7, that flips a bf16 rounding of an activation in
     # the next forward, the next gradients differ by ~1e-4 of their maximum in ~9 % of the elements, AdamW's m / sqrt(v)
