@@ -280,11 +280,16 @@ int poet_im2col3x3s2(const void* src, void* dst, int N, int C, int H, int W, int
  * stats (N,G,2) fp32 = (mean, rstd).  Backward accumulates dgamma/dbeta (fp32 [C]). */
 int poet_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                        int N, int HW, int C, int G, int64_t x_off, int64_t x_stride,
-                       int64_t y_off, int64_t y_stride, float eps, int dtype_x, int dtype_y, void* stream);
+                       int64_t y_off, int64_t y_stride, float eps, int dtype_x, int dtype_y,
+                       float* scratch, int64_t scratch_floats /* optional caller-owned scratch (contents undefined afterwards):
+                           with N * 32 * 64 floats (forward) / N * 32 * 512 floats (backward) and C = 256, G = 32 the
+                           whole-row kernels run (two launches, coalesced); without it one workgroup per (image, group) */,
+                       void* stream);
 int poet_groupnorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma,
                        void* dx, float* dgamma, float* dbeta,
                        int N, int HW, int C, int G, int64_t x_off, int64_t x_stride,
-                       int64_t y_off, int64_t y_stride, int dtype_x, int dtype_y, void* stream);
+                       int64_t y_off, int64_t y_stride, int dtype_x, int dtype_y,
+                       float* scratch, int64_t scratch_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pose heads tail: rot_all (R, ncls*6), trans_all (R, ncls*3) fp32, cls (R,) int32 (<=0 -> slot 0)

@@ -274,6 +274,178 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const TY* __restrict__ dy, 
     }
 }
 
+// ---- GroupNorm with whole token rows per wave (C = 256, 8 channels per group: the shape of every input_proj level) ----------
+// The kernels above give a workgroup ONE group's 16-32 bytes out of every row: every lane of a load touches its own cache line
+// (2.6 TB/s for the 60 x 80 level).  Here a workgroup owns GN_RB consecutive rows of one image with all 256 channels -- thread =
+// (group = its 8 channels, row lane), a wave reads two whole 512-byte rows per instruction -- and the reductions that span the
+// image go through a small caller-owned scratch in a fixed order (deterministic, like the one-workgroup-per-group kernels):
+//   forward : gn_rows_stats  -> partial (sum, sum of squares) per (image, row block, group);
+//             gn_rows_apply  -> every workgroup adds the partials of its image, normalises its rows (block 0 also stores mean / rstd);
+//   backward: gn_rows_bwd_partial -> partial (sum dy xhat, sum dy) per (image, row block, channel);
+//             gn_rows_bwd_apply   -> adds them (block 0 of each image also feeds d gamma / d beta), forms the two group means, writes dx.
+constexpr int GN_RB = 64;                  // rows per workgroup of the apply kernels
+constexpr int GN_NSB = 32;                 // row blocks per image of the partial-sum kernels (an apply workgroup adds that many partials)
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_rows_stats_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int nblk, int rb,
+                                                            int64_t x_off, int64_t x_stride) {
+    __shared__ float red[2][8][32];
+    const int n = blockIdx.x / nblk, blk = blockIdx.x % nblk, g = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const T* xb = x + ((int64_t)n * x_stride + x_off) * 256 + g * 8;
+    float s = 0.f, q = 0.f;
+    const int rend = min(HW, (blk + 1) * rb);
+    int r = blk * rb + rl;
+    for (; r + 24 < rend; r += 32) {                                // 4 rows in flight per thread
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vec<T, 8>::ld(xb + (int64_t)(r + 8 * u) * 256, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { s += v[u][c]; q += v[u][c] * v[u][c]; }
+    }
+    for (; r < rend; r += 8) {
+        float v[8];
+        vec<T, 8>::ld(xb + (int64_t)r * 256, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s += v[c]; q += v[c] * v[c]; }
+    }
+    red[0][rl][g] = s; red[1][rl][g] = q;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x >> 5;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[k][i][g];
+        part[((int64_t)blockIdx.x * 32 + g) * 2 + k] = t;
+    }
+}
+
+template <typename T, typename TY>
+__global__ __launch_bounds__(256) void gn_rows_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            TY* __restrict__ y, float* __restrict__ stats, const float* __restrict__ part,
+                                                            int HW, int nblk, int nsb, int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride, float eps) {
+    __shared__ float smu[32], srs[32];
+    const int n = blockIdx.x / nblk, blk = blockIdx.x % nblk, g = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    if (threadIdx.x < 32) {
+        float s = 0.f, q = 0.f;
+        const float2* pp = reinterpret_cast<const float2*>(part) + (int64_t)n * nsb * 32 + g;
+        float2 pv[GN_NSB];                                          // all partials requested before the first is used (one round trip)
+#pragma unroll
+        for (int b = 0; b < GN_NSB; ++b) pv[b] = b < nsb ? pp[b * 32] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < GN_NSB; ++b) { s += pv[b].x; q += pv[b].y; }
+        const float cnt = (float)HW * 8.f;
+        const float mu = s / cnt;
+        const float rs = rsqrtf(fmaxf(q / cnt - mu * mu, 0.f) + eps);
+        smu[g] = mu; srs[g] = rs;
+        if (blk == 0) { stats[(n * 32 + g) * 2] = mu; stats[(n * 32 + g) * 2 + 1] = rs; }
+    }
+    __syncthreads();
+    const float mu = smu[g], rs = srs[g];
+    float gm[8], bt[8];
+    vec<float, 8>::ld(gamma + g * 8, gm);
+    vec<float, 8>::ld(beta + g * 8, bt);
+    const T* xb = x + ((int64_t)n * x_stride + x_off) * 256 + g * 8;
+    TY* yb = y + ((int64_t)n * y_stride + y_off) * 256 + g * 8;
+    const int rend = min(HW, (blk + 1) * GN_RB);
+    int r = blk * GN_RB + rl;
+    for (; r + 24 < rend; r += 32) {                                // 4 rows in flight per thread
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vec<T, 8>::ld(xb + (int64_t)(r + 8 * u) * 256, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[u][c] = (v[u][c] - mu) * rs * gm[c] + bt[c];
+            vec<TY, 8>::st(yb + (int64_t)(r + 8 * u) * 256, v[u]);
+        }
+    }
+    for (; r < rend; r += 8) {
+        float v[8];
+        vec<T, 8>::ld(xb + (int64_t)r * 256, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (v[c] - mu) * rs * gm[c] + bt[c];
+        vec<TY, 8>::st(yb + (int64_t)r * 256, v);
+    }
+}
+
+template <typename T, typename TY>
+__global__ __launch_bounds__(256) void gn_rows_bwd_partial_kernel(const TY* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
+                                                                  float* __restrict__ part, int HW, int nblk, int rb, int64_t x_off, int64_t x_stride,
+                                                                  int64_t y_off, int64_t y_stride) {
+    __shared__ float red[2][8][256];
+    const int n = blockIdx.x / nblk, blk = blockIdx.x % nblk, g = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const float mu = stats[(n * 32 + g) * 2], rs = stats[(n * 32 + g) * 2 + 1];
+    const T* xb = x + ((int64_t)n * x_stride + x_off) * 256 + g * 8;
+    const TY* db = dy + ((int64_t)n * y_stride + y_off) * 256 + g * 8;
+    float pg[8], pb[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { pg[c] = 0.f; pb[c] = 0.f; }
+#pragma unroll 2
+    for (int r = blk * rb + rl; r < min(HW, (blk + 1) * rb); r += 8) {
+        float d[8], v[8];
+        vec<TY, 8>::ld(db + (int64_t)r * 256, d);
+        vec<T, 8>::ld(xb + (int64_t)r * 256, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { pg[c] += d[c] * (v[c] - mu) * rs; pb[c] += d[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { red[0][rl][g * 8 + c] = pg[c]; red[1][rl][g * 8 + c] = pb[c]; }
+    __syncthreads();
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { tg += red[0][i][threadIdx.x]; tb += red[1][i][threadIdx.x]; }
+    part[((int64_t)blockIdx.x * 2) * 256 + threadIdx.x] = tg;
+    part[((int64_t)blockIdx.x * 2 + 1) * 256 + threadIdx.x] = tb;
+}
+
+template <typename T, typename TY>
+__global__ __launch_bounds__(256) void gn_rows_bwd_apply_kernel(const TY* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, T* __restrict__ dx, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, const float* __restrict__ part, int HW, int nblk, int nsb,
+                                                                int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride) {
+    __shared__ float s1[256], s2[256], sm1[32], sm2[32];
+    const int n = blockIdx.x / nblk, blk = blockIdx.x % nblk, g = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    {
+        float tg = 0.f, tb = 0.f;
+        const float* pp = part + (int64_t)n * nsb * 512 + threadIdx.x;
+        float pgv[GN_NSB], pbv[GN_NSB];
+#pragma unroll
+        for (int b = 0; b < GN_NSB; ++b) { pgv[b] = b < nsb ? pp[b * 512] : 0.f; pbv[b] = b < nsb ? pp[b * 512 + 256] : 0.f; }
+#pragma unroll
+        for (int b = 0; b < GN_NSB; ++b) { tg += pgv[b]; tb += pbv[b]; }
+        if (blk == 0) { atomicAdd(dgamma + threadIdx.x, tg); atomicAdd(dbeta + threadIdx.x, tb); }
+        const float gmc = gamma[threadIdx.x];
+        s1[threadIdx.x] = gmc * tb; s2[threadIdx.x] = gmc * tg;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { a += s1[threadIdx.x * 8 + c]; b += s2[threadIdx.x * 8 + c]; }
+        const float cnt = (float)HW * 8.f;
+        sm1[threadIdx.x] = a / cnt; sm2[threadIdx.x] = b / cnt;
+    }
+    __syncthreads();
+    const float m1 = sm1[g], m2 = sm2[g];
+    const float mu = stats[(n * 32 + g) * 2], rs = stats[(n * 32 + g) * 2 + 1];
+    float gm[8];
+    vec<float, 8>::ld(gamma + g * 8, gm);
+    const T* xb = x + ((int64_t)n * x_stride + x_off) * 256 + g * 8;
+    const TY* db = dy + ((int64_t)n * y_stride + y_off) * 256 + g * 8;
+    T* ob = dx + ((int64_t)n * x_stride + x_off) * 256 + g * 8;
+#pragma unroll 2
+    for (int r = blk * GN_RB + rl; r < min(HW, (blk + 1) * GN_RB); r += 8) {
+        float d[8], v[8];
+        vec<TY, 8>::ld(db + (int64_t)r * 256, d);
+        vec<T, 8>::ld(xb + (int64_t)r * 256, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = rs * (d[c] * gm[c] - m1 - (v[c] - mu) * rs * m2);
+        vec<T, 8>::st(ob + (int64_t)r * 256, v);
+    }
+}
+
 }  // namespace poet
 
 using namespace poet;
@@ -334,11 +506,27 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
 
 extern "C" int poet_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int N,
                                   int HW, int C, int G, int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride,
-                                  float eps, int dtype_x, int dtype_y, void* stream) {
+                                  float eps, int dtype_x, int dtype_y, float* scratch, int64_t scratch_floats, void* stream) {
     POET_CHECK(x && gamma && beta && y && stats, POET_ERR_ARG, "groupnorm_fwd: null pointer");
     POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= GN_MAXCPG, POET_ERR_ARG, "groupnorm_fwd: bad dims (C/G must be <= 8)");
-    dim3 grid(N * G), block(256);
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int nblk = cdiv(HW, GN_RB), nsb = min(GN_NSB, nblk), rb = cdiv(cdiv(HW, nsb), 8) * 8;
+        static const int no_rows = [] { const char* e = getenv("POET_GN_NO_ROWS"); return e && atoi(e) ? 1 : 0; }();
+        if (!no_rows && C == 256 && G == 32 && scratch && scratch_floats >= (int64_t)N * nsb * 64 && HW >= 256 &&
+            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) == 0) {
+#define GN_ROWS_FWD(TX, TR)                                                                                                              \
+            do {                                                                                                                         \
+                gn_rows_stats_kernel<TX><<<dim3(N * nsb), dim3(256), 0, st>>>((const TX*)x, scratch, HW, nsb, rb, x_off, x_stride);     \
+                gn_rows_apply_kernel<TX, TR><<<dim3(N * nblk), dim3(256), 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, scratch, HW, nblk, nsb, x_off, x_stride, y_off, y_stride, eps); \
+            } while (0)
+            POET_DT2(dtype_x, dtype_y, GN_ROWS_FWD);
+#undef GN_ROWS_FWD
+            POET_LAUNCH_CHECK();
+            return POET_OK;
+        }
+    }
+    dim3 grid(N * G), block(256);
 #define GN_FWD(TX, TR) gn_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, HW, C, G, x_off, x_stride, y_off, y_stride, eps)
     POET_DT2(dtype_x, dtype_y, GN_FWD);
 #undef GN_FWD
@@ -348,11 +536,28 @@ extern "C" int poet_groupnorm_fwd(const void* x, const float* gamma, const float
 
 extern "C" int poet_groupnorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                                   float* dgamma, float* dbeta, int N, int HW, int C, int G, int64_t x_off,
-                                  int64_t x_stride, int64_t y_off, int64_t y_stride, int dtype_x, int dtype_y, void* stream) {
+                                  int64_t x_stride, int64_t y_off, int64_t y_stride, int dtype_x, int dtype_y, float* scratch,
+                                  int64_t scratch_floats, void* stream) {
     POET_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta, POET_ERR_ARG, "groupnorm_bwd: null pointer");
     POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= GN_MAXCPG, POET_ERR_ARG, "groupnorm_bwd: bad dims (C/G must be <= 8)");
-    dim3 grid(N * G), block(256);
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int nblk = cdiv(HW, GN_RB), nsb = min(GN_NSB, nblk), rb = cdiv(cdiv(HW, nsb), 8) * 8;
+        static const int no_rows = [] { const char* e = getenv("POET_GN_NO_ROWS"); return e && atoi(e) ? 1 : 0; }();
+        if (!no_rows && C == 256 && G == 32 && scratch && scratch_floats >= (int64_t)N * nsb * 512 && HW >= 256 &&
+            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 31) == 0) {
+#define GN_ROWS_BWD(TX, TR)                                                                                                              \
+            do {                                                                                                                         \
+                gn_rows_bwd_partial_kernel<TX, TR><<<dim3(N * nsb), dim3(256), 0, st>>>((const TR*)dy, (const TX*)x, stats, scratch, HW, nsb, rb, x_off, x_stride, y_off, y_stride); \
+                gn_rows_bwd_apply_kernel<TX, TR><<<dim3(N * nblk), dim3(256), 0, st>>>((const TR*)dy, (const TX*)x, stats, gamma, (TX*)dx, dgamma, dbeta, scratch, HW, nblk, nsb, x_off, x_stride, y_off, y_stride); \
+            } while (0)
+            POET_DT2(dtype_x, dtype_y, GN_ROWS_BWD);
+#undef GN_ROWS_BWD
+            POET_LAUNCH_CHECK();
+            return POET_OK;
+        }
+    }
+    dim3 grid(N * G), block(256);
 #define GN_BWD(TX, TR) gn_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)x, stats, gamma, (TX*)dx, dgamma, dbeta, HW, C, G, x_off, x_stride, y_off, y_stride)
     POET_DT2(dtype_x, dtype_y, GN_BWD);
 #undef GN_BWD

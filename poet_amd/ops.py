@@ -418,7 +418,8 @@ def ln_bwd(dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, rows, d, drop_p=0.0,
 def groupnorm_fwd(x, gamma, beta, y, stats, N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps=1e-5):
     lib = _lib.load()
     _lib.check(lib.poet_groupnorm_fwd(_req(x, "x").data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
-                                      N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps, dcode(x), dcode(y), _stream()),
+                                      N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps, dcode(x), dcode(y),
+                                      _workspace(x.device).data_ptr(), _WORKSPACE_BYTES // 4, _stream()),
                "poet_groupnorm_fwd")
 
 
@@ -426,7 +427,8 @@ def groupnorm_bwd(dy, x, stats, gamma, dx, dgamma, dbeta, N, HW, Cc, G, x_off, x
     lib = _lib.load()
     _lib.check(lib.poet_groupnorm_bwd(_req(dy, "dy").data_ptr(), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
                                       dgamma.data_ptr(), dbeta.data_ptr(), N, HW, Cc, G, x_off, x_stride, y_off, y_stride,
-                                      dcode(x), dcode(dy), _stream()), "poet_groupnorm_bwd")
+                                      dcode(x), dcode(dy), _workspace(x.device).data_ptr(), _WORKSPACE_BYTES // 4, _stream()),
+               "poet_groupnorm_bwd")
 
 
 # ---- attention -------------------------------------------------------------------------------------

@@ -1051,3 +1051,35 @@ def test_gemm_plain_large_k_vendor_route(ops, monkeypatch):
         assert (two.double().cpu() - exact).abs().max().item() <= 1e-4 * sc
         assert (one.double().cpu() - exact).abs().max().item() <= 1e-4 * sc
         assert (two.cpu() - one.cpu()).abs().max().item() <= 2e-5 * sc
+
+
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("HW", [300, 1217])
+def test_groupnorm_whole_row_kernels(ops, xdt, ydt, HW, monkeypatch):
+    """C = 256, G = 32, >= 256 tokens: the whole-row GroupNorm kernels (row blocks of 64, partial sums through the caller's
+    scratch) -- against torch, and against the one-workgroup-per-group kernels they replace (POET_GN_NO_ROWS is read once per
+    process, so that comparison is through torch's result).  Odd token counts: a partial last row block."""
+    N, C, G, S, off = 3, 256, 32, HW + 70, 50
+    x = (_rand(N, HW, C, seed=330) * 1.5 + 0.3).to(xdt)
+    gamma = 1 + 0.1 * _rand(C, seed=331)
+    beta = 0.1 * _rand(C, seed=332)
+    y = torch.zeros(N, S, C, dtype=ydt, device="cuda")
+    stats = torch.empty(N, G, 2, device="cuda")
+    ops.groupnorm_fwd(dev(x), dev(gamma), dev(beta), y, stats, N, HW, C, G, 0, HW, off, S)
+    xr = x.float().permute(0, 2, 1).contiguous().requires_grad_()
+    g32, b32 = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    yr = F.group_norm(xr, G, g32, b32, 1e-5)
+    _close(y[:, off:off + HW], yr.detach().permute(0, 2, 1), ydt, msg="gn rows fwd")
+    assert (y[:, :off] == 0).all() and (y[:, off + HW:] == 0).all()          # nothing outside the level's token range
+    mu = x.float().view(N, HW, G, 8).mean((1, 3))
+    assert torch.allclose(stats[..., 0].cpu(), mu, atol=1e-5)
+    dy = torch.zeros(N, S, C)
+    dy[:, off:off + HW] = _rand(N, HW, C, seed=333)
+    dy = dy.to(ydt)
+    yr.backward(dy[:, off:off + HW].float().permute(0, 2, 1))
+    dx = torch.empty(N, HW, C, dtype=xdt, device="cuda")
+    dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+    ops.groupnorm_bwd(dev(dy), dev(x), stats, dev(gamma), dx, dg, db, N, HW, C, G, 0, HW, off, S)
+    _close(dx, xr.grad.permute(0, 2, 1), xdt, msg="gn rows dx")
+    _close(dg, g32.grad, ydt, scale=math.sqrt(N * HW), msg="gn rows dgamma")
+    _close(db, b32.grad, ydt, scale=math.sqrt(N * HW), msg="gn rows dbeta")
