@@ -165,6 +165,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const S* __restrict__ src, 
 }
 
 // ---- position encodings --------------------------------------------------------------------------
+__device__ __forceinline__ void pair_st(float* o, float a, float b) { *reinterpret_cast<float2*>(o) = make_float2(a, b); }
+__device__ __forceinline__ void pair_st(bf16_t* o, float a, float b) { *reinterpret_cast<uint32_t*>(o) = pack_bf2(a, b); }
 template <typename T>
 __global__ __launch_bounds__(256) void pos_sine_kernel(const uint8_t* __restrict__ mask, T* __restrict__ out,
                                                        const float* __restrict__ level_embed,
@@ -178,8 +180,10 @@ __global__ __launch_bounds__(256) void pos_sine_kernel(const uint8_t* __restrict
     const float two_pi = 6.283185307179586f;
     for (int x = threadIdx.x; x < W; x += 256) {
         int cy = 0, ty = 0, cx = 0, tx = 0;
-        for (int r = 0; r < H; ++r) { const int u = mb[r * W + x] ? 0 : 1; ty += u; if (r <= y) cy += u; }
-        for (int c = 0; c < W; ++c) { const int u = mb[y * W + c] ? 0 : 1; tx += u; if (c <= x) cx += u; }
+#pragma unroll 8
+        for (int r = 0; r < H; ++r) { const int u = mb[r * W + x] ? 0 : 1; ty += u; cy += (r <= y) ? u : 0; }
+#pragma unroll 8
+        for (int c = 0; c < W; ++c) { const int u = mb[y * W + c] ? 0 : 1; tx += u; cx += (c <= x) ? u : 0; }
         ey[x] = ((float)cy - 0.5f) / ((float)ty + 1e-6f) * two_pi;
         ex[x] = ((float)cx - 0.5f) / ((float)tx + 1e-6f) * two_pi;
     }
@@ -189,20 +193,30 @@ __global__ __launch_bounds__(256) void pos_sine_kernel(const uint8_t* __restrict
     // (v_sin_f32 on revolutions, abs error ~1e-6) serves them; the huge arguments of fully masked rows / columns
     // ((c - 0.5) / 1e-6) keep the exact full-range path, where 1 ulp of the argument decides the value.
     const int C2 = 2 * F, HP = F / 2;                          // pairs per half (y features | x features)
-    for (int i = threadIdx.x; i < W * F; i += 256) {
-        const int x = i / F, pr = i - x * F;                   // pair index 0 .. F-1 over both halves
+    auto emit = [&](int x, int pr, float dt, float le0, float le1) __attribute__((always_inline)) {
         const bool ypart = pr < HP;
         const int k = ypart ? pr : pr - HP;                    // pair inside the half: channels 2k, 2k+1 of it
         const float e = ypart ? ey[x] : ex[x];
-        const float arg = e / dim_t[2 * k];
+        const float arg = e / dt;
         float sv, cv;
         if (fabsf(arg) <= 8.f) { sv = __sinf(arg); cv = __cosf(arg); }
         else { sv = sinf(arg); cv = cosf(arg); }
         const int c = (ypart ? 0 : F) + 2 * k;
-        if (level_embed) { sv += level_embed[c]; cv += level_embed[c + 1]; }
         T* o = out + ((int64_t)n * tok_stride + tok_off + (int64_t)y * W + x) * C2 + c;
-        io<T>::st(o, sv);
-        io<T>::st(o + 1, cv);
+        pair_st(o, sv + le0, cv + le1);
+    };
+    if (256 % F == 0) {
+        // a thread keeps ONE pair index and walks the row: its divisor and level-embedding pair are loaded once, no index
+        // division, and the F threads of a pixel write its C2 channels as one contiguous run
+        const int pr = threadIdx.x % F, k = pr < HP ? pr : pr - HP, c = (pr < HP ? 0 : F) + 2 * k;
+        const float dt = dim_t[2 * k];
+        const float le0 = level_embed ? level_embed[c] : 0.f, le1 = level_embed ? level_embed[c + 1] : 0.f;
+        for (int x = threadIdx.x / F; x < W; x += 256 / F) emit(x, pr, dt, le0, le1);
+    } else {
+        for (int i = threadIdx.x; i < W * F; i += 256) {
+            const int x = i / F, pr = i - x * F, k = pr < HP ? pr : pr - HP, c = (pr < HP ? 0 : F) + 2 * k;
+            emit(x, pr, dim_t[2 * k], level_embed ? level_embed[c] : 0.f, level_embed ? level_embed[c + 1] : 0.f);
+        }
     }
 }
 
