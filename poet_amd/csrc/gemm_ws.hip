@@ -603,12 +603,13 @@ bool ws_launch(const GemmK& p, int nblocks, hipStream_t st) {
 
 // b_split shapes.  The two weight images take 135 KB of LDS for a 128-column slice: ONE workgroup per CU with twice the
 // waves keeps the occupancy of the plain kernel (wide outputs: 8 waves; narrow: 16 waves need <= 128 VGPRs -- variant 0),
-// or a 64-column slice keeps two workgroups per CU at twice the A re-reads through L2 (variant 1, default; variant 2 =
-// one 8-wave workgroup per CU on a 128-column slice).  POET_WS_SPLIT_NARROW selects the narrow-output variant (A/B aid).
+// or a 64-column slice keeps two workgroups per CU at twice the A re-reads through L2 (variant 1; variant 2, the default =
+// one 8-wave workgroup per CU on a 128-column slice: 13.94 against 14.01 ms per step at 640x480, 31.96 / 32.07 at 1280x960,
+// no difference at the LM-O shape).  POET_WS_SPLIT_NARROW selects the narrow-output variant (A/B aid).
 int ws_blocks(int N, int BN, int wg_per_cu);
 template <typename TC, int KIND>
 bool ws_launch_split(const GemmK& p, hipStream_t st) {
-    static const int narrow = [] { const char* e = getenv("POET_WS_SPLIT_NARROW"); return e ? atoi(e) : 1; }();
+    static const int narrow = [] { const char* e = getenv("POET_WS_SPLIT_NARROW"); return e ? atoi(e) : 2; }();
     if (p.d.N <= 256) {
         if (narrow == 2) ws_launch_cfg<TC, KIND, false, 1, 512, true, 128>(p, ws_blocks(p.d.N, 128, 1), st);
         else ws_launch_cfg<TC, KIND, false, 1, 512, true, 64>(p, ws_blocks(p.d.N, 64, 2), st);
