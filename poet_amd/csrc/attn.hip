@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
 #pragma unroll
     for (int c = 0; c < HD; ++c) qr[c] = p.q[(rbase + lane) * p.ld + m * HD + c] * p.scale;
     float mx = -3.0e38f;
-#pragma unroll 2
+#pragma unroll 4
     for (int j = 0; j < Q; ++j) {
         float s = 0.f;
 #pragma unroll
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
         mx = fmaxf(mx, s);
     }
     float sum = 0.f;
-#pragma unroll 2
+#pragma unroll 4
     for (int j = 0; j < Q; ++j) {
         const float e = __expf(sp[lane * (Q + 1) + j] - mx);
         sp[lane * (Q + 1) + j] = e;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
 #pragma unroll
     for (int c = 0; c < HD; ++c) acc[c] = 0.f;
     const uint32_t ibase = ((uint32_t)blockIdx.x * Q + lane) * Q;
-#pragma unroll 2
+#pragma unroll 4
     for (int j = 0; j < Q; ++j) {
         float pj = sp[lane * (Q + 1) + j] * inv;
         if (p.thresh) pj = drop_keep(p.seed ^ (p.seed_dev ? *p.seed_dev * 0x9E3779B1u : 0u), ibase + j, p.thresh) ? pj * p.dscale : 0.f;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
 #pragma unroll
         for (int c = 0; c < HD; ++c) { qr[c] = sq[lane * PH + c]; dor[c] = sdo[lane * PH + c]; }
         float mx = -3.0e38f;
-    #pragma unroll 2
+    #pragma unroll 4
     for (int j = 0; j < Q; ++j) {
             float s = 0.f;
 #pragma unroll
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
             mx = fmaxf(mx, s);
         }
         float sum = 0.f;
-    #pragma unroll 2
+    #pragma unroll 4
     for (int j = 0; j < Q; ++j) {
             const float e = __expf(spd[lane * PQ + j] - mx);
             spd[lane * PQ + j] = e;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         const float inv = 1.f / sum;
         const uint32_t ibase = ((uint32_t)blockIdx.x * Q + lane) * Q;
         float dot = 0.f;
-    #pragma unroll 2
+    #pragma unroll 4
     for (int j = 0; j < Q; ++j) {
             const float pj = spd[lane * PQ + j] * inv;
             float keep = 1.f;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         float dqr[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) dqr[c] = 0.f;
-    #pragma unroll 2
+    #pragma unroll 4
     for (int j = 0; j < Q; ++j) {
             // recover p_j from the dropped value is not possible when keep == 0, so recompute it
             float s = 0.f;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         float dkr[HD], dvr[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) { dkr[c] = 0.f; dvr[c] = 0.f; }
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < Q; ++i) {
             const float ds = sds[i * PQ + lane], pd = spd[i * PQ + lane];
 #pragma unroll
