@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define POET_ABI_VERSION 1
+#define POET_ABI_VERSION 2
 #define POET_SQNORM_SCRATCH 1024
 
 #define POET_F32 0
@@ -110,7 +110,7 @@ typedef struct PoetGemmDesc {
     int32_t out_mode, hm_M, hm_S, hm_D;
     const uint32_t* seed_dev; /* optional device word XOR-mixed into `seed` at run time: lets a captured hipGraph draw a
                                  fresh dropout mask on every replay (the host bumps the word between replays) */
-    int32_t b_split;       /* 1: B is an fp32 [N,K] weight used as bf16 hi + bf16 lo, lo = bf16(B - float(hi)): two
+    int32_t b_split;       /* 1 (B fp32): B is an fp32 [N,K] weight used as bf16 hi + bf16 lo, lo = bf16(B - float(hi)): two
                               v_mfma_f32_16x16x32_bf16 per fragment pair, so the WEIGHT enters with 16 mantissa bits while
                               the activation operand stays plain bf16 (needs b_dtype f32, compute bf16, b_kmajor 0).  Weight
                               rounding is the same perturbation for every token and does not average out downstream the way
@@ -120,6 +120,10 @@ typedef struct PoetGemmDesc {
                               partial tiles with plain stores + one reduction launch instead of fp32 atomics.  Contents are
                               undefined afterwards; calls sharing it must be ordered on one stream. */
     int64_t workspace_bytes;
+    const void* B_lo;      /* optional, with b_split = 1 and a BF16 B: the second bf16 image of the weight (lo = bf16(W - float(hi)),
+                              same layout and ldb as B, which then holds hi) -- the two images the optimiser kernel maintains
+                              (poet_adamw p_bf16 / p_bf16_lo); the long-K kernel multiplies every activation fragment with both
+                              in one pass over A */
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
 /* Which kernel family the calling thread's last successful poet_gemm launched (profiling aid: lets a caller attribute a
@@ -130,7 +134,7 @@ int poet_gemm(const PoetGemmDesc* desc, void* stream);
 int poet_gemm_dw_list(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n,
                       int n_out, int k_in, int rows, int64_t ldy, int64_t ldx, int64_t ldw, void* stream);
 enum { POET_GEMM_PATH_NONE = 0, POET_GEMM_PATH_TILED = 1, POET_GEMM_PATH_STREAM = 2, POET_GEMM_PATH_DW = 3, POET_GEMM_PATH_SMALL = 4,
-       POET_GEMM_PATH_LT = 5 /* hipBLASLt: plain bf16 x bf16 -> fp32 (+=) products with K >= 512 */ };
+       POET_GEMM_PATH_PIPE = 5 /* deep-pipeline kernel: plain bf16 x bf16 -> fp32 (+=) products with N = 256, K >= 512 */ };
 int poet_gemm_last_path(void);
 
 /* ------------------------------------------------------------------------------------------------

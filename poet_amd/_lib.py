@@ -26,6 +26,7 @@ class GemmDesc(C.Structure):
         ("alpha", f32), ("gate_scale", f32), ("drop_p", f32), ("seed", u32),
         ("out_mode", C.c_int32), ("hm_M", C.c_int32), ("hm_S", C.c_int32), ("hm_D", C.c_int32),
         ("seed_dev", vp), ("b_split", C.c_int32), ("reserved0", C.c_int32), ("workspace", vp), ("workspace_bytes", i64),
+        ("B_lo", vp),
     ]
 
 
@@ -93,7 +94,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError here = header/library mismatch
         fn.argtypes = args
         fn.restype = res
-    if lib.poet_hip_version() != 1:
+    if lib.poet_hip_version() != 2:
         raise PoetHipError("libpoet_hip.so ABI version mismatch")
     _lib = lib
     return lib

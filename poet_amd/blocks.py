@@ -169,13 +169,11 @@ def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=Non
     mixed = x_in.dtype == torch.bfloat16 and res.dtype == torch.float32
     Wt, sp = Wf(W, x_in, split)
     tmp = empty((rows, d), torch.float32 if (sp and mixed) else x_in.dtype, res)
-    lo = getattr(W, "_bf16_lo", None) if (sp and mixed and rows >= 4096 and W.shape[1] >= 512) else None
-    if lo is not None and getattr(W, "_bf16", None) is not None and ops.two_pass_split():
-        # long-K split product as two PLAIN GEMMs on the arena's bf16 shadows, tmp = x hi^T + b, then tmp += x lo^T: plain
-        # products with K >= 512 run on the vendor kernel (gemm_lt.hip), 67 + 75 us against 178 us for the K-chunked
-        # split-weight kernel at K = 1024
-        ops.linear_fwd(x_in, W._bf16, b, tmp)
-        ops.linear_fwd(x_in, lo, None, tmp, add_src=tmp)
+    lo = getattr(W, "_bf16_lo", None) if (sp and mixed and rows >= 4096 and W.shape[1] >= 512 and W.shape[0] == 256) else None
+    if lo is not None and getattr(W, "_bf16", None) is not None and ops.pipe_split():
+        # long-K split product on the arena's two bf16 images, tmp = x (hi + lo)^T + b in ONE pass over x (gemm_pipe.hip):
+        # every activation fragment staged in LDS meets both weight images
+        ops.linear_fwd(x_in, W._bf16, b, tmp, W_lo=lo)
     else:
         ops.linear_fwd(x_in, Wt, b, tmp, split=sp)
     y = torch.empty_like(res) if y_out is None else y_out      # residual-stream dtype (y_out: the caller's buffer, e.g. a row of hs)

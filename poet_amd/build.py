@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpoet_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "gemm_dw.hip", "gemm_small.hip", "gemm_lt.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "gemm_dw.hip", "gemm_small.hip", "gemm_pipe.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
 RESOURCES = os.path.join(CSRC, "kernel_resources.txt")      # per-kernel VGPRs / scratch of the last build (git-ignored)
@@ -123,7 +123,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
             reports = list(ex.map(run, jobs))
         _write_resources([r for r in reports if r], verbose)
     if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lhipblaslt", "-o", LIB])
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB
 
 

@@ -16,8 +16,8 @@ struct GemmK {
 bool gemm_ws_try(const GemmK& p, hipStream_t st);
 // same contract for the weight-gradient kernel (gemm_dw.hip)
 bool gemm_dw_try(const GemmK& p, hipStream_t st);
-// plain tall-skinny bf16 x bf16 -> fp32 (+=) products through hipBLASLt (gemm_lt.hip)
-bool gemm_lt_try(const GemmK& p, hipStream_t st);
+// plain tall-skinny bf16 x bf16 -> fp32 (+=) products with N = 256, K >= 512: the deep-pipeline kernel (gemm_pipe.hip)
+bool gemm_pipe_try(const GemmK& p, hipStream_t st);
 // latency-oriented fp32 kernel for the <= 1024-row decoder / head Linears (gemm_small.hip)
 bool gemm_small_try(const GemmK& p, hipStream_t st);
 // dW[i] += Y[i]^T X[i] (+ column sums of Y[i]) for n <= 8 fp32 problems of one shape, rows <= 1024, in one launch

@@ -466,9 +466,14 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.out_mode == 1) POET_CHECK(d.hm_M > 0 && d.hm_S > 0 && d.hm_D > 0 && d.hm_M * d.hm_D == d.N, POET_ERR_ARG, "poet_gemm: head-major dims");
-    if (d.b_split)
+    if (d.b_split && d.B_lo)
+        POET_CHECK(d.b_dtype == POET_BF16 && d.compute == POET_BF16 && !atomic, POET_ERR_ARG,
+                   "poet_gemm: b_split with B_lo needs two bf16 weight images, bf16 compute, no split-K");
+    else if (d.b_split)
         POET_CHECK(d.b_dtype == POET_F32 && d.compute == POET_BF16 && !d.b_kmajor && !atomic, POET_ERR_ARG,
                    "poet_gemm: b_split needs an fp32 [N,K] weight, bf16 compute, no split-K");
+    else
+        POET_CHECK(d.B_lo == nullptr, POET_ERR_ARG, "poet_gemm: B_lo without b_split");
     const int tcs = tile_choice(d);
     const int BKB = d.b_split ? (tcs == 0 ? split_bkb() : 128) : (tcs == 0 ? 128 : (tcs == 3 ? 1024 : 256));
     const int BK = BKB / (d.compute == POET_BF16 ? 2 : 4);
@@ -500,10 +505,13 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     }
     POET_CHECK(d.batch == 1 || (!d.add_src && !d.gate_ref), POET_ERR_UNSUPPORTED,
                "poet_gemm: batched add_src / gate_ref only in the <= 1024-row kernels");
-    if (gemm_lt_try(p, st)) {                               // plain K >= 512 products: the vendor library (gemm_lt.hip)
-        g_last_path = POET_GEMM_PATH_LT;
+    if (gemm_pipe_try(p, st)) {                             // plain N = 256, K >= 512 products: the deep-pipeline kernel (gemm_pipe.hip)
+        g_last_path = POET_GEMM_PATH_PIPE;
+        POET_LAUNCH_CHECK();
         return POET_OK;
     }
+    POET_CHECK(d.B_lo == nullptr, POET_ERR_UNSUPPORTED,
+               "poet_gemm: two-image split weights (B_lo) only in the long-K kernel (N = 256, K >= 512, K %% 64 == 0, M >= 4096)");
     if (gemm_ws_try(p, st)) {
         g_last_path = POET_GEMM_PATH_STREAM;
         POET_LAUNCH_CHECK();

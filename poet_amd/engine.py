@@ -505,9 +505,11 @@ class SetCriterion(nn.Module):
             self._lsa_status = torch.zeros(1, dtype=torch.int32, device=dev)
         col = torch.empty((N, Q), dtype=torch.int32, device=dev)
         ops.lsa_boxes(pb.float().contiguous(), tb, meta_d[: N + 1], meta_d[N + 1:], col, self._lsa_status, self.matcher.cost_bbox)
-        qi = torch.empty(n_obj, dtype=torch.int64, device=dev)
-        tt = torch.empty((n_obj, 3), dtype=torch.float32, device=dev)
-        tr = torch.empty((n_obj, 3, 3), dtype=torch.float32, device=dev)
+        # zero-filled: should the assignment kernel bail out (status != 0: non-finite costs) fewer than n_obj slots are written,
+        # and the loss kernel must then still index valid rows (oversized problems never get here: see forward())
+        qi = torch.zeros(n_obj, dtype=torch.int64, device=dev)
+        tt = torch.zeros((n_obj, 3), dtype=torch.float32, device=dev)
+        tr = torch.zeros((n_obj, 3, 3), dtype=torch.float32, device=dev)
         ops.match_gather(col, meta_d[: N + 1], tpos, trot, qi, tt, tr)
         self._last_col = col
         return qi, tt, tr, n_obj
@@ -558,7 +560,9 @@ class SetCriterion(nn.Module):
         dev = outputs["pred_translation"].device
         stacked0 = outputs.get("_stacked")
         if (self.default_terms and getattr(self.matcher, "device_assign", False) and dev.type == "cuda" and stacked0 is not None
-                and stacked0[0].shape[0] == len(aux_list) + 1):
+                and stacked0[0].shape[0] == len(aux_list) + 1
+                # poet_lsa_boxes solves <= 64 x 64 per image; larger problems take the host (SciPy) matcher below
+                and outputs["pred_boxes"].shape[1] <= 64 and all(int(t["boxes"].shape[0]) <= 64 for t in targets)):
             # every decoder layer carries the same query boxes in 'gt' mode: ONE assignment, solved on the GPU, feeds the fused
             # loss of all layers
             from .functional import PoseLossFn
@@ -773,7 +777,12 @@ class GraphedTrainer(Trainer):
     Host work per step: pad/pack the boxes, three small H2D copies, the matcher, the loss and its backward (eager).
     Requirements: fixed batch size / image geometry, model in train() mode for the whole run."""
 
-    def __init__(self, model, criterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=3, segment_backward=None):
+    def __init__(self, model, criterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=3, segment_backward=None,
+                 persistent_inputs=False):
+        """persistent_inputs=True: the caller promises that the feature / mask tensors it passes are the SAME buffers on every
+        step (a backbone writing into fixed outputs); they are then used as the graphs' static inputs without a copy.  The
+        default keeps private static buffers and copies every step's inputs into them -- the trainer never writes into a
+        tensor it does not own."""
         # the base class broadcasts the parameters and owns the bucket reducer used by the EAGER warm-up steps (without it
         # the ranks would drift apart before the graphs are captured); the captured steps all-reduce the whole arena
         # themselves (see _Replay.backward) and run with the reducer detached
@@ -784,6 +793,7 @@ class GraphedTrainer(Trainer):
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena.world = self.world
         self.warm, self.calls, self.ready = warm, 0, False
+        self.persistent_inputs = bool(persistent_inputs)
         if segment_backward is None:         # per-bucket backward graphs: needed (only) to overlap all-reduces with backward
             segment_backward = (self.reducer is not None and self.reducer.active) or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
         self.segment_backward = bool(segment_backward)
@@ -845,12 +855,13 @@ class GraphedTrainer(Trainer):
     def _capture(self, samples, targets):
         m, dev = self.model, self.arena.flat.device
         features, boxes, classes, valid, _ = self._static_inputs(samples, targets)
-        self.s_feats = [f.tensors for f in features]
-        # static mask buffers = the caller's own tensors (no clone): a backbone / loader that hands over the same buffers every
-        # step costs no copy at all (as for the feature maps); anything else is copied into them each step
+        # static input buffers are PRIVATE clones unless the caller registered its buffers as persistent: step() copies into
+        # them, and writing into a tensor the caller owns would corrupt a batch that is stepped again later
         u8 = lambda t: t.contiguous().view(torch.uint8) if t.dtype == torch.bool else t.contiguous()
-        self.s_fmasks = [u8(f.mask) for f in features]
-        self.s_imask = u8(samples.mask)
+        own = (lambda t: t) if self.persistent_inputs else (lambda t: t.clone())
+        self.s_feats = [own(f.tensors.contiguous()) for f in features]
+        self.s_fmasks = [own(u8(f.mask)) for f in features]
+        self.s_imask = own(u8(samples.mask))
         # pinned staging ring: the host may run several steps ahead of the GPU, so a slot is only rewritten after the
         # H2D copies that read it have completed (event per slot)
         self.ring = [dict(boxes=torch.from_numpy(boxes.copy()).pin_memory(), cls=torch.from_numpy(classes.copy()).pin_memory(),
@@ -1067,7 +1078,7 @@ class GraphedInference:
         u8 = lambda t: t.contiguous().view(torch.uint8) if t.dtype == torch.bool else t.contiguous()
         if not self.ready:
             dev = features[0].tensors.device
-            self.s_feats = [f.tensors for f in features]
+            self.s_feats = [f.tensors.contiguous().clone() for f in features]
             self.s_fmasks = [u8(f.mask).clone() for f in features]
             self.s_imask = u8(samples.mask).clone()
             self.pin = [torch.from_numpy(a.copy()).pin_memory() for a in (boxes, classes, valid)]

@@ -15,8 +15,8 @@ import struct as _struct
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 # PoetGemmDesc as one packed record (natural C layout of include/poet_hip.h; checked against ctypes below)
-_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i Q q")     # native alignment inserts the same padding as the C compiler
-assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 32 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
+_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i Q q Q")     # native alignment inserts the same padding as the C compiler
+assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 40 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
 
 # Device word mixed into every dropout seed (and the Adam step) at run time.  None in eager mode; engine.GraphedTrainer
 # sets it so captured hipGraphs draw fresh masks on each replay.
@@ -30,17 +30,19 @@ _GEMM_DESC = GemmDesc()
 _GEMM_BUF = (C.c_char * C.sizeof(GemmDesc)).from_buffer(_GEMM_DESC)
 
 
-# Caller-owned scratch handed to the weight-gradient GEMMs (PoetGemmDesc.workspace): one buffer per device, allocated on first use
-# (before any graph capture: the eager warm-up steps run every shape) and shared by all dW launches of the process -- they are
-# ordered on one stream.
+# Caller-owned scratch handed to the weight-gradient GEMMs and the whole-row GroupNorm kernels (PoetGemmDesc.workspace,
+# `scratch`): one buffer per (device, launch stream), allocated on first use (before any graph capture: the eager warm-up
+# steps run every shape).  Users of one buffer are ordered on its stream; the side stream of POET_SIDE_STREAM=1 (weight
+# gradients forked off the main stream) gets its own, so a dW reduction never shares scratch with a kernel of the main stream.
 _WORKSPACE = {}
 _WORKSPACE_BYTES = 48 << 20
 
 
 def _workspace(device):
-    ws = _WORKSPACE.get(device)
+    key = (device, _STREAM_OVERRIDE[0] if SIDE.stream is not None and _STREAM_OVERRIDE[0] == SIDE.stream.cuda_stream else 0)
+    ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = _WORKSPACE[device] = torch.empty(_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        ws = _WORKSPACE[key] = torch.empty(_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -188,7 +190,7 @@ def _esz(t):
     return t.element_size()
 
 
-_GEMM_PATHS = {0: "none", 1: "tiled", 2: "stream", 3: "dw", 4: "small", 5: "lt"}
+_GEMM_PATHS = {0: "none", 1: "tiled", 2: "stream", 3: "dw", 4: "small", 5: "pipe"}
 
 
 class LevelGeom:
@@ -215,7 +217,7 @@ class LevelGeom:
 def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
          a_kmajor=False, b_kmajor=False, bias=None, act=0, add_src=None, ld_add=0, gate_ref=None, gate_scale=1.0,
          row_mask=None, drop_p=0.0, seed=0, compute=None, batch=1, strideA=0, strideB=0, strideC=0, stride_bias=0,
-         splitk=1, atomic=False, alpha=1.0, head_major=None, b_split=False):
+         splitk=1, atomic=False, alpha=1.0, head_major=None, b_split=False, B_lo=None):
     lib = _lib.load()
     if not (A.is_cuda and B.is_cuda and Cout.is_cuda):
         raise _lib.PoetHipError("poet_amd: GEMM operands must live on the GPU (no CPU path exists)")
@@ -225,9 +227,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
     hm = head_major or (0, 0, 0)
-    # caller-owned scratch: partial tiles of the weight-gradient form; hipBLASLt's workspace for the plain K >= 512 products
-    ws = _workspace(Cout.device).data_ptr() if ((atomic and a_kmajor and b_kmajor and batch == 1 and K >= 4096) or
-                                                (M >= 4096 and K >= 512 and cd == F32 and ad == BF16 and bd == BF16 and batch == 1 and not atomic)) else 0
+    # caller-owned scratch: partial tiles of the weight-gradient form
+    ws = _workspace(Cout.device).data_ptr() if (atomic and a_kmajor and b_kmajor and batch == 1 and K >= 4096) else 0
     d = _GEMM_DESC
     _GEMM_PACK.pack_into(_GEMM_BUF, 0, A.data_ptr(), 0, B.data_ptr(), Cout.data_ptr(),
                          0 if bias is None else bias.data_ptr(), 0 if add_src is None else add_src.data_ptr(),
@@ -235,7 +236,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                          M, N, K, lda, ldb, ldc, ld_add, int(a_kmajor), int(b_kmajor), ad, bd, cd, compute, batch,
                          strideA, strideB, strideC, stride_bias, splitk, int(atomic), act, alpha, gate_scale, drop_p,
                          seed & 0xFFFFFFFF, 1 if head_major is not None else 0, hm[0], hm[1], hm[2],
-                         (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), 0, ws, _WORKSPACE_BYTES if ws else 0)
+                         (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), 0, ws, _WORKSPACE_BYTES if ws else 0,
+                         0 if B_lo is None else B_lo.data_ptr())
     if PROFILE.on:
         e0 = PROFILE.begin()
         _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
@@ -256,14 +258,15 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
 
 
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, *, act=0,
-               drop_p=0.0, seed=0, row_mask=None, add_src=None, head_major=None, ldc=None, ldx=None, split=False):
+               drop_p=0.0, seed=0, row_mask=None, add_src=None, head_major=None, ldc=None, ldx=None, split=False, W_lo=None):
     """out[rows, N] = act(x[rows, K] @ W[N, K]^T + b).  x / out may be column slices (ldx / ldc).
-    split: W is the fp32 master, used as bf16 hi + bf16 lo (PoetGemmDesc.b_split)."""
+    split: W is the fp32 master, used as bf16 hi + bf16 lo (PoetGemmDesc.b_split); or, with W_lo, W and W_lo are the two
+    bf16 images the optimiser maintains (PoetGemmDesc.B_lo: the long-K kernel, one pass over x)."""
     rows = x.numel() // x.shape[-1] if ldx is None else x.shape[0]
     N, K = W.shape
     return gemm(x, W, out, rows, N, K, lda=ldx or K, ldb=K, ldc=ldc or N, bias=b, act=act, drop_p=drop_p, seed=seed,
                 row_mask=row_mask, add_src=add_src, ld_add=(ldc or N), head_major=head_major,
-                b_split=split, compute=BF16 if split else None)
+                b_split=split or W_lo is not None, B_lo=W_lo, compute=BF16 if (split or W_lo is not None) else None)
 
 
 def linear_dx(dy: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, rows: int, ldy=None, add_src=None,
@@ -521,9 +524,10 @@ def colsum(x, ld, out, batch, rows_per_batch, cols, segs=None, nseg=1):
                                _stream()), "poet_colsum")
 
 
-def two_pass_split() -> bool:
-    """long-K split-weight products as two plain GEMMs (POET_NO_TWO_PASS_SPLIT=1 or POET_GEMM_NO_LT=1: the split-weight kernel)."""
-    return os.environ.get("POET_NO_TWO_PASS_SPLIT", "0") in ("", "0") and os.environ.get("POET_GEMM_NO_LT", "0") in ("", "0")
+def pipe_split() -> bool:
+    """long-K split-weight products on the deep-pipeline kernel with the arena's two bf16 weight images (POET_GEMM_NO_PIPE=1: the
+    K-chunked weight-stationary kernel on the fp32 master)."""
+    return os.environ.get("POET_GEMM_NO_PIPE", "0") in ("", "0")
 
 
 def tiled_scatter_bf16() -> bool:
