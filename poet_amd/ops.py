@@ -527,7 +527,7 @@ def colsum(x, ld, out, batch, rows_per_batch, cols, segs=None, nseg=1):
 def pipe_split() -> bool:
     """long-K split-weight products on the deep-pipeline kernel with the arena's two bf16 weight images (POET_GEMM_NO_PIPE=1: the
     K-chunked weight-stationary kernel on the fp32 master)."""
-    return os.environ.get("POET_GEMM_NO_PIPE", "0") in ("", "0")
+    return os.environ.get("POET_GEMM_NO_PIPE", "0") in ("", "0") and os.environ.get("POET_NO_PIPE_SPLIT", "0") in ("", "0")
 
 
 def tiled_scatter_bf16() -> bool:

@@ -1009,48 +1009,80 @@ def test_lsa_boxes_matches_scipy_including_ties(ops):
         assert np.array_equal(col[i], exp), (i, n_pred[i], len(tgts[i]), col[i][:12], exp[:12])
 
 
-def test_gemm_plain_large_k_vendor_route(ops, monkeypatch):
-    """Plain tall-skinny products C (fp32) (+)= A (bf16) W (bf16) with K >= 512 -- the encoder's K = 768 / 1024 / 1280 input
-    gradients -- are routed to hipBLASLt (gemm_lt.hip); same result as the library's own tiled kernel (POET_GEMM_NO_LT is read
-    once per process, so the reference here is torch), for both weight layouts, written and accumulated."""
+@pytest.mark.parametrize("M", [5000 + 8, 4096, 16 * 417 + 5, 53 * 256])
+@pytest.mark.parametrize("K", [512, 1024, 1280])
+def test_gemm_pipe_long_k(ops, M, K):
+    """Plain tall-skinny products C (fp32) (+)= A (bf16) W (bf16) with N = 256, K >= 512 -- the encoder's K = 1024 / 1280 input
+    gradients and the FFN's second Linear -- run on the library's own deep-pipeline kernel (gemm_pipe.hip: persistent, LDS-DMA
+    rings, transposing LDS reads for the [K][N] weight) and nothing else: against a float64 product, for both weight layouts,
+    written (+ bias) and accumulated in place, on row counts that are ragged (partial last 16-row unit), smaller than one unit
+    per CU, and that give every workgroup tiles of unequal height; results must be bit-identical between calls (no atomics, no
+    arrival order) -- and the two-image split product (B_lo) must equal the fp32 weight to 2^-16."""
     import poet_amd._lib as L
     lib = L.load()
-    M = 5000 + 8
-    for K, N in ((1024, 256), (768, 256), (1280, 256), (512, 128)):
-        a = _rand(M, K, seed=300 + K).to(torch.bfloat16)
-        w_kn = _rand(K, N, seed=301 + K, scale=1 / math.sqrt(K)).to(torch.bfloat16)      # W[K][N]: the dX form (weight (n_out, k_in))
-        acc0 = _rand(M, N, seed=302 + K)
-        ref = a.float() @ w_kn.float()
-        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
-        ops.linear_dx(dev(a), dev(w_kn), out, rows=M)
-        assert lib.poet_gemm_last_path() == 5, lib.poet_gemm_last_path()                 # POET_GEMM_PATH_LT
-        assert (out.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
-        acc = dev(acc0.clone())
-        ops.linear_dx(dev(a), dev(w_kn), acc, rows=M, add_src=acc)
-        assert lib.poet_gemm_last_path() == 5
-        assert (acc.cpu() - (ref + acc0)).abs().max().item() <= 2e-3 * (ref + acc0).abs().max().item()
-        # [N][K] weight (the forward form), plain fp32 output
-        out2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
-        ops.linear_fwd(dev(a), dev(w_kn.t().contiguous()), None, out2)
-        assert (out2.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
-        # a split-weight product as two plain ones on the bf16 shadows (hi, lo = bf16(W - hi)), bias on the first:
-        # == the split-weight kernel on the fp32 master, and both == the fp32 weight to 2^-16
-        w32 = _rand(N, K, seed=303 + K, scale=1 / math.sqrt(K))
-        bias = _rand(N, seed=304 + K)
-        hi = w32.to(torch.bfloat16)
-        lo = (w32 - hi.float()).to(torch.bfloat16)
-        two = torch.empty(M, N, dtype=torch.float32, device="cuda")
-        ops.linear_fwd(dev(a), dev(hi), dev(bias), two)
-        assert lib.poet_gemm_last_path() == 5
-        ops.linear_fwd(dev(a), dev(lo), None, two, add_src=two)
-        assert lib.poet_gemm_last_path() == 5
-        one = torch.empty(M, N, dtype=torch.float32, device="cuda")
-        ops.linear_fwd(dev(a), dev(w32), dev(bias), one, split=True)
-        exact = a.double() @ w32.double().t() + bias.double()
-        sc = exact.abs().max().item()
-        assert (two.double().cpu() - exact).abs().max().item() <= 1e-4 * sc
-        assert (one.double().cpu() - exact).abs().max().item() <= 1e-4 * sc
-        assert (two.cpu() - one.cpu()).abs().max().item() <= 2e-5 * sc
+    N = 256
+    a = _rand(M, K, seed=300 + K).to(torch.bfloat16)
+    w_kn = _rand(K, N, seed=301 + K, scale=1 / math.sqrt(K)).to(torch.bfloat16)      # W[K][N]: the dX form (weight (n_out, k_in))
+    acc0 = _rand(M, N, seed=302 + K)
+    bias = _rand(N, seed=304 + K)
+    ref = a.double() @ w_kn.double()
+    sc = ref.abs().max().item()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    ops.linear_dx(dev(a), dev(w_kn), out, rows=M)
+    assert lib.poet_gemm_last_path() == 5, lib.poet_gemm_last_path()                 # POET_GEMM_PATH_PIPE
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-5 * sc
+    out_b = torch.full_like(out, float("nan"))
+    ops.linear_dx(dev(a), dev(w_kn), out_b, rows=M)
+    assert torch.equal(out, out_b)                                                    # deterministic
+    acc = dev(acc0.clone())
+    ops.linear_dx(dev(a), dev(w_kn), acc, rows=M, add_src=acc)
+    assert lib.poet_gemm_last_path() == 5
+    assert (acc.double().cpu() - (ref + acc0.double())).abs().max().item() <= 2e-5 * (sc + acc0.abs().max().item())
+    # [N][K] weight (the forward form) + bias
+    out2 = torch.full_like(out, float("nan"))
+    ops.linear_fwd(dev(a), dev(w_kn.t().contiguous()), dev(bias), out2)
+    assert lib.poet_gemm_last_path() == 5
+    assert (out2.double().cpu() - (ref + bias.double())).abs().max().item() <= 2e-5 * sc
+    # row-strided operands: A and C as column blocks of wider buffers (the packed [d(offsets|logits) | d(value) rows] buffer)
+    wide = torch.zeros(M, K + 64, dtype=torch.bfloat16, device="cuda")
+    wide[:, 32:32 + K] = dev(a)
+    cw = torch.zeros(M, N + 8, dtype=torch.float32, device="cuda")
+    ops.gemm(wide[:, 32:], dev(w_kn), cw[:, 4:], M, N, K, lda=K + 64, ldb=N, ldc=N + 8, b_kmajor=True)
+    assert lib.poet_gemm_last_path() == 5
+    assert (cw[:, 4:4 + N].double().cpu() - ref).abs().max().item() <= 2e-5 * sc and (cw[:, :4] == 0).all() and (cw[:, 4 + N:] == 0).all()
+    # the split-weight product on two bf16 images (hi, lo = bf16(W - hi)): ONE pass; == the fp32 weight to 2^-16, and == the
+    # split-weight kernel that takes the fp32 master
+    w32 = _rand(N, K, seed=303 + K, scale=1 / math.sqrt(K))
+    hi = w32.to(torch.bfloat16)
+    lo = (w32 - hi.float()).to(torch.bfloat16)
+    two = torch.full_like(out, float("nan"))
+    ops.linear_fwd(dev(a), dev(hi), dev(bias), two, W_lo=dev(lo))
+    assert lib.poet_gemm_last_path() == 5
+    exact = a.double() @ w32.double().t() + bias.double()
+    sc = exact.abs().max().item()
+    assert (two.double().cpu() - exact).abs().max().item() <= 2e-5 * sc
+    one = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.linear_fwd(dev(a), dev(w32), dev(bias), one, split=True)
+    assert (two.cpu() - one.cpu()).abs().max().item() <= 2e-5 * sc
+    single = torch.empty_like(one)
+    ops.linear_fwd(dev(a), dev(hi), dev(bias), single)
+    assert (single.double().cpu() - exact).abs().max().item() > 20 * (two.double().cpu() - exact).abs().max().item()
+
+
+def test_gemm_pipe_grid_independent(ops):
+    """The persistent kernel deals 16-row units to workgroups and cuts them into tiles; the result may not depend on how:
+    bit-identical outputs for 256 and 7 workgroups (POET_PIPE_GRID is latched per process: run the second in a fresh one)."""
+    import subprocess, sys, os
+    code = ("import torch, math, sys, hashlib; sys.path.insert(0, %r); from poet_amd import ops; from tests.test_kernels_gpu import _rand;"
+            "M,K,N=6000,1024,256; a=_rand(M,K,seed=1).to(torch.bfloat16).cuda(); w=_rand(K,N,seed=2,scale=1/32).to(torch.bfloat16).cuda();"
+            "c=_rand(M,N,seed=3).cuda(); ops.linear_dx(a,w,c,rows=M,add_src=c); print('SUM', hashlib.sha1(c.cpu().numpy().tobytes()).hexdigest())"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for grid in ("0", "7", "100"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, POET_PIPE_GRID=grid), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("SUM")][0])
+    assert outs[0] == outs[1] == outs[2], outs
 
 
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])

@@ -355,8 +355,8 @@ def test_arena_trainer_matches_oracle_step(gpu):
 def test_arena_paths_match_plain_model_at_full_size(gpu):
     """Everything that only exists with the flat parameter arena -- the stacked [offsets | logits] Linear, the K = 1024 input
     gradient over [W_so ; W_aw ; W_v] with its shared gradient-row buffer, the decoder's stacked value projections, the
-    two-pass split FFN2 on the hi / lo shadows, gradients written straight into arena views -- at YCB-V geometry (6380 token rows
-    per image: the streaming / vendor-route kernels the benchmark runs).  Two bf16 programs whose forwards differ by one
+    one-pass split FFN2 on the hi / lo shadows (gemm_pipe.hip), gradients written straight into arena views -- at YCB-V geometry
+    (6380 token rows per image: the streaming / long-K kernels the benchmark runs).  Two bf16 programs whose forwards differ by one
     rounding somewhere differ by a few percent in their gradients (that IS the bf16 noise floor: GRAD_TOL_BF16), so the
     yardstick is the fp32 policy of the same model (whose gradients the goldens of the real reference pin): the arena's bf16
     gradients must be as close to it as the plain model's bf16 gradients are."""
@@ -389,9 +389,13 @@ def test_arena_paths_match_plain_model_at_full_size(gpu):
         return (num / max(den, 1e-30)) ** 0.5
     names = sorted(grads["fp32"])
     ga, gp = l2("arena", names), l2("plain", names)
-    bad = [(n, l2("arena", [n]), l2("plain", [n])) for n in names if l2("arena", [n]) > 3.0 * l2("plain", [n]) + 2e-2]
+    # per tensor: within the bf16 gradient tolerance the reference goldens are held to (GRAD_TOL_BF16 of the tensor's norm), or
+    # within 3x of what the plain bf16 program shows on a tensor where that itself is larger (the sampling_offsets tensors: ~0.13)
+    bad = [(n, l2("arena", [n]), l2("plain", [n])) for n in names if l2("arena", [n]) > max(3.0 * l2("plain", [n]), GRAD_TOL_BF16)]
     print(f"bf16 gradients vs the fp32 policy at YCB-V size, relative L2 over all {len(names)} tensors: arena {ga:.4f}, plain {gp:.4f}; "
           f"losses fp32 {losses['fp32']:.5f} plain {losses['plain']:.5f} arena {losses['arena']:.5f}")
+    top = sorted(((l2("arena", [n]), l2("plain", [n]), n) for n in names), reverse=True)[:5]
+    print("largest per-tensor arena errors (arena, plain, name):", [(round(a, 4), round(b, 4), n) for a, b, n in top])
     assert ga < 1.3 * gp + 2e-3, (ga, gp)
     assert not bad, bad[:8]
 
