@@ -93,7 +93,7 @@ def gemm_flops_per_image(cfg):
 # config): (2 * FETCH_SIZE + WRITE_SIZE) KiB -- the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None when
 # the family is not in the summary.
 # profile tag (poet_amd/ops.py) -> substring of the kernel symbols in the summaries
-_PMC_NAMES = {"gemm_lt": "hipblaslt_Cijk", "msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_shared_kernel|msda_bwd_kernel<bf16, bf16", "msda_fused_fwd": "msda_fwd_shared_kernel|msda_fwd_kernel<bf16, bf16",
+_PMC_NAMES = {"gemm_pipe": "gemm_pipe_kernel", "msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_shared_kernel|msda_bwd_kernel<bf16, bf16", "msda_fused_fwd": "msda_fwd_shared_kernel|msda_fwd_kernel<bf16, bf16",
               "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws", "gemm_stream_fwd": "gemm_ws",
               "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
               "gemm_small_fwd": "gemm_small_kernel<false", "gemm_small_dX": "gemm_small_kernel<true", "gemm_small_dW": "gemm_small_dw_kernel",
@@ -151,7 +151,7 @@ def pmc_mfma_summary(config="ycbv"):
     us = tf = busy = 0.0
     top = None
     for r in rows[1:]:
-        if not r[0].startswith(("gemm", "hipblaslt")) or float(r[h["SQ_INSTS_MFMA"]]) == 0:
+        if "gemm" not in r[0].split("<")[0] or float(r[h["SQ_INSTS_MFMA"]]) == 0:
             continue
         w = float(r[h["avg_us"]])                       # per-launch time; launches per step are in the kernel_stats summary
         us += w
@@ -243,22 +243,28 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, max_seconds=45.0):
-    """The oracle (CPU restatement of the reference's PyTorch path, grid_sample MSDA) timed on the host cores
-    of this box on a BOUNDED sample: YCB-V geometry at bs=1, 1 warm-up + up to 2 timed optimisation steps."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def _cpu_steps(cfg, batch, warm, steps, max_seconds, cores):
+    """seconds per optimisation step of the CPU oracle (fwd + loss + bwd + clip + AdamW) at `batch` images of `cfg` geometry"""
     from oracle import poet_ref
-    cores = min(usable_cores(), 32)
-    torch.set_num_threads(cores)
-    feats, targets = synth_batch(cfg, 1, 99, "cpu")
+    feats, targets = synth_batch(cfg, batch, 99, "cpu")
     torch.manual_seed(0)
     model, crit = poet_ref.build_poet(cfg, feats)
     model.train()
     opt = torch.optim.AdamW(poet_ref.param_groups(model), lr=2e-4, weight_decay=1e-4)
     ih, iw = cfg["image_hw"]
-    samples = poet_ref.nested_from_list([torch.zeros(3, ih, iw)])
-    times = []
-    t_begin = time.perf_counter()
-    for it in range(3):
+    samples = poet_ref.nested_from_list([torch.zeros(3, ih, iw) for _ in range(batch)])
+    times, t_begin = [], time.perf_counter()
+    for it in range(warm + steps):
         t0 = time.perf_counter()
         out, nb = model(samples, targets)
         ls = crit(out, targets, nb)
@@ -268,16 +274,27 @@ def cpu_baseline(cfg, max_seconds=45.0):
         torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
         opt.step()
         dt = time.perf_counter() - t0
-        if it > 0:
+        if it >= warm:
             times.append(dt)
-        if time.perf_counter() - t_begin > max_seconds:
-            if not times:
-                times.append(dt)
+        if time.perf_counter() - t_begin > max_seconds and len(times) >= min(3, steps):
             break
-    sec = float(np.mean(times))
-    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"YCB-V geometry, bs=1, {len(times)} timed fwd+loss+bwd+clip+AdamW step(s) of the CPU oracle "
-                      f"({sec:.1f} s/step, torch {torch.__version__} CPU, {cores} threads)"}
+    return float(np.mean(times)), len(times)
+
+
+def cpu_baseline(cfg, max_seconds=40.0):
+    """The oracle (CPU restatement of the reference's PyTorch path, grid_sample MSDA) timed on the host cores of this box on a
+    BOUNDED sample: the metric's geometry at bs = 2, 1 warm-up + 3 timed optimisation steps; and BASELINE.json
+    configs[0] (the reference's own CPU-runnable case: 1 enc / 1 dec / 4 heads, 2 levels, 128x128, bs = 2), 3 + 20 steps."""
+    cores = min(usable_cores(), 32)
+    torch.set_num_threads(cores)
+    sec, n = _cpu_steps(cfg, 2, 1, 3, max_seconds, cores)
+    sec0, n0 = _cpu_steps(CONFIGS["cfg0"], 2, 3, 20, 15.0, cores)
+    cpu = _cpu_model()
+    return {"value": round(2.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu,
+            "sample": f"metric geometry, bs=2, {n} timed fwd+loss+bwd+clip+AdamW steps of the CPU oracle after 1 warm-up "
+                      f"({sec:.2f} s/step, torch {torch.__version__} CPU, {cores} threads, {cpu})",
+            "cfg0": {"value": round(2.0 / sec0, 2), "unit": "images/s", "sample": f"BASELINE.json configs[0] (128x128, 1 enc / 1 dec / 4 heads, 2 levels), bs=2, "
+                     f"{n0} timed steps after 3 warm-up ({1e3 * sec0:.1f} ms/step)"}}
 
 
 def main():
@@ -340,6 +357,12 @@ def main():
     t_enq = time.perf_counter() - t0                              # host time to ENQUEUE the K steps (no device sync inside)
     sync()
     elapsed = time.perf_counter() - t0
+    # host cost of ONE step with an empty GPU queue (the in-loop figure above includes back-pressure: the runtime lets the host
+    # run only about one graph launch ahead, so at steady state the enqueue loop is paced by the GPU)
+    t1 = time.perf_counter()
+    trainer.step(samples, targets)
+    t_host = time.perf_counter() - t1
+    sync()
     prof, prof_steps = None, 3
     if not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, over 3 EXTRA steps of the same workload right after the
@@ -382,11 +405,22 @@ def main():
                        "launch": "eager" if args.no_graphs else ("hipGraph replay (fwd + matcher + loss graph, bwd + clip + AdamW graph)" if getattr(trainer, "graph_loss", False) else "hipGraph replay (fwd graph, eager loss, bwd+opt graph)"),
                        "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
                        "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4),
-                       "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 3)},
+                       "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 3),
+                       "host_enqueue_ms_one_step_idle_queue": round(1000.0 * t_host, 3)},
         }
         if prof is not None:
             out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)
             out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"], args.config)
+            # the three kernels (symbol x shape) that take the most time, each against its own roof, with the counter traffic
+            # of the committed PMC summary next to the algorithmic bytes
+            top = []
+            for tg in sorted(prof, key=lambda k: -prof[k]["total_ms"])[:3]:
+                r3 = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS, tag=tg)
+                tr3 = pmc_traffic_bytes(tg, args.config)
+                top.append({"kernel": tg, "ms_per_step": r3["ms_per_step"], "avg_launch_us": r3["avg_launch_us"], "bound": r3["bound"], "frac": r3["frac"],
+                            "algorithmic_bytes_per_launch": r3["algorithmic_bytes_per_launch"], "traffic": tr3,
+                            "traffic_over_algorithmic": round(tr3 / r3["algorithmic_bytes_per_launch"], 2) if tr3 and r3["algorithmic_bytes_per_launch"] else None})
+            out["roofline"]["top3"] = top
             # the step's matrix work next to the dominant (HBM / LDS-atomic bound) kernel: algorithmic GEMM flops of the
             # step over the MFMA kernels' own time, and what the SQ counters say about them
             gemm_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("gemm")) / prof_steps

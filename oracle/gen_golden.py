@@ -166,6 +166,20 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
     if default_init:
         rec["param_names"] = np.asarray([n for n, _ in model.named_parameters()])
         rec["param_checksums"] = np.stack([checksum(p) for _, p in model.named_parameters()])
+        # Encoder sampling_offsets at the reference's own init: every query's offsets are the bias alone, the axis / diagonal
+        # heads' bias components are exact integers and grid queries sit on pixel centres, so those OUTPUT CHANNELS take a
+        # one-sided derivative of the bilinear interpolation (decided by the rounding of the reference's own 2 * loc - 1):
+        # checksums of the gradient restricted to the channels whose bias component is NOT an integer pin everything else.
+        kn, ks, kc = [], [], []
+        params = dict(model.named_parameters())
+        for n, p in model.named_parameters():
+            if "encoder" in n and "sampling_offsets" in n and p.grad is not None:
+                b = params[n.rsplit(".", 1)[0] + ".bias"].detach()
+                kink = (b - b.round()).abs() < 1e-3
+                kn.append(n)
+                ks.append(checksum(p.grad[~kink]))
+                kc.append(int(kink.sum()))
+        rec["nokink_names"], rec["nokink_checksums"], rec["kink_channels"] = np.asarray(kn), np.stack(ks), np.asarray(kc)
     tag = f"{name}_b{batch}{'_pad' if pad else ''}{'_init' if default_init else ''}"
     if (bbox_mode, class_mode) != ("gt", "specific"):
         tag += f"_{bbox_mode}_{class_mode}"
@@ -271,6 +285,12 @@ def main():
         _run_model("lmo", 2, True, False)
         _run_model("hires", 1, False, False)
         return
+    if "--round3" in sys.argv:                # the reference's own init at every full-size config; LM-O at >= 4096 token rows (bs 3)
+        _run_model("ycbv", 1, False, False, default_init=True)
+        _run_model("lmo", 1, False, False, default_init=True)
+        _run_model("hires", 1, False, False, default_init=True)
+        _run_model("lmo", 3, True, False)
+        return
     if "--modes" in sys.argv:                 # only the jitter / class-agnostic goldens
         _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
         _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
@@ -285,6 +305,9 @@ def main():
     _run_model("lmo", 1, False, False)
     _run_model("lmo", 2, True, False)
     _run_model("hires", 1, False, False)
+    _run_model("lmo", 1, False, False, default_init=True)
+    _run_model("hires", 1, False, False, default_init=True)
+    _run_model("lmo", 3, True, False)
     _run_model("tiny", 2, True, True, default_init=True)
     _run_inference("tiny")
     _run_inference("cfg0")

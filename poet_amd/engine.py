@@ -272,45 +272,94 @@ class BucketReducer:
     `bucket_done(tag)` is called from the end of each backward node, records an event on the compute
     stream and enqueues the all-reduce on a dedicated comm stream, so the collective of bucket k
     overlaps the backward of bucket k+1.  Sum-reduce here, the 1/world average is folded into the
-    optimizer kernel (grad_scale)."""
+    optimizer kernel (grad_scale).
 
-    def __init__(self, arena: ParamArena, group=None):
+    * The TAIL buckets (level_embed, input_proj: final only when backward is over) are never reduced on their own: `finish()`
+      coalesces every adjacent un-reduced range into ONE collective, so exactly one small all-reduce (1.3 MB) is exposed at the
+      end of backward -- the last encoder layer's bucket already runs under the input_proj backward.
+    * grad_dtype=torch.bfloat16 (or POET_DP_GRAD_DTYPE=bf16): buckets travel as bf16 (24.5 MB instead of 49 MB per step over the
+      153 GB/s xGMI links): cast into a staging buffer, all-reduce, cast back into the fp32 gradient arena, all on the comm
+      stream; accumulation in the optimiser stays fp32.  Off by default: the sum over 8 ranks is then rounded to 8 mantissa bits
+      per addition."""
+
+    TAIL = ("2_encoder_99", "3_input_proj")
+
+    def __init__(self, arena: ParamArena, group=None, grad_dtype=None):
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.active = self.world > 1 or (collectives_forced() and dist.is_available() and dist.is_initialized())
         arena.world = self.world
         self.on_gpu = arena.grad.is_cuda
         self.comm = torch.cuda.Stream() if (self.on_gpu and self.active) else None
-        self.pending = []
+        if grad_dtype is None:
+            grad_dtype = torch.bfloat16 if os.environ.get("POET_DP_GRAD_DTYPE", "fp32").lower() in ("bf16", "bfloat16") else torch.float32
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("BucketReducer: grad_dtype must be float32 or bfloat16")
+        self.grad_dtype = grad_dtype
+        self.stage = None
+        if self.active and grad_dtype == torch.bfloat16:
+            self.stage = torch.empty(arena.total, dtype=torch.bfloat16, device=arena.grad.device)
         self.done = set()
+        self.collectives = []                # (start, end) of every all-reduce of the current / last step
 
     def bucket_done(self, tag: str):
-        if not self.active:
+        if not self.active or tag in self.TAIL:
             return
+        if not self.done:
+            self.collectives = []
         for name, a, b in self.arena.buckets:
             if name == tag and name not in self.done:
                 self.done.add(name)
                 self._reduce(a, b)
 
-    def _reduce(self, a, b):
+    def _all_reduce(self, a, b):
         buf = self.arena.grad[a:b]
+        if self.stage is None:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        st = self.stage[a:b]
+        if self.on_gpu:                      # HIP casts on the stream the collective runs on
+            prev = ops._STREAM_OVERRIDE[0]
+            ops._STREAM_OVERRIDE[0] = torch.cuda.current_stream().cuda_stream
+            try:
+                ops.cast(buf, st)
+                dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+                ops.cast(st, buf)
+            finally:
+                ops._STREAM_OVERRIDE[0] = prev
+        else:                                # (CPU arenas exist in the gloo tests only)
+            st.copy_(buf)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(st)
+
+    def _reduce(self, a, b):
+        self.collectives.append((a, b))
         if self.comm is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(a, b)
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(a, b)
 
     def finish(self):
-        """Reduce whatever was not announced, then make the compute stream wait."""
+        """Reduce whatever was not reduced yet -- adjacent ranges as ONE collective --, then make the compute stream wait."""
         if not self.active:
             return
+        if not self.done:
+            self.collectives = []
+        run = None
         for name, a, b in self.arena.buckets:
-            if name not in self.done:
-                self.done.add(name)
-                self._reduce(a, b)
+            if name in self.done:
+                if run is not None:
+                    self._reduce(*run)
+                    run = None
+                continue
+            self.done.add(name)
+            run = (a, b) if run is None else (run[0], b)
+        if run is not None:
+            self._reduce(*run)
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
         self.done.clear()

@@ -164,9 +164,10 @@ class _Profile:
         self.rec.append((tag, e0, e1, float(flops), float(nbytes)))
 
     @staticmethod
-    def roofline(agg, steps, hbm_peak_gbs, mfma_peak_tfs):
-        """Roofline line for the kernel family that takes the most time."""
-        tag = max(agg, key=lambda k: agg[k]["total_ms"])
+    def roofline(agg, steps, hbm_peak_gbs, mfma_peak_tfs, tag=None):
+        """Roofline line for one kernel family = one kernel symbol on one shape (default: the one that takes the most time)."""
+        if tag is None:
+            tag = max(agg, key=lambda k: agg[k]["total_ms"])
         a = agg[tag]
         sec = a["total_ms"] / 1e3
         # the binding roof is the one this family's own algorithmic flops / bytes take longer on
@@ -177,6 +178,7 @@ class _Profile:
             ach, peak, unit = a["bytes"] / sec / 1e9, hbm_peak_gbs, "GB/s"
         return {"kernel": tag, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
                 "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": a["launches"] / steps,
+                "ms_per_step": round(a["total_ms"] / steps, 3),
                 "avg_launch_us": round(1e3 * a["total_ms"] / a["launches"], 2),
                 "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]), "algorithmic_flops_per_launch": round(a["flops"] / a["launches"]),
                 "achieved_GBs_algorithmic": round(a["bytes"] / sec / 1e9, 1)}
@@ -250,7 +252,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                 nb += batch * M * N * _esz(extra)
         # one tag per kernel family, role AND shape: "the dominant kernel" of the roofline line is one kernel on one shape,
         # not 26 launches of five different GEMMs that happen to share a symbol
-        shape = f"_{N}x{K}" if M >= 4096 else ""
+        # (the weight-gradient form has M = n_out, N = k_in, K = token rows)
+        shape = f"_{M}x{N}" if (role == "dW" and K >= 4096) else (f"_{N}x{K}" if (role != "dW" and M >= 4096) else "")
         PROFILE.end(f"gemm_{path}_{role}{shape}", e0, 2.0 * M * N * K * batch, nb)
         return Cout
     _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
@@ -387,13 +390,19 @@ def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value,
                    grad_offattn, N, M, D, P, Lq, grid_queries=False, parts=3, ld_grad=0):
     lib = _lib.load()
-    if PROFILE.on and parts == 3:       # time the two kernels of the backward separately
+    if PROFILE.on and not getattr(msda_fused_bwd, "_timing", False):       # time the two kernels of the backward separately
         a = (value, vstrides, geom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value, grad_offattn, N, M, D, P, Lq)
         nb_q = offattn.numel() * offattn.element_size() * 2 + grad_out.numel() * grad_out.element_size() + value.numel() * value.element_size()
-        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2, ld_grad=ld_grad)
-        PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype == torch.bfloat16) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * grad_value.element_size())
-        e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1, ld_grad=ld_grad)
-        PROFILE.end("msda_bwd_dq" + ("_small" if N * Lq < 4096 else ""), e0, 0.0, nb_q)
+        msda_fused_bwd._timing = True
+        try:
+            if parts in (2, 3, 0):
+                e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2, ld_grad=ld_grad)
+                PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype == torch.bfloat16) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * grad_value.element_size())
+            if parts in (1, 3, 0):
+                e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1, ld_grad=ld_grad)
+                PROFILE.end("msda_bwd_dq" + ("_small" if N * Lq < 4096 else ""), e0, 0.0, nb_q)
+        finally:
+            msda_fused_bwd._timing = False
         return
     _lib.check(lib.poet_msda_fused_bwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
                                        offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, grad_out.data_ptr(),

@@ -71,11 +71,27 @@ def _worker(rank, world, port, q):
             p._grad_view.fill_(float(rank + 1))
         for tag in ["0_heads", "1_decoder", "2_encoder_99", "3_input_proj"]:   # order of the autograd nodes' announce()
             announce(tag)
-        red.finish()                                       # (nothing is left un-announced here; finish() also joins the comm stream)
+        # the tail buckets (level_embed, input_proj) are not reduced when announced: finish() sends them as ONE collective
+        rng = {t: (a, b) for t, a, b in arena.buckets}
+        assert red.collectives == [rng["0_heads"], rng["1_decoder"]], red.collectives
+        red.finish()                                       # (also joins the comm stream)
+        assert red.collectives == [rng["0_heads"], rng["1_decoder"], (rng["2_encoder_99"][0], rng["3_input_proj"][1])], red.collectives
         set_reducer(None)
         expect = float(sum(r + 1 for r in range(world)))
         for n, p, _ in arena.entries:
             assert torch.all(p._grad_view == expect), n
+        # bf16 transport (POET_DP_GRAD_DTYPE=bf16 / grad_dtype): same sums wherever bf16 holds them exactly, the arena stays fp32,
+        # and nothing announced + finish() = the whole arena in one collective
+        red16 = BucketReducer(arena, grad_dtype=torch.bfloat16)
+        for n, p, _ in arena.entries:
+            p._grad_view.fill_(0.5 * (rank + 1))
+        set_reducer(red16); announce("1_decoder"); red16.finish(); set_reducer(None)
+        assert red16.collectives == [rng["1_decoder"], rng["0_heads"], (rng["2_encoder_99"][0], rng["3_input_proj"][1])], red16.collectives
+        assert arena.grad.dtype == torch.float32 and all(bool(torch.all(p._grad_view == 0.5 * expect)) for _, p, _ in arena.entries)
+        arena.grad.fill_(1.0 + 2.0 ** -10 * (rank + 1))    # not representable in bf16: the transport rounds, fp32 would not
+        red16.finish()
+        assert red16.collectives == [(0, arena.total)]
+        assert torch.all(arena.grad == float(world))
         # a second step must reduce again (done-set is cleared)
         for n, p, _ in arena.entries:
             p._grad_view.fill_(1.0)

@@ -63,7 +63,10 @@ def test_msda_core_vs_hf(golden_dir):
                                                       ("tiny", 2, True, True, True),
                                                       # BASELINE.json configs[3] (LM-O geometry) and configs[4] (1280x960, 6/6, Q=50)
                                                       ("lmo", 1, False, False, False), ("lmo", 2, True, False, False),
-                                                      ("hires", 1, False, False, False)])
+                                                      ("hires", 1, False, False, False),
+                                                      # round 3: the reference's own init at the full-size configs; LM-O at bs 3 (4800 rows)
+                                                      ("ycbv", 1, False, False, True), ("lmo", 1, False, False, True),
+                                                      ("hires", 1, False, False, True), ("lmo", 3, True, False, False)])
 def test_poet_vs_reference(golden_dir, name, batch, pad, full, init):
     g = _load(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz")
     r = run_oracle(name, batch, pad, default_init=init)
@@ -95,6 +98,12 @@ def test_poet_vs_reference(golden_dir, name, batch, pad, full, init):
         got = checksum(p.grad)
         scale = max(1.0, abs(ref_sum[0]))
         np.testing.assert_allclose(got, ref_sum, atol=2e-4 * scale, err_msg=str(n))
+    if "nokink_names" in g.files:       # gradient of the encoder's sampling_offsets restricted to the channels without a kink
+        for n, ref_sum, nk in zip(g["nokink_names"], g["nokink_checksums"], g["kink_channels"]):
+            b = grads[str(n).rsplit(".", 1)[0] + ".bias"].detach()
+            kink = (b - b.round()).abs() < 1e-3
+            assert int(kink.sum()) == int(nk) and 0 < int(nk) < b.numel(), (n, int(kink.sum()), int(nk))
+            np.testing.assert_allclose(checksum(grads[str(n)].grad[~kink]), ref_sum, atol=2e-4 * max(1.0, abs(ref_sum[0])), err_msg=str(n))
 
 
 def test_state_dict_keys_match_reference(golden_dir):

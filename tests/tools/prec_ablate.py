@@ -1,4 +1,4 @@
-"""CPU ablation: which bf16 rounding events of the encoder produce the output error at YCB-V geometry?
+"""CPU ablation: which bf16 rounding events of the encoder produce the output error at YCB-V geometry (CONFIG=hires|lmo: another)?
 Emulates the HIP bf16 policy on the oracle (fp32 math, operands/stores rounded to bf16 where the policy does).
 Usage: python tests/tools/prec_ablate.py [input_seed init_seed]"""
 import sys, os, time
@@ -92,15 +92,18 @@ class RoundedProj(torch.nn.Module):
 
 
 def run(model, samples, targets):
+    """translations / rotations of ALL decoder layers (auxiliary outputs first, the model output last)"""
     with torch.no_grad():
         out, _ = model(samples, targets)
-    return out["pred_translation"], out["pred_rotation"]
+    aux = out.get("aux_outputs", [])
+    return (torch.stack([a["pred_translation"] for a in aux] + [out["pred_translation"]]),
+            torch.stack([a["pred_rotation"] for a in aux] + [out["pred_rotation"]]))
 
 
 def main():
     iseed, wseed = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1234, 4321)
     torch.set_num_threads(8)
-    cfg = CONFIGS["ycbv"]
+    cfg = CONFIGS[os.environ.get("CONFIG", "ycbv")]
     feats, sizes, targets = make_inputs(cfg, seed=iseed, batch=1, pad=False)
     torch.manual_seed(wseed)
     model, _ = poet_ref.build_poet(cfg, feats)
@@ -124,7 +127,8 @@ def main():
         nonlocal t_ref, r_ref, mem_ref
         t, r = run(model, samples, targets)
         dm = (cap["mem"] - mem_ref)
-        print(f"{tag:34s} mem rms {dm.pow(2).mean().sqrt():.2e}  dt max {(t - t_ref).abs().max():.2e}  dR rms {(r - r_ref).pow(2).mean().sqrt():.2e} max {(r - r_ref).abs().max():.2e}", flush=True)
+        print(f"{tag:34s} mem rms {dm.pow(2).mean().sqrt():.2e}  dt max {(t - t_ref).abs().max():.2e}  dR rms {(r - r_ref).pow(2).mean().sqrt():.2e} "
+              f"max final layer {(r[-1] - r_ref[-1]).abs().max():.2e} all layers {(r - r_ref).abs().max():.2e}", flush=True)
 
     pols = {"P0 splitW": (),
             "P1 splitW+LNfused": ("tmp1", "tmp2"),
