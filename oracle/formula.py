@@ -83,6 +83,8 @@ def formula_fill(model: torch.nn.Module) -> None:
             val = (1.0 + 0.1 * _wave(n, name)) if leaf == "weight" else 0.05 * _wave(n, name)
         elif "level_embed" in name:
             val = 0.5 * _wave(n, name)
+        elif name.startswith("query_embed"):                      # learned (query_pos | tgt) rows: unit scale like nn.Embedding's init
+            val = _wave(n, name)
         elif p.dim() >= 2:
             fan_in = p[0].numel()
             val = math.sqrt(2.0 / fan_in) * _wave(n, name)          # variance 1/fan_in == xavier_uniform for square maps

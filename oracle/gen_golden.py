@@ -60,7 +60,8 @@ def _install_shims():
     sys.path.insert(0, REF)
 
 
-def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False):
+def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
+               ref_points_mode="bbox", query_embedding_mode="bbox"):
     """Build the reference's own PoET around a Joiner-like synthetic backbone."""
     import torch.nn as nn
     import torch.nn.functional as F
@@ -95,7 +96,7 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specifi
                                num_feature_levels=cfg["n_levels"], dec_n_points=cfg["n_points"],
                                enc_n_points=cfg["n_points"])
     model = PoET(Joinerish(), tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
-                 n_classes=cfg["n_classes"], bbox_mode=bbox_mode, ref_points_mode="bbox", query_embedding_mode="bbox",
+                 n_classes=cfg["n_classes"], bbox_mode=bbox_mode, ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode,
                  rotation_mode=rotation_mode, class_mode=class_mode, aleatoric=aleatoric, aux_loss=True, backbone_type="yolo")
     crit = SetCriterion(PoseMatcher(bbox_mode=bbox_mode, class_mode=class_mode), build_weight_dict(cfg["dec_layers"]),
                         list(losses_for(rotation_mode, aleatoric)))
@@ -105,7 +106,8 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specifi
 INIT_SEED = 4321
 
 
-def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class_mode="specific", rotation_mode="6d", aleatoric=False):
+def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class_mode="specific", rotation_mode="6d", aleatoric=False,
+               ref_points_mode="bbox", query_embedding_mode="bbox"):
     from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples, checksum
     from util.misc import nested_tensor_from_tensor_list
 
@@ -123,7 +125,8 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
         for k, v in model.state_dict().items():
             assert torch.equal(v, osd[k]), f"default init differs at {k}"
     else:
-        model, crit = _ref_model(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode, rotation_mode=rotation_mode, aleatoric=aleatoric)
+        model, crit = _ref_model(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode, rotation_mode=rotation_mode, aleatoric=aleatoric,
+                                 ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode)
         formula_fill(model)
     model.eval()
     crit.eval()
@@ -183,6 +186,8 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
     tag = f"{name}_b{batch}{'_pad' if pad else ''}{'_init' if default_init else ''}"
     if (bbox_mode, class_mode) != ("gt", "specific"):
         tag += f"_{bbox_mode}_{class_mode}"
+    if (ref_points_mode, query_embedding_mode) != ("bbox", "bbox"):
+        tag += f"_q{query_embedding_mode}_r{ref_points_mode}"
     if rotation_mode != "6d" or aleatoric:
         tag += f"_{rotation_mode}{'_aleatoric' if aleatoric else ''}"
         if aleatoric:
@@ -285,6 +290,10 @@ def main():
         _run_model("lmo", 2, True, False)
         _run_model("hires", 1, False, False)
         return
+    if "--learned" in sys.argv:               # --query_embedding learned / --reference_points learned (main.py:76-79)
+        _run_model("tiny", 2, True, True, query_embedding_mode="learned")
+        _run_model("tiny", 2, True, True, query_embedding_mode="learned", ref_points_mode="learned")
+        return
     if "--round3" in sys.argv:                # the reference's own init at every full-size config; LM-O at >= 4096 token rows (bs 3)
         _run_model("ycbv", 1, False, False, default_init=True)
         _run_model("lmo", 1, False, False, default_init=True)
@@ -309,6 +318,8 @@ def main():
     _run_model("hires", 1, False, False, default_init=True)
     _run_model("lmo", 3, True, False)
     _run_model("tiny", 2, True, True, default_init=True)
+    _run_model("tiny", 2, True, True, query_embedding_mode="learned")
+    _run_model("tiny", 2, True, True, query_embedding_mode="learned", ref_points_mode="learned")
     _run_inference("tiny")
     _run_inference("cfg0")
     _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")

@@ -370,8 +370,11 @@ class SyntheticBackbone(nn.Module):
 
 class PoET(nn.Module):
     def __init__(self, backbone, transformer, num_queries, num_feature_levels, n_classes,
-                 bbox_mode="gt", class_mode="specific", aux_loss=True, rotation_mode="6d", aleatoric=False):
+                 bbox_mode="gt", class_mode="specific", aux_loss=True, rotation_mode="6d", aleatoric=False,
+                 ref_points_mode="bbox", query_embedding_mode="bbox"):
         super().__init__()
+        assert ref_points_mode in ("bbox", "learned") and query_embedding_mode in ("bbox", "learned")
+        self.ref_points_mode, self.query_embedding_mode = ref_points_mode, query_embedding_mode
         self.transformer, self.backbone = transformer, backbone
         d = transformer.d_model
         self.hidden_dim, self.n_queries, self.n_classes = d, num_queries, n_classes + 1
@@ -406,6 +409,8 @@ class PoET(nn.Module):
         if aleatoric:
             self.translation_head_aleatoric = nn.ModuleList([copy.deepcopy(ta_head) for _ in range(n_pred)])
             self.rotation_head_aleatoric = nn.ModuleList([copy.deepcopy(ra_head) for _ in range(n_pred)])
+        if query_embedding_mode == "learned":           # pose_estimation_transformer.py:149-150 (nn.Embedding: normal_ init)
+            self.query_embed = nn.Embedding(num_queries, d * 2)
         self.bbox_embedding = BoundingBoxEmbeddingSine(num_pos_feats=d / 8)
 
     def assemble_queries(self, targets):
@@ -475,7 +480,9 @@ class PoET(nn.Module):
             pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
             srcs.append(src)
             masks.append(mask)
-        ref = pred_boxes[:, :, :2]
+        ref = pred_boxes[:, :, :2] if self.ref_points_mode == "bbox" else None      # :337-340
+        if self.query_embedding_mode == "learned":                                  # :342-343
+            query_embeds = self.query_embed.weight
         hs, _, _, _, _ = self.transformer(srcs, masks, pos, query_embeds, ref)
 
         bs = pred_classes.shape[0]
@@ -639,14 +646,15 @@ def param_groups(model, lr=2e-4, lr_backbone=2e-5, proj_names=("reference_points
     ]
 
 
-def build_poet(cfg, features, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False):
+def build_poet(cfg, features, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
+               ref_points_mode="bbox", query_embedding_mode="bbox"):
     """cfg: dict(d_model, nheads, enc_layers, dec_layers, d_ffn, n_levels, n_points, num_queries,
     n_classes, dropout, strides, num_channels)."""
     bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions)
     tr = DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"],
                                cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"])
     model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, class_mode, True,
-                 rotation_mode=rotation_mode, aleatoric=aleatoric)
+                 rotation_mode=rotation_mode, aleatoric=aleatoric, ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode)
     crit = SetCriterion(PoseMatcher(bbox_mode="jitter" if bbox_mode == "jitter" else "gt"), build_weight_dict(cfg["dec_layers"]),
                         losses_for(rotation_mode, aleatoric))
     return model, crit

@@ -362,8 +362,11 @@ def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training, y_
     return t3, saved
 
 
-def dec_layer_bwd(dt3, sv, P_, G, pre, ref_in, geom, N, Q, M, npts, dV):
-    """Returns d(tgt).  dV (fp32, zeroed) receives the value-map gradient of this layer."""
+def dec_layer_bwd(dt3, sv, P_, G, pre, ref_in, geom, N, Q, M, npts, dV, dqp=None, dOA_out=None):
+    """Returns d(tgt).  dV (fp32, zeroed) receives the value-map gradient of this layer.
+    dqp (rows, d), optional: += d(query_pos) of this layer (learned query embeddings: q = tgt + query_pos enters the self-
+    attention's q / k and the cross-attention's query, deformable_transformer.py:277-284); dOA_out: optional caller buffer that
+    receives d(offsets | logits) (learned reference points need the offsets' gradient: d(loc) = d(offset) * (W_l, H_l))."""
     d = dt3.shape[1]
     D, rows = d // M, N * Q
     pd, seeds = sv["pd"], sv["seeds"]
@@ -374,10 +377,15 @@ def dec_layer_bwd(dt3, sv, P_, G, pre, ref_in, geom, N, Q, M, npts, dV):
     dt1, d_out_m = proj_ln_bwd(dt2, sv["out_m"], P_["cross_attn.output_proj.weight"], P_["norm1.weight"], sv["ln1"], pd,
                                seeds[2], g("cross_attn.output_proj.weight"), g("cross_attn.output_proj.bias"),
                                g("norm1.weight"), g("norm1.bias"))
+    dq2 = torch.empty_like(dt1) if dqp is not None else None
     sample_bwd(d_out_m, sv["q2"], sv["OA"], P_["cross_attn.sampling_offsets.weight"], P_["cross_attn.attention_weights.weight"],
                sv["V"], geom, ref_in, Q * geom.L * 2, N, Q, M, D, npts, dV,
                g("cross_attn.sampling_offsets.weight"), g("cross_attn.sampling_offsets.bias"),
-               g("cross_attn.attention_weights.weight"), g("cross_attn.attention_weights.bias"), dt1, True)
+               g("cross_attn.attention_weights.weight"), g("cross_attn.attention_weights.bias"),
+               dt1 if dqp is None else dq2, dqp is None, dOA=dOA_out)
+    if dqp is not None:                       # d(q2) goes to t1 AND to query_pos
+        ops.add(dt1, dq2, dt1)
+        ops.add(dqp, dq2, dqp)
     dtgt, datt = proj_ln_bwd(dt1, sv["att"], P_["self_attn.out_proj.weight"], P_["norm2.weight"], sv["ln2"], pd, seeds[1],
                              g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), g("norm2.weight"), g("norm2.bias"))
     packed = sv["packed"]
@@ -390,7 +398,14 @@ def dec_layer_bwd(dt3, sv, P_, G, pre, ref_in, geom, N, Q, M, npts, dV):
     ops.linear_dw(dpk[:, 2 * d:], sv["tgt"], gWin[2 * d:], rows=rows, ldy=3 * d, db=gbin[2 * d:])
     # d(tgt) += d(q|k) W_qk + d(v) W_v: q = k = tgt + query_pos and v = tgt (deformable_transformer.py:277-278), and query_pos
     # has no gradient consumer, so the two products collapse into ONE GEMM over the packed in_proj_weight (K = 3d)
-    ops.linear_dx(dpk, Win, dtgt, rows=rows, add_src=dtgt)
+    if dqp is None:
+        ops.linear_dx(dpk, Win, dtgt, rows=rows, add_src=dtgt)
+    else:                                     # d(qk) = d(q|k) W_qk goes to tgt AND to query_pos; d(v) W_v to tgt only
+        dqk = torch.empty_like(dtgt)
+        ops.linear_dx(dpk, Win[: 2 * d], dqk, rows=rows, ldy=3 * d)
+        ops.linear_dx(dpk[:, 2 * d:], Win[2 * d:], dtgt, rows=rows, ldy=3 * d, add_src=dtgt)
+        ops.add(dtgt, dqk, dtgt)
+        ops.add(dqp, dqk, dqp)
     return dtgt
 
 

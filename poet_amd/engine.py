@@ -18,7 +18,7 @@ from . import ops
 
 ALIGN = 64   # elements (256 B): every parameter starts on a 16-B-aligned, vector-friendly offset
 # parameter-name prefixes of the hot path (pose_estimation_transformer.py:85-144 heads / input_proj; the transformer)
-HOT_PREFIXES = ("input_proj.", "transformer.", "translation_head", "rotation_head")
+HOT_PREFIXES = ("input_proj.", "transformer.", "translation_head", "rotation_head", "query_embed.")
 
 
 _ENC_LAYER = re.compile(r"^transformer\.encoder\.layers\.(\d+)\.")
@@ -732,7 +732,10 @@ class Trainer:
     def __init__(self, model: nn.Module, criterion: SetCriterion, lr=2e-4, weight_decay=1e-4, max_norm=0.1,
                  distributed: Optional[bool] = None):
         self.model, self.criterion, self.max_norm = model, criterion, max_norm
-        self.arena = ParamArena(model, lr=lr, weight_decay=weight_decay)
+        # transformer.reference_points only receives a gradient with learned reference points (else it stays outside, as
+        # torch.optim.AdamW skips parameters whose .grad is None)
+        exclude = () if getattr(model, "ref_points_mode", "bbox") == "learned" else ("transformer.reference_points",)
+        self.arena = ParamArena(model, lr=lr, weight_decay=weight_decay, exclude=exclude)
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or collectives_forced())
         self.reducer = BucketReducer(self.arena) if distributed else None
@@ -788,13 +791,15 @@ class _Replay(torch.autograd.Function):
     def forward(ctx, trainer, handle):
         ctx.trainer = trainer
         trainer.g_fwd.replay()
-        return trainer.s_rot.detach(), trainer.s_trans.detach()
+        return (trainer.s_rot.detach(), trainer.s_trans.detach(), *[x.detach() for x in trainer.s_extra])   # (+ the aleatoric heads' outputs)
 
     @staticmethod
-    def backward(ctx, drot, dtrans):
+    def backward(ctx, drot, dtrans, *dextra):
         t = ctx.trainer
         t.s_drot.copy_(drot)
         t.s_dtrans.copy_(dtrans)
+        for buf, g in zip(t.s_dextra, dextra):
+            buf.zero_() if g is None else buf.copy_(g)
         _Replay.replay_backward(t)
         return None, None
 
@@ -835,9 +840,6 @@ class GraphedTrainer(Trainer):
         # the base class broadcasts the parameters and owns the bucket reducer used by the EAGER warm-up steps (without it
         # the ranks would drift apart before the graphs are captured); the captured steps all-reduce the whole arena
         # themselves (see _Replay.backward) and run with the reducer detached
-        if getattr(model, "aleatoric", False):
-            raise NotImplementedError("GraphedTrainer does not capture the aleatoric heads (their outputs are not part of the captured "
-                                      "forward's interface); use Trainer")
         super().__init__(model, criterion, lr=lr, weight_decay=weight_decay, max_norm=max_norm, distributed=None)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena.world = self.world
@@ -968,6 +970,10 @@ class GraphedTrainer(Trainer):
                     self.s_dtrans = gt_ * w[:, 0].reshape(L, *([1] * (gt_.dim() - 1)))
                     self.s_drot = gr_ * w[:, 1].reshape(L, *([1] * (gr_.dim() - 1)))
         self.s_rot, self.s_trans = rot, trans
+        # the aleatoric heads' log-variances (pose_estimation_transformer.py:402-411) are two more static outputs of the forward graph
+        al = getattr(m, "_last_aleatoric", None)
+        self.s_extra = list(al) if al is not None else []
+        self.s_dextra = [torch.zeros_like(x) for x in self.s_extra]
         if not self.graph_loss:
             self.s_drot, self.s_dtrans = torch.zeros_like(rot), torch.zeros_like(trans)
         self.segs = None
@@ -991,11 +997,16 @@ class GraphedTrainer(Trainer):
 
             def first():
                 self.arena.zero_grad()
-                return torch.autograd.grad([rot, trans], [hs], [self.s_drot, self.s_dtrans], retain_graph=True)[0]
+                return torch.autograd.grad([rot, trans, *self.s_extra], [hs], [self.s_drot, self.s_dtrans, *self.s_dextra], retain_graph=True)[0]
 
             from .functional import enc_bucket_tag
             dhs = seg(first, ["0_heads"])
-            dx = seg(lambda: torch.autograd.grad([hs], [outs[-1]], [dhs], retain_graph=True)[0], ["1_decoder"])
+            # (learned query embeddings / reference points: their nodes hang off the decoder node, not off the path to the
+            # memory -- ask for those leaves too so that their backward programs run in this segment; they write into the arena
+            # views themselves and hand autograd None)
+            extra = [p for n, p in m.named_parameters() if n.startswith("query_embed.") or
+                     (n.startswith("transformer.reference_points.") and getattr(m, "ref_points_mode", "bbox") == "learned")]
+            dx = seg(lambda: torch.autograd.grad([hs], [outs[-1]] + extra, [dhs], retain_graph=True, allow_unused=True)[0], ["1_decoder"])
             keep = [dhs, dx]
             for i in reversed(range(n_enc)):
                 tags = [enc_bucket_tag(n_enc, i)] + (["2_encoder_99"] if i == 0 else [])
@@ -1011,7 +1022,7 @@ class GraphedTrainer(Trainer):
             with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), **_CAPTURE):
                 with ops.pinned_stream():
                     self.arena.zero_grad()
-                    torch.autograd.backward([rot, trans], [self.s_drot, self.s_dtrans])
+                    torch.autograd.backward([rot, trans, *self.s_extra], [self.s_drot, self.s_dtrans, *self.s_dextra])
                     ops.counter_add(self.step_word, 1)
                     self.arena.step(self.max_norm, step_dev=self.step_word)
         if self.segs is not None:
@@ -1064,7 +1075,8 @@ class GraphedTrainer(Trainer):
             _Replay.replay_backward(self)
             vec = self.s_lossvec.clone()                         # the static buffers are overwritten by the next replay
             return self.s_total.clone(), _vec_dict(vec)
-        rot, trans = _Replay.apply(self, self.handle)
+        rot, trans, *extra = _Replay.apply(self, self.handle)
+        m._last_aleatoric = tuple(extra) if extra else None
         out = m.make_outputs(rot, trans, self.s_boxes, self.s_cls, boxes)
         loss_dict = self.criterion(out, targets, n_boxes)
         wd = self.criterion.weight_dict

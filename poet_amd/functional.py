@@ -37,6 +37,32 @@ class CastFn(torch.autograd.Function):
 # Encoder: one autograd node per layer (a gradient bucket each: the layer's parameter gradients are complete -- and their
 # all-reduce can start -- as soon as its backward program ends, main.py:280-283's DDP overlap)
 # ====================================================================================================
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the HIP GEMMs for a stand-alone fp32 nn.Linear (forward, dX, dW + db) -- the learned reference-point
+    projection `self.reference_points(query_embed)` (deformable_transformer.py:157-158); parameter gradients go through the
+    arena's views when there are any (GradSink), else back to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        y = torch.empty((x2.shape[0], W.shape[0]), dtype=torch.float32, device=x.device)
+        ops.linear_fwd(x2, W.detach(), b.detach(), y)
+        ctx.save_for_backward(x2)
+        ctx.W, ctx.b, ctx.shape = W, b, x.shape
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        dy2 = dy.reshape(-1, W.shape[0]).contiguous().float()
+        G = B.GradSink(["w", "b"], [W, b])
+        ops.linear_dw(dy2, x2, G("w"), rows=x2.shape[0], db=G("b"))
+        dx = torch.empty_like(x2)
+        ops.linear_dx(dy2, W.detach(), dx, rows=x2.shape[0])
+        return dx.view(ctx.shape), G.ret[0], G.ret[1]
+
+
 def enc_bucket_tag(n_layers: int, i: int) -> str:
     """Bucket name of encoder layer i (engine._bucket_of): backward completes layer n-1 first, so it sorts first."""
     return f"2_encoder_{n_layers - 1 - i:02d}"
@@ -112,15 +138,51 @@ def encoder_forward(src, pos, level_embed, ref, mask, geom, cfg, layers_named):
 # ====================================================================================================
 # Decoder: memory value projections + all layers in one node
 # ====================================================================================================
+class QueryEmbedFn(torch.autograd.Function):
+    """Learned query embeddings (pose_estimation_transformer.py:149-150,342-343; deformable_transformer.py:150-155): the rows of
+    nn.Embedding.weight (Q, 2d) split into (query_pos | tgt) and repeated for every image.  A node of its own so that the
+    parameter's gradient -- the batch sums of d(query_pos) and d(tgt) -- is written straight into its arena view like every
+    other parameter gradient of the path (an AccumulateGrad node kept alive from the eager warm-up steps would run on another
+    stream and break the HIP-graph capture of backward)."""
+
+    @staticmethod
+    def forward(ctx, weight, N):
+        d = weight.shape[1] // 2
+        ctx.weight = weight
+        w = weight.detach()
+        return w[:, :d][None].expand(N, -1, -1).contiguous(), w[:, d:][None].expand(N, -1, -1).contiguous()
+
+    @staticmethod
+    def backward(ctx, dqpos, dtgt):
+        G = B.GradSink(["w"], [ctx.weight])
+        gw = G("w")
+        d = gw.shape[1] // 2
+        if dqpos is not None:
+            gw[:, :d] += dqpos.sum(0)
+        if dtgt is not None:
+            gw[:, d:] += dtgt.sum(0)
+        return G.ret[0], None
+
+
+_WH_CACHE = {}
+
+
+def _level_wh(geom, device):
+    """(L, 2) fp32 tensor of (W_l, H_l) on `device`, cached per geometry: the upload happens in the eager warm-up steps, never
+    inside a graph capture (a host -> device copy there is illegal)."""
+    key = (geom.key(), str(device))
+    t = _WH_CACHE.get(key)
+    if t is None:
+        t = _WH_CACHE[key] = torch.tensor([[w, h] for h, w in geom.shapes], dtype=torch.float32, device=device)
+    return t
+
+
 class DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, memory, memory16, tgt, qpos, ref_in, mask, geom, cfg, names, *params):
         """memory (N,S,d): differentiable handle in the residual-stream dtype; memory16: the copy the value projections
         actually read (bf16 in the bf16 policy); tgt,qpos (N,Q,d) fp32; ref_in (N,Q,L,2) fp32.
         Returns hs (n_layers,N,Q,d) fp32."""
-        if qpos.requires_grad:
-            raise NotImplementedError("DecoderFn: query_pos that requires grad (learned query embeddings, query_embedding_mode="
-                                      "'learned') is not supported: the backward program produces d(tgt) only")
         N, S, d = memory.shape
         Q, M = tgt.shape[1], cfg["M"]
         D = d // M
@@ -157,6 +219,7 @@ class DecoderFn(torch.autograd.Function):
         ctx.mem2, ctx.ref_in, ctx.mask, ctx.dims = mem2, ref_in, mask, (N, S, d, Q)
         ctx.mem_dtype = memory.dtype
         ctx.need_mem, ctx.need_tgt = memory.requires_grad, tgt.requires_grad
+        ctx.need_qpos, ctx.need_ref = qpos.requires_grad, ref_in.requires_grad       # learned query embeddings / reference points
         return hs
 
     @staticmethod
@@ -173,6 +236,11 @@ class DecoderFn(torch.autograd.Function):
         nl = cfg["n_layers"]
         vs = ctx.vstack
         dV_all = torch.zeros((N, M * nl, S, D), dtype=torch.float32, device=dhs.device) if vs is not None else None
+        dqp = torch.zeros((N * Q, d), dtype=torch.float32, device=dhs.device) if ctx.need_qpos else None
+        mlp = M * geom.L * cfg["P"]
+        dref = torch.zeros((N, Q, geom.L, 2), dtype=torch.float32, device=dhs.device) if ctx.need_ref else None
+        if ctx.need_ref:
+            wh = _level_wh(geom, dhs.device)                                                                   # (L, 2): x scales with W, y with H
         with ops.defer_small_dw() as deferred:           # the 320-row dW + db of all layers: one launch per Linear, at the end
             for i in reversed(range(nl)):
                 deferred.next_layer()
@@ -184,7 +252,13 @@ class DecoderFn(torch.autograd.Function):
                 else:
                     dx = dcur.clone()
                 dV = dV_all[:, i * M:(i + 1) * M] if vs is not None else torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
-                dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV)
+                # (a fresh buffer per layer: the deferred weight-gradient launches read it after the loop)
+                dOA = torch.empty((N * Q, 3 * mlp), dtype=torch.float32, device=dhs.device) if ctx.need_ref else None
+                dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV, dqp=dqp, dOA_out=dOA)
+                if ctx.need_ref:
+                    # loc = ref_in + offset / (W_l, H_l): d(ref_in)[n, q, l] = (W_l, H_l) * sum over heads and points of d(offset)
+                    # -- 320 rows x 512 offsets: elementwise torch on the kernel's d(offsets) block, as for the quaternion extras
+                    dref += dOA[:, : 2 * mlp].view(N, Q, M, geom.L, cfg["P"], 2).sum((2, 4)) * wh
                 if vs is None:
                     B.value_proj_bwd(dV, ctx.mem2, P_["cross_attn.value_proj.weight"], ctx.mask, N, S, M, D,
                                      G(pre + "cross_attn.value_proj.weight"), G(pre + "cross_attn.value_proj.bias"), dmem, not first,
@@ -198,7 +272,8 @@ class DecoderFn(torch.autograd.Function):
         announce("1_decoder")
         dmemory = dmem.view(N, S, d) if ctx.need_mem else None
         dtgt = dx.view(N, Q, d) if ctx.need_tgt else None
-        return (dmemory, None, dtgt, None, None, None, None, None, None, *G.ret)
+        dqpos = dqp.view(N, Q, d) if ctx.need_qpos else None
+        return (dmemory, None, dtgt, dqpos, dref, None, None, None, None, *G.ret)
 
 
 # ====================================================================================================

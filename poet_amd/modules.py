@@ -271,8 +271,14 @@ class DeformableTransformer(nn.Module):
         ops.enc_ref_points(vr, geom, ref, N)
         memory, memory16 = self.encoder.run(src, pos, self.level_embed, ref, mask_flat, geom, self.act_dtype, self.split_w)
         Q = tgt.shape[1]
-        ref_in = torch.empty((N, Q, geom.L, 2), dtype=torch.float32, device=dev)
-        ops.dec_ref_points(reference_points.contiguous(), vr, ref_in, N, Q, geom.L)
+        if reference_points is None:      # learned reference points (deformable_transformer.py:157-158): sigmoid(Linear(query_pos))
+            reference_points = torch.sigmoid(Fn.LinearFn.apply(qpos, self.reference_points.weight, self.reference_points.bias))
+        self._last_reference_points = reference_points
+        if reference_points.requires_grad:  # differentiable form of dec_ref_points (deformable_transformer.py:317): 320 x L x 2 values
+            ref_in = reference_points[:, :, None, :] * vr[:, None, :, :]
+        else:
+            ref_in = torch.empty((N, Q, geom.L, 2), dtype=torch.float32, device=dev)
+            ops.dec_ref_points(reference_points.contiguous(), vr, ref_in, N, Q, geom.L)
         hs = self.decoder.run(memory, memory16, tgt, qpos, ref_in, mask_flat, geom, self.act_dtype, self.split_w)
         self._last_memory = memory
         return hs
@@ -280,8 +286,6 @@ class DeformableTransformer(nn.Module):
     # ---- reference-compatible entry (deformable_transformer.py:120-166) -----------------------------
     def forward(self, srcs, masks, pos_embeds, query_embed=None, reference_points=None):
         assert query_embed is not None
-        if reference_points is None:
-            raise NotImplementedError("learned reference points (reference_points=None) are not on PoET's path")
         geom = LevelGeom([s.shape[-2:] for s in srcs])
         N, d = srcs[0].shape[0], srcs[0].shape[1]
         src = Fn_flatten(srcs, geom, self.stream_dtype)
@@ -299,7 +303,8 @@ class DeformableTransformer(nn.Module):
         else:
             qpos, tgt = torch.split(query_embed, d, dim=2)
         hs = self.forward_flat(src, pos, [_u8(m) for m in masks], geom, tgt.contiguous().float(),
-                               qpos.contiguous().float(), reference_points.float())
+                               qpos.contiguous().float(), None if reference_points is None else reference_points.float())
+        reference_points = self._last_reference_points
         inter_refs = reference_points[None].expand(hs.shape[0], -1, -1, -1)
         return hs, reference_points, inter_refs, None, None
 
@@ -371,8 +376,13 @@ class PoET(nn.Module):
                  ref_points_mode="bbox", query_embedding_mode="bbox", rotation_mode="6d", class_mode="agnostic",
                  aleatoric=False, aux_loss=True, backbone_type="yolo"):
         super().__init__()
-        if bbox_mode not in ("gt", "jitter", "backbone") or ref_points_mode != "bbox" or query_embedding_mode != "bbox":
-            raise NotImplementedError("only bbox_mode gt/jitter/backbone with bbox queries/reference points is implemented")
+        if bbox_mode not in ("gt", "jitter", "backbone"):
+            raise NotImplementedError("PoET Bounding Box Mode not implemented!")
+        if query_embedding_mode not in ("bbox", "learned"):
+            raise NotImplementedError("This query embedding mode is not implemented.")
+        if ref_points_mode not in ("bbox", "learned"):
+            raise NotImplementedError("This reference point mode is not implemented.")
+        self.ref_points_mode, self.query_embedding_mode = ref_points_mode, query_embedding_mode
         if rotation_mode not in ("6d", "quat", "silho_quat"):
             raise NotImplementedError("Rotational representation is not supported.")
         if aleatoric and rotation_mode != "6d":        # pose_estimation_transformer.py:72-73
@@ -410,6 +420,8 @@ class PoET(nn.Module):
             self.translation_head_aleatoric = nn.ModuleList([copy.deepcopy(tah) for _ in range(n_pred)])
             self.rotation_head_aleatoric = nn.ModuleList([copy.deepcopy(rah) for _ in range(n_pred)])
         self.bbox_embedding = BoundingBoxEmbeddingSine(num_pos_feats=d / 8)
+        if query_embedding_mode == "learned":           # pose_estimation_transformer.py:149-150 (after the heads: RNG order)
+            self.query_embed = nn.Embedding(num_queries, d * 2)
 
     # ---- query assembly (pose_estimation_transformer.py:203-239,309-311,337-338), batched on the host ----
     def host_queries(self, targets):
@@ -493,7 +505,12 @@ class PoET(nn.Module):
         lvl_embed = tr.level_embed.detach().contiguous()
         for l, (h, w) in enumerate(geom.shapes):
             ops.pos_sine(masks[l], pos, lvl_embed[l], N, h, w, self.hidden_dim // 2, geom.starts[l], geom.S)
-        hs = tr.forward_flat(src, pos, masks, geom, emb, emb, boxes[:, :, :2].contiguous())
+        ref_pts = boxes[:, :, :2].contiguous() if self.ref_points_mode == "bbox" else None      # :337-340
+        if self.query_embedding_mode == "learned":     # :342-343 and deformable_transformer.py:150-155: (query_pos | tgt) rows, same for every image
+            qpos, tgt = Fn.QueryEmbedFn.apply(self.query_embed.weight, N)
+            hs = tr.forward_flat(src, pos, masks, geom, tgt, qpos, ref_pts)
+        else:
+            hs = tr.forward_flat(src, pos, masks, geom, emb, emb, ref_pts)
         if self.class_mode == "specific":
             cls32 = classes.to(torch.int32).view(-1)
             ncls = self.n_classes

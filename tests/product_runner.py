@@ -7,7 +7,8 @@ from oracle.formula import CONFIGS, formula_fill, make_inputs
 
 
 def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False,
-                  bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False):
+                  bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
+                  ref_points_mode="bbox", query_embedding_mode="bbox"):
     if not isinstance(precision, str):
         precision = "fp32" if precision == torch.float32 else "bf16"
     cfg = CONFIGS[name]
@@ -26,7 +27,8 @@ def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, f
     tr.set_precision(precision)
     model = poet_amd.PoET(bb, tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
                           n_classes=cfg["n_classes"], bbox_mode=bbox_mode, class_mode=class_mode, aux_loss=True,
-                          rotation_mode=rotation_mode, aleatoric=aleatoric)
+                          rotation_mode=rotation_mode, aleatoric=aleatoric, ref_points_mode=ref_points_mode,
+                          query_embedding_mode=query_embedding_mode)
     if not default_init:
         formula_fill(model)
     model = model.cuda()

@@ -151,6 +151,32 @@ def test_poet_modes_vs_reference(golden_dir, bbox_mode, class_mode):
             np.testing.assert_allclose(checksum(p.grad), cs, rtol=2e-4, atol=2e-6, err_msg=str(n))
 
 
+@pytest.mark.parametrize("qmode,rmode", [("learned", "bbox"), ("learned", "learned")])
+def test_poet_learned_queries_vs_reference(golden_dir, qmode, rmode):
+    """--query_embedding learned (nn.Embedding rows as (query_pos | tgt), pose_estimation_transformer.py:149-150,342-343) and
+    --reference_points learned (sigmoid(Linear(query_pos)), deformable_transformer.py:157-158): outputs, losses and gradient
+    checksums -- incl. query_embed.weight and transformer.reference_points.* -- equal the real reference's."""
+    g = _load(golden_dir, f"poet_tiny_b2_pad_q{qmode}_r{rmode}.npz")
+    r = run_oracle("tiny", 2, True, query_embedding_mode=qmode, ref_points_mode=rmode)
+    np.testing.assert_allclose(r["out"]["pred_translation"].detach().numpy(), g["pred_translation"], rtol=1e-5, atol=ATOL)
+    np.testing.assert_allclose(r["out"]["pred_rotation"].detach().numpy(), g["pred_rotation"], rtol=1e-5, atol=ATOL)
+    names = sorted(r["losses"])
+    assert names == list(g["loss_names"])
+    np.testing.assert_allclose([float(r["losses"][k]) for k in names], g["loss_values"], rtol=1e-5, atol=1e-6)
+    grads = dict(r["model"].named_parameters())
+    assert sorted(grads) == sorted(str(n) for n in g["grad_names"])
+    got_ref_grad = False
+    for n, cs in zip(g["grad_names"], g["grad_checksums"]):
+        p = grads[str(n)]
+        if np.isnan(cs[0]):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+        else:
+            np.testing.assert_allclose(checksum(p.grad), cs, rtol=2e-4, atol=2e-6, err_msg=str(n))
+            got_ref_grad |= "reference_points" in str(n)
+    assert float(grads["query_embed.weight"].grad.abs().max()) > 0
+    assert got_ref_grad == (rmode == "learned")
+
+
 @pytest.mark.parametrize("rotation_mode,aleatoric", [("quat", False), ("silho_quat", False), ("6d", True)])
 def test_poet_rotation_modes_vs_reference(golden_dir, rotation_mode, aleatoric):
     """Quaternion representations (4-wide rotation heads, L2-normalised; losses -log(<q,q*>^2 + eps) and log(1 - |<q,q*>| + eps),
