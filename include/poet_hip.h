@@ -159,10 +159,12 @@ int poet_msda_bwd(const void* value, const int64_t* spatial_shapes_host, const i
  * the upstream (N,S,M,D) and the head-major (N,M,S,D) layouts are accepted.  out (N,Lq,M*D) q_dtype.
  * Limit (all msda entry points): the gather kernels use 32-bit byte offsets and 24-bit pixel arithmetic, so a value map
  * must span < 4 GiB, S < 2^24 and vs_s * sizeof(element) < 2^24; larger calls return POET_ERR_UNSUPPORTED.
- * Backward: grad_value (gv_dtype: POET_F32, or POET_BF16 for the LDS-tiled scatter of grid queries only), same element
- * strides as value, accumulated atomically (caller zero-fills).  bf16: the per-tile int32 windows are exact and leave
- * through packed bf16x2 atomics -- half the memory-side atomics, half the zero-fill and half the read of the consumer, which
- * rounds the value gradient to bf16 anyway; a pixel on a tile border receives up to 4 rounded partial sums.
+ * Backward: grad_value (gv_dtype POET_F32 or POET_BF16) is accumulated atomically (caller zero-fills), addressed by
+ * gv_strides = (n, s, m) element strides, NULL = the value strides -- the decoder passes the strides of token-major rows
+ * (N*S, layers*M*D) so that the scatter writes what the value projection's backward GEMMs read, with no transposing pass.
+ * bf16: packed bf16x2 atomics (even strides, 4-byte aligned base) -- half the memory-side atomics, half the zero-fill and half
+ * the read of the consumer, which rounds the value gradient to bf16 anyway.  Grid queries: the per-tile int32 windows are exact
+ * and a pixel on a tile border receives up to 4 rounded partial sums; other queries: one rounding per contribution.
  * grad_offattn (N,Lq,ldq) q_dtype receives d/d(offsets) and d/d(logits) (softmax backward folded). */
 int poet_msda_fused_fwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m,
                         const int64_t* spatial_shapes_host, const int64_t* level_start_host,
@@ -186,6 +188,7 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
                                             enables the LDS-privatised value-gradient scatter */,
                         int parts /* 3 (or 0) = everything; 1 = only d(offsets|logits); 2 = only the d(value) scatter
                                      -- lets a profiler time the two kernels of this call separately */,
+                        const int64_t* gv_strides_host /* (n, s, m) element strides of grad_value, or NULL */,
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -268,6 +271,9 @@ int poet_colsum(const void* x, int64_t ld, float* out, int batch, int64_t rows_p
  * with row stride ld_out (0: M*D), rows with row_mask != 0 zeroed (masked_fill backward). */
 int poet_vgrad_to_rows(const void* gv, int64_t vs_n, int64_t vs_s, int64_t vs_m, const uint8_t* row_mask,
                        void* out, int64_t ld_out, int N, int S, int M, int D, int gv_dtype, int dtype, void* stream);
+/* rows with row_mask != 0 of x (rows, cols) `dtype`, row stride ld: zeroed (masked_fill backward for gradient rows that were
+ * scattered in place; cols * sizeof(element) % 16 == 0). */
+int poet_zero_masked_rows(void* x, int64_t ld, const uint8_t* row_mask, int64_t rows, int cols, int dtype, void* stream);
 /* NCHW (N,C,H,W) <-> token-major rows [tok_off, tok_off+H*W) of (N, tok_stride, C). */
 int poet_nchw_to_tokens(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
                         int src_dtype, int dst_dtype, void* stream);

@@ -41,7 +41,7 @@ _PROTOS = {
     "poet_msda_fused_fwd": ([vp, i64, i64, i64, pi64, pi64, vp, i64, i32, vp, i64, vp,
                              i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_msda_fused_bwd": ([vp, i64, i64, i64, pi64, pi64, vp, i64, i32, vp, i64, vp, vp, vp, i64,
-                             i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+                             i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, pi64, vp], i32),
     "poet_ln_fwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
     "poet_ln_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u32, i32, i32, vp, vp], i32),
     "poet_mha_fwd": ([vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, u32, vp, vp], i32),
@@ -57,6 +57,7 @@ _PROTOS = {
     "poet_cast": ([vp, vp, i64, i32, i32, vp], i32),
     "poet_colsum": ([vp, i64, vp, i32, i64, i32, pi64, i32, i32, vp], i32),
     "poet_vgrad_to_rows": ([vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
+    "poet_zero_masked_rows": ([vp, i64, vp, i64, i32, i32, vp], i32),
     "poet_nchw_to_tokens": ([vp, vp, i32, i32, i32, i64, i64, i32, i32, vp], i32),
     "poet_tokens_to_nchw": ([vp, vp, i32, i32, i32, i64, i64, i32, i32, vp], i32),
     "poet_im2col3x3s2": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),

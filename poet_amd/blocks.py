@@ -90,11 +90,16 @@ def value_proj_fwd(inp2d, W, b, row_mask, N, S, M, D, act=None, split=False):
 
 def value_proj_bwd(dV, inp2d, W, row_mask, N, S, M, D, gW, gb, dinp, accumulate, act=None, wb_is_operand=False, dVr=None):
     """wb_is_operand: W is already the GEMM operand (a stacked view chosen by the caller), not a parameter to look a shadow up for.
-    dVr: optional caller-owned (rows, M*D) buffer for the gradient rows (a column block of a wider one)."""
+    dVr: optional caller-owned (rows, M*D) buffer for the gradient rows (a column block of a wider one); with dV=None it already
+    HOLDS the gradient rows (scattered in place, masked rows not yet zeroed)."""
     rows, d = N * S, M * D
-    if dVr is None:
-        dVr = empty((rows, d), act or inp2d.dtype, inp2d)
-    ops.vgrad_to_rows(dV, vstrides(M, S, D), row_mask, dVr, N, S, M, D, ld_out=dVr.stride(0))
+    if dV is None:                                                     # the scatter wrote dVr itself (token-major rows): only the
+        if row_mask is not None:                                       # masked_fill backward is left
+            ops.zero_masked_rows(dVr, row_mask, rows, d)
+    else:
+        if dVr is None:
+            dVr = empty((rows, d), act or inp2d.dtype, inp2d)
+        ops.vgrad_to_rows(dV, vstrides(M, S, D), row_mask, dVr, N, S, M, D, ld_out=dVr.stride(0))
     ops.linear_dw(dVr, inp2d, gW, rows=rows, ldy=dVr.stride(0), db=gb)
     if dinp is not None:
         ops.linear_dx(dVr, W if wb_is_operand else Wb(W, dVr), dinp, rows=rows, ldy=dVr.stride(0), add_src=dinp if accumulate else None)
@@ -139,8 +144,9 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
     if dOA is None:
         dOA = torch.empty_like(OA)
     ldg = dOA.stride(0)
+    gvs = vstrides_of(dV)                                              # (the decoder scatters into token-major rows: its own strides)
     ops.msda_fused_bwd(V, vstrides_of(V), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
-                       grid_queries=grid_queries, ld_grad=ldg)
+                       grid_queries=grid_queries, ld_grad=ldg, gv_strides=None if gvs == vstrides_of(V) else gvs)
     plain = seg_sums is None
     pr = _pair(so_w, dOA)
     if pr is not None and pr[2].data_ptr() == g_so_w.data_ptr():      # (the gradient sink is the arena: stacked dW + db)

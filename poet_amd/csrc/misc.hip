@@ -689,6 +689,24 @@ extern "C" int poet_vgrad_to_rows(const void* gv, int64_t vs_n, int64_t vs_s, in
     return POET_OK;
 }
 
+// one wave per row: rows whose mask byte is set are overwritten with zeros (16-byte stores)
+__global__ __launch_bounds__(256) void zero_masked_rows_kernel(char* x, int64_t ld_bytes, const uint8_t* __restrict__ mask, int64_t rows, int row_bytes) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows || !mask[row]) return;
+    char* r = x + row * ld_bytes;
+    for (int c = (threadIdx.x & 63) * 16; c < row_bytes; c += 64 * 16) *reinterpret_cast<uint4*>(r + c) = make_uint4(0u, 0u, 0u, 0u);
+}
+
+extern "C" int poet_zero_masked_rows(void* x, int64_t ld, const uint8_t* row_mask, int64_t rows, int cols, int dtype, void* stream) {
+    const int esz = dtype == POET_BF16 ? 2 : 4;
+    POET_CHECK(x && row_mask && rows > 0 && cols > 0 && ld >= cols, POET_ERR_ARG, "zero_masked_rows: bad args");
+    POET_CHECK((dtype == POET_BF16 || dtype == POET_F32) && ((int64_t)cols * esz) % 16 == 0 && (ld * esz) % 16 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+               POET_ERR_UNSUPPORTED, "zero_masked_rows: rows must be 16-byte multiples, 16-byte aligned");
+    hipLaunchKernelGGL(zero_masked_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, ST, reinterpret_cast<char*>(x), ld * esz, row_mask, rows, cols * esz);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
 template <bool TO_TOKENS>
 static int transpose_dispatch(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
                               int sd, int dd, void* stream) {

@@ -24,6 +24,7 @@ constexpr int MAXL = 4;
 struct MsdaP {
     const void* value;
     int64_t vs_n, vs_s, vs_m;
+    int64_t gs_n, gs_s, gs_m;   // element strides of grad_value (backward; = the value strides unless the caller lays the gradient out differently)
     const void* q1;      // fused: offattn; plain: sampling_loc
     const void* q2;      // plain: attn_weight
     int64_t ldq, ldg;    // row strides (elements) of q1 and of g1 (fused: the gradient rows may sit in a wider buffer)
@@ -614,6 +615,19 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
     }
 }
 
+// packed bf16x2 memory-side atomic add (global_atomic_pk_add_bf16): `p2` = the even channel of a pair (4-byte aligned)
+typedef short gv_short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gv16_add2(bf16_t* p2, float lo, float hi) {
+    const uint32_t w = pack_bf2(lo, hi);
+    const gv_short2_t v = {(short)(w & 0xffffu), (short)(w >> 16)};
+    (void)__builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) gv_short2_t*)(p2), v);
+}
+// ... of ONE channel c (its pair partner receives +0)
+__device__ __forceinline__ void gv16_add(bf16_t* pc, int c, float v) {
+    if (c & 1) gv16_add2(pc - 1, 0.f, v);
+    else gv16_add2(pc, v, 0.f);
+}
+
 // d(value): pure scatter, no value loads.  One lane per channel: the D lanes of a (query, head) add D consecutive
 // floats, so every atomic wave-instruction covers whole contiguous 4*D-byte segments (coalesced into a few L2 atomic
 // requests) instead of 64 scattered dwords.  The softmax / corner arithmetic is recomputed per lane (it is tiny).
@@ -629,19 +643,31 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
     float a[L * P];
     load_weights<TQ, L, P, FUSED>(p, row, m, a);
     const float g = io<TQ>::ld(reinterpret_cast<const TQ*>(p.grad_out) + row * ((int64_t)p.M * p.D) + m * p.D + c);
-    float* gv = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;
+    float* gv = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + c;
+    bf16_t* gv16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + c;
+    const bool b16 = p.gv_bf16 != 0;
+    // bf16 maps: the even lane of a channel pair adds both channels with ONE packed bf16x2 atomic (the corner weights are the
+    // same for all D lanes of a (query, head), so the pair takes every branch together)
+    auto add = [&](int64_t off, float v) __attribute__((always_inline)) {
+        if (b16) {
+            const float o = __shfl_xor(v, 1);
+            if (!(c & 1)) gv16_add2(gv16 + off, v, o);
+        } else {
+            atomicAdd(gv + off, v);
+        }
+    };
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         float xy[2 * P];
         load_points<TQ, L, P, FUSED>(p, row, n, q, m, l, p.W[l], p.H[l], xy);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const Corner cn = make_corner(xy[2 * i], xy[2 * i + 1], p.H[l], p.W[l], p.start[l], p.vs_s);
+            const Corner cn = make_corner(xy[2 * i], xy[2 * i + 1], p.H[l], p.W[l], p.start[l], p.gs_s);
             const float ag = a[l * P + i] * g;
-            if (cn.w00 != 0.f) atomicAdd(gv + cn.o00, ag * cn.w00);
-            if (cn.w01 != 0.f) atomicAdd(gv + cn.o01, ag * cn.w01);
-            if (cn.w10 != 0.f) atomicAdd(gv + cn.o10, ag * cn.w10);
-            if (cn.w11 != 0.f) atomicAdd(gv + cn.o11, ag * cn.w11);
+            if (cn.w00 != 0.f) add(cn.o00, ag * cn.w00);
+            if (cn.w01 != 0.f) add(cn.o01, ag * cn.w01);
+            if (cn.w10 != 0.f) add(cn.o10, ag * cn.w10);
+            if (cn.w11 != 0.f) add(cn.o11, ag * cn.w11);
         }
     }
 }
@@ -713,19 +739,6 @@ __device__ __forceinline__ void row_points(const int (&arow)[2], const float (&c
 template <typename T>
 __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-
-// packed bf16x2 memory-side atomic add (global_atomic_pk_add_bf16): `p2` = the even channel of a pair (4-byte aligned)
-typedef short gv_short2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gv16_add2(bf16_t* p2, float lo, float hi) {
-    const uint32_t w = pack_bf2(lo, hi);
-    const gv_short2_t v = {(short)(w & 0xffffu), (short)(w >> 16)};
-    (void)__builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) gv_short2_t*)(p2), v);
-}
-// ... of ONE channel c (its pair partner receives +0)
-__device__ __forceinline__ void gv16_add(bf16_t* pc, int c, float v) {
-    if (c & 1) gv16_add2(pc - 1, 0.f, v);
-    else gv16_add2(pc, v, 0.f);
 }
 
 // D == 16, P == 4 (one DPP row of 16 lanes = the 16 channels of a head = the <= 16 sample points of a query).
@@ -805,8 +818,8 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     (void)frexpf(gm, &ex);                                    // gm in [2^(ex-1), 2^ex)
     const float scale = ldexpf(1.f, 18 - ex), inv = ldexpf(1.f, ex - 18);
 
-    float* gvb = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;
-    bf16_t* gvb16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + c;       // (gv_bf16)
+    float* gvb = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + c;
+    bf16_t* gvb16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + c;       // (gv_bf16)
     const int lane_off = c * 4;
     // Two dummy pixels per DPP row of the wave, behind the windows.  (The LDS atomic unit works through a ds_add 16 lanes
     // = one pixel = 16 consecutive banks at a time, so the 4 rows of a wave never conflict with each other: measured, a
@@ -943,7 +956,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
                     for (int k = 0; k < 4; ++k) {
                         const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfar[k]), src));
                         if (mine && wv != 0.f) {
-                            const int64_t pe = (int64_t)(gpb + (k & 1) + (k >> 1) * wlr) * p.vs_s;
+                            const int64_t pe = (int64_t)(gpb + (k & 1) + (k >> 1) * wlr) * p.gs_s;
                             if (p.gv_bf16) gv16_add(gvb16 + pe, c, wv * gsi);
                             else atomicAdd(gvb + pe, wv * gsi);
                         }
@@ -966,7 +979,7 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
         const int wpf = bx - ax, cnt = wpf * (by - ay) * D;
         const float inv_wp = 1.f / (float)wpf;
         if (p.gv_bf16) {                                      // channel PAIRS: one packed bf16x2 atomic per nonzero pair
-            bf16_t* gl16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)start * p.vs_s;
+            bf16_t* gl16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + (int64_t)start * p.gs_s;
             const int2* w2 = reinterpret_cast<const int2*>(win + lofff * D);
             for (int i = tid; i < (cnt >> 1); i += TILED_NT) {
                 const int2 v = w2[i];
@@ -974,18 +987,18 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
                     const int cc = (i & 7) * 2, pix = i >> 3;
                     const int py = idiv_small(pix, wpf, inv_wp);
                     const int xx = ax + pix - py * wpf, yy = ay + py;
-                    gv16_add2(gl16 + (int64_t)(yy * W + xx) * p.vs_s + cc, (float)v.x * inv, (float)v.y * inv);
+                    gv16_add2(gl16 + (int64_t)(yy * W + xx) * p.gs_s + cc, (float)v.x * inv, (float)v.y * inv);
                 }
             }
         } else {
-        float* gl = p.grad_value + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + (int64_t)start * p.vs_s;
+        float* gl = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + (int64_t)start * p.gs_s;
         for (int i = tid; i < cnt; i += TILED_NT) {
             const int v = win[lofff * D + i];
             if (v != 0) {
                 const int cc = i & 15, pix = i >> 4;
                 const int py = idiv_small(pix, wpf, inv_wp);
                 const int xx = ax + pix - py * wpf, yy = ay + py;
-                atomicAdd(gl + (int64_t)(yy * W + xx) * p.vs_s + cc, (float)v * inv);
+                atomicAdd(gl + (int64_t)(yy * W + xx) * p.gs_s + cc, (float)v * inv);
             }
         }
         }
@@ -1474,6 +1487,7 @@ extern "C" int poet_msda_bwd(const void* value, const int64_t* shapes, const int
     if (rc) return rc;
     POET_CHECK(value && loc && attn && grad_out && grad_value && grad_loc && grad_attn, POET_ERR_ARG, "msda_bwd: null pointer");
     p.value = value; p.vs_n = (int64_t)S * M * D; p.vs_s = (int64_t)M * D; p.vs_m = D;
+    p.gs_n = p.vs_n; p.gs_s = p.vs_s; p.gs_m = p.vs_m;
     p.q1 = loc; p.q2 = attn; p.grad_out = grad_out; p.grad_value = grad_value; p.g1 = grad_loc; p.g2 = grad_attn;
     p.parts = 3;
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, (hipStream_t)stream);
@@ -1517,7 +1531,7 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
                                    const int64_t* starts, const void* offattn, int64_t ldq, int logit_col,
                                    const float* ref, int64_t ref_bs, const void* grad_out, void* grad_value,
                                    void* grad_offattn, int64_t ld_grad, int N, int S, int M, int D, int L, int P, int Lq,
-                                   int v_dtype, int q_dtype, int gv_dtype, int grid_queries, int parts, void* stream) {
+                                   int v_dtype, int q_dtype, int gv_dtype, int grid_queries, int parts, const int64_t* gv_strides, void* stream) {
     MsdaP p{};
     int rc = fill_common(p, shapes, starts, N, S, M, D, L, P, Lq);
     if (rc) return rc;
@@ -1531,15 +1545,13 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
     p.gv_bf16 = gv_dtype == POET_BF16;
     p.grid_queries = grid_queries;
     p.parts = (parts & 3) ? (parts & 3) : 3;
-    if (p.gv_bf16) {                                          // only the LDS-tiled scatter writes bf16 maps: refuse what would take the plain one
-        TileP tp_{};
-        const char* e_ = getenv("POET_NO_TILED_SCATTER");
-        const int64_t rows_ = (int64_t)N * Lq;                 // (the conditions of launch_dv_tiled)
-        POET_CHECK(grid_queries && Lq == S && q_dtype == POET_BF16 && P == 4 && L * P <= 16 && D == 16 && !(e_ && atoi(e_)) && plan_tiles(p, L, tp_) &&
-                   (vs_n % 2 == 0) && (vs_m % 2 == 0) && (vs_s % 2 == 0) && rows_ * M * D * 2 < (1ll << 32) && rows_ * ldq * 2 < (1ll << 32) &&
-                   !(ldq & 1) && !(ref_bs & 1) && ((int64_t)(N - 1) * ref_bs + (int64_t)Lq * L * 2) * 4 < (1ll << 32),
-                   POET_ERR_UNSUPPORTED, "msda_fused_bwd: a bf16 grad_value needs the LDS-tiled scatter (grid queries, D = 16, P = 4, bf16 offsets)");
-    }
+    // grad_value may be laid out differently from value ((n, s, m) element strides; NULL = the value strides): the decoder scatters
+    // straight into the token-major rows its value-projection backward consumes
+    p.gs_n = gv_strides ? gv_strides[0] : vs_n; p.gs_s = gv_strides ? gv_strides[1] : vs_s; p.gs_m = gv_strides ? gv_strides[2] : vs_m;
+    POET_CHECK(p.gs_s > 0 && p.gs_n >= 0 && p.gs_m >= 0, POET_ERR_ARG, "msda_fused_bwd: grad_value strides");
+    if (p.gv_bf16)                                            // packed bf16x2 atomics: channel pairs must be 4-byte aligned
+        POET_CHECK((p.gs_n % 2 == 0) && (p.gs_m % 2 == 0) && (p.gs_s % 2 == 0) && D % 2 == 0 && (reinterpret_cast<uintptr_t>(grad_value) & 3) == 0,
+                   POET_ERR_UNSUPPORTED, "msda_fused_bwd: a bf16 grad_value needs even strides and a 4-byte aligned base");
     rc = dispatch<true, true>(p, L, P, v_dtype, q_dtype, (hipStream_t)stream);
     if (rc) return rc;
     POET_LAUNCH_CHECK();

@@ -235,7 +235,11 @@ class DecoderFn(torch.autograd.Function):
         first = True
         nl = cfg["n_layers"]
         vs = ctx.vstack
-        dV_all = torch.zeros((N, M * nl, S, D), dtype=torch.float32, device=dhs.device) if vs is not None else None
+        # bf16 policy with stacked value projections: the scatters of all layers write bf16 token-major rows (N*S, nl*M*D) in place --
+        # what the stacked weight / input-gradient GEMMs read; no fp32 head-major staging map (522 MB zero-fill + transposing pass)
+        rows16 = vs is not None and ctx.mem2.dtype == torch.bfloat16 and os.environ.get("POET_DEC_DV_F32", "0") in ("", "0")
+        dVr_all = torch.zeros((N * S, nl * M * D), dtype=torch.bfloat16, device=dhs.device) if rows16 else None
+        dV_all = torch.zeros((N, M * nl, S, D), dtype=torch.float32, device=dhs.device) if (vs is not None and not rows16) else None
         dqp = torch.zeros((N * Q, d), dtype=torch.float32, device=dhs.device) if ctx.need_qpos else None
         mlp = M * geom.L * cfg["P"]
         dref = torch.zeros((N, Q, geom.L, 2), dtype=torch.float32, device=dhs.device) if ctx.need_ref else None
@@ -251,7 +255,10 @@ class DecoderFn(torch.autograd.Function):
                     ops.add(dx, dcur, dx)
                 else:
                     dx = dcur.clone()
-                dV = dV_all[:, i * M:(i + 1) * M] if vs is not None else torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
+                if rows16:
+                    dV = dVr_all.view(N, S, nl, M, D)[:, :, i].permute(0, 2, 1, 3)      # (N, M, S, D) view of this layer's column block
+                else:
+                    dV = dV_all[:, i * M:(i + 1) * M] if vs is not None else torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
                 # (a fresh buffer per layer: the deferred weight-gradient launches read it after the loop)
                 dOA = torch.empty((N * Q, 3 * mlp), dtype=torch.float32, device=dhs.device) if ctx.need_ref else None
                 dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV, dqp=dqp, dOA_out=dOA)
@@ -267,7 +274,7 @@ class DecoderFn(torch.autograd.Function):
                 ctx.saved[i] = None
         if vs is not None:                                # one stacked backward for the value projections of all layers
             B.value_proj_bwd(dV_all, ctx.mem2, vs["w16"] if ctx.mem2.dtype == torch.bfloat16 else vs["w"], ctx.mask, N, S, M * nl, D,
-                             vs["gw"], vs["gb"], dmem, False, cfg.get("act"), wb_is_operand=True)
+                             vs["gw"], vs["gb"], dmem, False, cfg.get("act"), wb_is_operand=True, dVr=dVr_all)
         ops.SIDE.join()
         announce("1_decoder")
         dmemory = dmem.view(N, S, d) if ctx.need_mem else None

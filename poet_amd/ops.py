@@ -388,7 +388,8 @@ def msda_fused_fwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 
 
 def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value,
-                   grad_offattn, N, M, D, P, Lq, grid_queries=False, parts=3, ld_grad=0):
+                   grad_offattn, N, M, D, P, Lq, grid_queries=False, parts=3, ld_grad=0, gv_strides=None):
+    """gv_strides: (n, s, m) element strides of grad_value when it is not laid out like value."""
     lib = _lib.load()
     if PROFILE.on and not getattr(msda_fused_bwd, "_timing", False):       # time the two kernels of the backward separately
         a = (value, vstrides, geom, offattn, ldq, logit_col, ref, ref_bs, grad_out, grad_value, grad_offattn, N, M, D, P, Lq)
@@ -396,10 +397,10 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
         msda_fused_bwd._timing = True
         try:
             if parts in (2, 3, 0):
-                e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2, ld_grad=ld_grad)
+                e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2, ld_grad=ld_grad, gv_strides=gv_strides)
                 PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype == torch.bfloat16) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * grad_value.element_size())
             if parts in (1, 3, 0):
-                e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1, ld_grad=ld_grad)
+                e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1, ld_grad=ld_grad, gv_strides=gv_strides)
                 PROFILE.end("msda_bwd_dq" + ("_small" if N * Lq < 4096 else ""), e0, 0.0, nb_q)
         finally:
             msda_fused_bwd._timing = False
@@ -407,7 +408,8 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
     _lib.check(lib.poet_msda_fused_bwd(_req(value, "value").data_ptr(), *vstrides, geom.c_shapes, geom.c_starts,
                                        offattn.data_ptr(), ldq, logit_col, ref.data_ptr(), ref_bs, grad_out.data_ptr(),
                                        grad_value.data_ptr(), grad_offattn.data_ptr(), ld_grad, N, geom.S, M, D, geom.L, P, Lq,
-                                       dcode(value), dcode(offattn), dcode(grad_value), int(grid_queries), parts, _stream()), "poet_msda_fused_bwd")
+                                       dcode(value), dcode(offattn), dcode(grad_value), int(grid_queries), parts,
+                                       None if gv_strides is None else (C.c_int64 * 3)(*gv_strides), _stream()), "poet_msda_fused_bwd")
 
 
 # ---- norms -----------------------------------------------------------------------------------------
@@ -548,6 +550,13 @@ def vgrad_to_rows(gv, vstrides, row_mask, out, N, S, M, D, ld_out=0):
     lib = _lib.load()
     _lib.check(lib.poet_vgrad_to_rows(_req(gv, "gv").data_ptr(), *vstrides, _ptr(row_mask), out.data_ptr(), ld_out, N, S, M, D, dcode(gv), dcode(out),
                                       _stream()), "poet_vgrad_to_rows")
+
+
+def zero_masked_rows(x, row_mask, rows, cols):
+    """x (rows, cols) with row stride x.stride(0): rows whose mask byte is set become zero."""
+    lib = _lib.load()
+    _lib.check(lib.poet_zero_masked_rows(_req(x, "x").data_ptr(), x.stride(0), row_mask.data_ptr(), rows, cols, dcode(x), _stream()),
+               "poet_zero_masked_rows")
 
 
 def nchw_to_tokens(src, dst, N, Cc, HW, tok_off, tok_stride):

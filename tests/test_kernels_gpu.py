@@ -223,6 +223,53 @@ def test_msda_fused(ops, vdt, qdt, head_major):
     _close(goa, oa32.grad, worst, scale=3, msg="fused d(off|logit)")
 
 
+@pytest.mark.parametrize("gdt", [torch.bfloat16, torch.float32])
+def test_msda_fused_bwd_scatter_into_token_rows(ops, gdt):
+    """The decoder's value-gradient path (functional.DecoderFn.backward, bf16 policy): head-major value maps, but grad_value is a column
+    block of token-major rows (N*S, layers*M*D) addressed by its own strides (poet_msda_fused_bwd gv_strides) and, in bf16, accumulated
+    with packed bf16x2 atomics; masked rows are zeroed afterwards (poet_zero_masked_rows).  Reference: autograd of the explicit
+    sampling (models/deformable_transformer.py:300-340 cross-attention, ops/functions/ms_deform_attn_func.py:41-61)."""
+    shapes = [(10, 12), (5, 6), (3, 3)]
+    n, m, d, lq, p, nl, layer = 2, 4, 16, 23, 4, 3, 1
+    L = len(shapes)
+    geom = ops.LevelGeom(shapes)
+    S = geom.S
+    rng = np.random.default_rng(11)
+    value = torch.from_numpy(rng.standard_normal((n, S, m, d)).astype(np.float32)).to(torch.bfloat16)
+    mlp = m * L * p
+    oa = torch.from_numpy(np.concatenate([rng.standard_normal((n, lq, 2 * mlp)) * 2.0, rng.standard_normal((n, lq, mlp))], -1).astype(np.float32))
+    ref_pts = torch.from_numpy(rng.uniform(-0.1, 1.1, (n, lq, L, 2)).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((n, lq, m * d)).astype(np.float32))
+    v32 = value.float().requires_grad_()
+    oa32 = oa.clone().requires_grad_()
+    off = oa32[..., : 2 * mlp].view(n, lq, m, L, p, 2)
+    w = torch.softmax(oa32[..., 2 * mlp:].view(n, lq, m, L * p), -1).view(n, lq, m, L, p)
+    norm = torch.tensor([[wd, ht] for ht, wd in shapes], dtype=torch.float32)
+    loc = ref_pts[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    (poet_ref.msda_core(v32, shapes, loc, w) * gout).sum().backward()
+
+    vdev = dev(value.permute(0, 2, 1, 3).contiguous())                   # head-major (N, M, S, D)
+    vstr = (m * S * d, d, S * d)
+    rows = torch.full((n * S, nl * m * d), 7.0, dtype=gdt, device="cuda")  # the other layers' columns must stay untouched
+    blk = rows.view(n, S, nl, m, d)[:, :, layer]
+    blk.zero_()
+    gv = blk.permute(0, 2, 1, 3)                                         # (N, M, S, D) view of the column block
+    goa = torch.empty_like(dev(oa))
+    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, dev(ref_pts), lq * L * 2, dev(gout), gv, goa, n, m, d, p, lq,
+                       gv_strides=(gv.stride(0), gv.stride(2), gv.stride(1)))
+    got = rows.view(n, S, nl, m, d)[:, :, layer].float().cpu()
+    _close(got, v32.grad, torch.bfloat16, scale=3, msg="dvalue rows")
+    _close(goa, oa32.grad, torch.bfloat16, scale=3, msg="d(off|logit)")
+    assert (rows.view(n, S, nl, m, d)[:, :, [0, 2]] == 7.0).all()
+    mask = torch.from_numpy(rng.uniform(size=n * S) < 0.3).cuda()
+    ops.zero_masked_rows(rows, mask, n * S, nl * m * d)
+    out = rows.float().cpu()
+    assert (out[mask.cpu()] == 0).all()
+    keep = (~mask).cpu()
+    assert torch.equal(out.view(n * S, nl, m * d)[keep][:, layer], got.reshape(n * S, m * d)[keep])
+    assert (out.view(n * S, nl, m * d)[keep][:, [0, 2]] == 7.0).all()
+
+
 # ---------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("d", [256, 64])

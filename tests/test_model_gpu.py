@@ -572,9 +572,16 @@ def test_transformer_nchw_dropin_matches_oracle(gpu):
         assert (p.grad.cpu() - pr[n].grad).abs().max().item() < 2e-3 * max(1.0, pr[n].grad.abs().max().item()), n
 
 
-def test_graphed_trainer_matches_eager(gpu):
+@pytest.mark.parametrize("dec_dv", ["bf16_rows", "f32_maps"])
+def test_graphed_trainer_matches_eager(gpu, dec_dv, monkeypatch):
     """HIP-graph replay of forward / backward+optimiser == the eager launch sequence (dropout off so both are
-    deterministic), across steps whose targets change (different boxes, object counts and assignments)."""
+    deterministic), across steps whose targets change (different boxes, object counts and assignments).
+    dec_dv: the decoder's value gradient is scattered with packed bf16 atomics straight into token-major rows (default), or
+    with fp32 atomics into head-major staging maps (POET_DEC_DV_F32=1).  Both are order dependent; a bf16 read-modify-write
+    rounds every partial sum of a pixel that several samples hit (2^-9 of it), and AdamW turns the sign of a near-zero gradient
+    into a +-lr step (2e-4 per step): the two launch modes may drift 2e-3 apart in 5 steps instead of 1e-3."""
+    monkeypatch.setenv("POET_DEC_DV_F32", "1" if dec_dv == "f32_maps" else "0")
+    ptol, ltol = (1e-3, 2e-3) if dec_dv == "f32_maps" else (2e-3, 4e-3)
     import poet_amd
     from oracle.formula import CONFIGS, make_inputs
     cfg = CONFIGS["tiny"]
@@ -599,17 +606,20 @@ def test_graphed_trainer_matches_eager(gpu):
             assert (tr.segs is not None) == (mode == "segmented")
         runs[mode] = (losses, {n: p.detach().float().cpu().clone() for n, p in r["model"].named_parameters()})
     for mode in ("graph", "segmented"):
-        assert runs[mode][0] == pytest.approx(runs["eager"][0], rel=2e-3, abs=2e-3), (mode, runs)
+        assert runs[mode][0] == pytest.approx(runs["eager"][0], rel=ltol, abs=ltol), (mode, runs[mode][0], runs["eager"][0])
         worst = max((runs[mode][1][n] - runs["eager"][1][n]).abs().max().item() for n in runs["eager"][1])
-        assert worst < 1e-3, (mode, worst)
+        assert worst < ptol, (mode, worst)
     worst = max((runs["segmented"][1][n] - runs["graph"][1][n]).abs().max().item() for n in runs["graph"][1])
-    assert worst < 1e-3, worst                    # same kernels in the same order (fp32 atomics make runs differ at ~1e-4 after AdamW)
+    assert worst < ptol, worst                    # same kernels in the same order (fp32 atomics make runs differ at ~1e-4 after AdamW)
 
 
-def test_graphed_trainer_captures_matcher_and_loss(gpu):
+def test_graphed_trainer_captures_matcher_and_loss(gpu, monkeypatch):
     """With the on-device matcher ('gt' mode, default loss pair) assignment + loss + their gradients are part of the forward
     graph: no eager launch between the replays.  Same trajectory as the eager trainer with the HOST (SciPy) matcher across
     steps whose targets, object counts and assignments change -- and as the graphed trainer with the eager loss."""
+    # (fp32 staging maps for the decoder's value gradient: this test pins the matcher / loss capture at 1e-3 over 6 AdamW steps,
+    # below the run-to-run spread of the default bf16 atomics -- test_graphed_trainer_matches_eager covers both)
+    monkeypatch.setenv("POET_DEC_DV_F32", "1")
     import poet_amd
     from oracle.formula import CONFIGS, make_inputs
     cfg = CONFIGS["tiny"]
