@@ -82,10 +82,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     }
 }
 
-// NIT: 64-lane x 4-column passes over a row (1 for d <= 256); R: rows a wave has in flight per loop trip -- the kernel runs 8
-// waves per CU (the grid is capped so that the per-column atomics at the end stay few), so the memory-level parallelism has to
-// come from the wave itself: with one row per trip it moved 312 MB in 75 us.
-template <typename TX, typename TR, int NIT, int R>
+template <typename TX, typename TR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, const TX* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, TR* __restrict__ dz,
@@ -93,80 +90,63 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, 
                                                      float* __restrict__ dbeta, int64_t rows, int d,
                                                      uint32_t thresh, float dscale, uint32_t seed,
                                                      const uint32_t* __restrict__ seed_dev) {
-    __shared__ float red[2][4][NIT * 256];
+    __shared__ float red[2][4][LN_MAXIT * 256];
     if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float ag[NIT][4], ab[NIT][4], gm[NIT][4];
+    float ag[LN_MAXIT][4], ab[LN_MAXIT][4], gm[LN_MAXIT][4];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < LN_MAXIT; ++it) {
         const int c = (lane + 64 * it) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ag[it][e] = 0.f; ab[it][e] = 0.f; gm[it][e] = 0.f; }
         if (c < d) vec<float, 4>::ld(gamma + c, gm[it]);
     }
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t row0 = (int64_t)blockIdx.x * 4 + wid; row0 < rows; row0 += stride * R) {
-        float a[R][NIT][4], zz[R][NIT][4], mu[R], rs[R];
-        // all loads of the R rows go out before anything is consumed (rows past the end re-read the last row; masked below)
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAXIT][4], xh[LN_MAXIT][4];
+        float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t row = min(row0 + r * stride, rows - 1);
-            mu[r] = mean[row]; rs[r] = rstd[row];
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < d) {
+                float a[4], zz[4];
+                vec<TR, 4>::ld(dy + row * d + c, a);
+                vec<TX, 4>::ld(z + row * d + c, zz);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = (lane + 64 * it) * 4;
-                if (c < d) {
-                    vec<TR, 4>::ld(dy + row * d + c, a[r][it]);
-                    vec<TX, 4>::ld(z + row * d + c, zz[r][it]);
+                for (int e = 0; e < 4; ++e) {
+                    xh[it][e] = (zz[e] - mu) * rs;
+                    ag[it][e] += a[e] * xh[it][e];
+                    ab[it][e] += a[e];
+                    g[it][e] = a[e] * gm[it][e];
+                    c1 += g[it][e];
+                    c2 += g[it][e] * xh[it][e];
                 }
             }
         }
+        c1 = wave_sum(c1) / (float)d;
+        c2 = wave_sum(c2) / (float)d;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t row = row0 + r * stride;
-            if (row >= rows) break;                                      // (wave-uniform)
-            float g[NIT][4], xh[NIT][4];
-            float c1 = 0.f, c2 = 0.f;
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c = (lane + 64 * it) * 4;
+            if (c < d) {
+                float o[4];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = (lane + 64 * it) * 4;
-                if (c < d) {
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
+                vec<TR, 4>::st(dz + row * d + c, o);
+                if (dx && ((const void*)dx != (const void*)dz || thresh)) {
+                    if (thresh) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        xh[it][e] = (zz[r][it][e] - mu[r]) * rs[r];
-                        ag[it][e] += a[r][it][e] * xh[it][e];
-                        ab[it][e] += a[r][it][e];
-                        g[it][e] = a[r][it][e] * gm[it][e];
-                        c1 += g[it][e];
-                        c2 += g[it][e] * xh[it][e];
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c + e), thresh) ? o[e] * dscale : 0.f;
                     }
-                }
-            }
-            c1 = wave_sum(c1) / (float)d;
-            c2 = wave_sum(c2) / (float)d;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = (lane + 64 * it) * 4;
-                if (c < d) {
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rs[r] * (g[it][e] - c1 - xh[it][e] * c2);
-                    vec<TR, 4>::st(dz + row * d + c, o);
-                    if (dx && ((const void*)dx != (const void*)dz || thresh)) {
-                        if (thresh) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                o[e] = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c + e), thresh) ? o[e] * dscale : 0.f;
-                        }
-                        vec<TX, 4>::st(dx + row * d + c, o);
-                    }
+                    vec<TX, 4>::st(dx + row * d + c, o);
                 }
             }
         }
     }
     // block reduction of the parameter gradients, then one atomic per column per block
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < LN_MAXIT; ++it) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             red[0][wid][(lane + 64 * it) * 4 + e] = ag[it][e];
@@ -517,12 +497,9 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     if (nb > 512) nb = 512;          // one row per wave iteration, no prefetch: occupancy is what hides the load latency
     dim3 grid(nb), block(256);
     hipStream_t st = (hipStream_t)stream;
-    static const int rpt = [] { const char* e = getenv("POET_LN_BWD_ROWS"); return e ? atoi(e) : 4; }();     // rows in flight per wave (A/B switch)
-#define LN_BWD_(TX, TR, NIT, R) ln_bwd_kernel<TX, TR, NIT, R><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev)
-#define LN_BWD(TX, TR) do { if (d > 256) LN_BWD_(TX, TR, LN_MAXIT, 1); else if (rpt == 1 || rows < 4096) LN_BWD_(TX, TR, 1, 1); else if (rpt == 2) LN_BWD_(TX, TR, 1, 2); else LN_BWD_(TX, TR, 1, 4); } while (0)
+#define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev)
     POET_DT2(dtype_x, dtype_r, LN_BWD);
 #undef LN_BWD
-#undef LN_BWD_
     POET_LAUNCH_CHECK();
     return POET_OK;
 }
