@@ -7,6 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpoet_hip.so")
+ABI_VERSION = 2                                # POET_ABI_VERSION of include/poet_hip.h this binding was written against
 
 F32, BF16 = 0, 1
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -95,7 +96,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError here = header/library mismatch
         fn.argtypes = args
         fn.restype = res
-    if lib.poet_hip_version() != 2:
+    if lib.poet_hip_version() != ABI_VERSION:
         raise PoetHipError("libpoet_hip.so ABI version mismatch")
     _lib = lib
     return lib

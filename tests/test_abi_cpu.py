@@ -126,3 +126,10 @@ def test_default_init_matches_reference_rng_order(golden_dir):
     model = poet_amd.PoET(BB(), tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode="gt", class_mode="specific")
     for (n, p), ref in zip(model.named_parameters(), g["param_checksums"]):
         np.testing.assert_allclose(checksum(p), ref, atol=0, rtol=0, err_msg=n)
+
+
+def test_graft_entry_build_passes():
+    """The driver's per-round "does it build" check is `__graft_entry__.build()`: it must agree with the library's ABI version
+    (it asserted version 1 after the header had moved to 2) and resolve every declared symbol."""
+    import __graft_entry__
+    __graft_entry__.build()
