@@ -467,6 +467,39 @@ def test_pose_finish(ops, golden_dir):
     assert torch.allclose(dta.cpu(), ta.grad, atol=1e-6)
 
 
+@pytest.mark.parametrize("n", [5000, 5003, 70])
+def test_adamw_vector_path_equals_element_path(ops, n):
+    """poet_adamw updates four consecutive elements per thread when its buffers are 16-byte aligned and falls back to one element at
+    a time otherwise: the two paths must agree bit for bit, including the per-64-element learning-rate table and the two bf16 weight images (optimizer step of main.py:300-305 / torch.optim.AdamW)."""
+    p0 = _rand(n + 1, seed=170); g0 = _rand(n + 1, seed=171) * 0.01
+    lrs = dev(torch.linspace(0.1, 1.0, (n + 64) // 64 + 1))
+    outs = []
+    for off in (0, 1):                                                   # off = 1: every buffer misaligned by one element
+        pad = 4 - off                                                    # keep the SAME element <-> learning-rate-group relation in both runs
+        def buf(t, dt=torch.float32):
+            full = torch.zeros(pad + n + 8, dtype=dt, device="cuda")
+            if t is not None:
+                full[pad: pad + n] = t[:n].to(dt).cuda()
+            return full
+        P, G, M_, V_ = buf(p0), buf(g0), buf(None), buf(None)
+        H, L = buf(None, torch.bfloat16), buf(None, torch.bfloat16)
+        if off == 0:
+            views = [t[pad: pad + n] for t in (P, G, M_, V_, H, L)]     # pad = 4 floats: 16-byte aligned
+        else:
+            views = [t[pad: pad + n] for t in (P, G, M_, V_, H, L)]     # pad = 3 floats: misaligned
+        p, g, m, v, h, l = views
+        assert (p.data_ptr() % 16 == 0) == (off == 0)
+        sq = torch.zeros(1 + 1024, device="cuda")
+        for step in (1, 2, 3):
+            sq.zero_(); ops.sqnorm(g, sq)
+            # (the learning-rate group of element k is k >> 6 relative to the view's first element in both runs)
+            ops.adamw(p, g, m, v, n, 2e-4, 0.9, 0.999, 1e-8, 1e-4, step, sqnorm_buf=sq, max_norm=0.1, p_bf16=h, lr_scale=lrs, p_bf16_lo=l)
+        outs.append([t.clone().float().cpu() for t in (p, m, v, h, l)])
+    for a, b, name in zip(outs[0], outs[1], ("p", "m", "v", "hi", "lo")):
+        assert torch.equal(a, b), name
+    assert torch.equal(outs[0][3] + outs[0][4], (outs[0][0].to(torch.bfloat16).float() + (outs[0][0] - outs[0][0].to(torch.bfloat16).float()).to(torch.bfloat16).float()))
+
+
 def test_adamw_and_clip(ops):
     n = 5000
     p0 = _rand(n, seed=70); g = _rand(n, seed=71) * 0.01
