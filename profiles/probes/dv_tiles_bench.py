@@ -33,6 +33,6 @@ gout = torch.randn(n, S, m * d, device="cuda", generator=g).to(torch.bfloat16)
 ref = torch.empty(n, S, L, 2, device="cuda")
 ops.enc_ref_points(torch.ones(n, L, 2, device="cuda"), geom, ref, n)
 vstr = (m * S * d, d, S * d)
-gv = torch.zeros(n, m, S, d, device="cuda"); goa = torch.empty_like(oa)
+gv = torch.zeros(n, m, S, d, device="cuda", dtype=torch.bfloat16 if os.environ.get("GV", "bf16") == "bf16" else torch.float32); goa = torch.empty_like(oa)   # (GV=f32: the fp32 map)
 def dv(): ops.msda_fused_bwd(value, vstr, geom, oa, 3 * mlp, 2 * mlp, ref, S * L * 2, gout, gv, goa, n, m, d, p, S, grid_queries=True, parts=2)
 print(f"dV {timeit(dv):.1f} us")
