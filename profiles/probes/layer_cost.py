@@ -3,7 +3,7 @@ kernels and cannot show how much of the decoder's ~90 small launches per layer o
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import bench, poet_amd
-from oracle.formula import CONFIGS
+CONFIGS = bench.CONFIGS
 device = torch.device("cuda:0")
 def step_ms(enc, dec, batch=16, steps=30):
     cfg = dict(CONFIGS["ycbv"], enc_layers=enc, dec_layers=dec)
