@@ -1263,7 +1263,8 @@ static size_t tile_footprint(const MsdaP& p, int L, int TX, int TY, int halo, si
 // The FEWEST tiles whose windows (tile + halo of every level) fit the pixel budget -- TX and TY chosen independently: larger
 // tiles mean fewer halo pixels to zero and flush and fewer samples that leave the window (measured at 1280x960: 8x8 tiles
 // 1152 us, 4x8 970 us, 6x5 975 us; at 640x480 2x2 458 us against 606 us for 4x4).  Ties go to the smaller footprint.
-static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, size_t extra_px, int halo_hi = 4, int halo_lo = 2, int halo_step = 2) {
+static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, size_t extra_px, int halo_hi = 4, int halo_lo = 2, int halo_step = 2,
+                            bool grow_halo = false) {
     for (int halo = halo_hi; halo >= halo_lo; halo -= halo_step) {
         int best_tx = 0, best_ty = 0;
         size_t best_px = 0;
@@ -1278,7 +1279,18 @@ static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, 
                 if (px + extra_px > px_budget || q > 8000) continue;
                 if (!best_tx || TX * TY < best_tx * best_ty || px < best_px) { best_tx = TX; best_ty = TY; best_px = px; }
             }
-        if (best_tx) { tp.TX = best_tx; tp.TY = best_ty; tp.HALO = halo; tp.skip = 0; return best_px + extra_px; }
+        if (best_tx) {
+            // one more halo pixel when the same tiling still fits: with n_points = 4 the initial sampling pattern reaches 4 px (+ 1 for the
+            // right / lower bilinear corner), so a halo of 5 keeps it inside the window (measured at 640x480, 2 x 2 tiles: 376 -> 362 us,
+            // 13.57 -> 13.50 ms per step; a halo of 6 gives the gain back to the larger windows: 380 us)
+            if (grow_halo && halo == halo_hi) {
+                size_t q = 0;
+                const size_t px5 = tile_footprint(p, L, best_tx, best_ty, halo + 1, &q);
+                if (px5 + extra_px <= px_budget && q <= 8000) { halo += 1; best_px = px5; }
+            }
+            tp.TX = best_tx; tp.TY = best_ty; tp.HALO = halo; tp.skip = 0;
+            return best_px + extra_px;
+        }
     }
     return 0;
 }
@@ -1303,7 +1315,7 @@ static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
         }
     }
     // 150 KB of int32 windows (one 1024-thread workgroup per CU) + 1 pad pixel + 8 dummy pixels (see the kernel)
-    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 9) * 16 * 4;
+    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 9, 4, 2, 2, true) * 16 * 4;
 }
 
 template <typename TV, typename TQ, int L, bool BWD>
