@@ -1263,9 +1263,13 @@ static size_t tile_footprint(const MsdaP& p, int L, int TX, int TY, int halo, si
 // The FEWEST tiles whose windows (tile + halo of every level) fit the pixel budget -- TX and TY chosen independently: larger
 // tiles mean fewer halo pixels to zero and flush and fewer samples that leave the window (measured at 1280x960: 8x8 tiles
 // 1152 us, 4x8 970 us, 6x5 975 us; at 640x480 2x2 458 us against 606 us for 4x4).  Ties go to the smaller footprint.
-static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, size_t extra_px, int halo_hi = 4, int halo_lo = 2, int halo_step = 2,
-                            bool grow_halo = false) {
-    for (int halo = halo_hi; halo >= halo_lo; halo -= halo_step) {
+// Halo first, tile count second: a sample whose corner leaves the window takes the slow path (wave-voted global atomics), and with
+// n_points = 4 the initial sampling pattern reaches 4 px (+ 1 for the right / lower bilinear corner), so a halo of 5 keeps it inside --
+// measured per launch: 640x480 2 x 2 tiles 383 us at halo 4, 366 at 5, 380 at 6; 1280x960 the fewest tiles at halo 4 (8 x 3) 974 us, the
+// same 5 x 6 tiling 1110 us at halo 4 and 833 at halo 5 (8 x 4: 828, 6 x 6: 867).  `halos`: the values tried, in order.
+static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, size_t extra_px, const int* halos, int n_halos) {
+    for (int hi = 0; hi < n_halos; ++hi) {
+        const int halo = halos[hi];
         int best_tx = 0, best_ty = 0;
         size_t best_px = 0;
         const int mx = min(16, max(p.W[0] / 4, 1)), my = min(16, max(p.H[0] / 4, 1));
@@ -1279,18 +1283,7 @@ static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, 
                 if (px + extra_px > px_budget || q > 8000) continue;
                 if (!best_tx || TX * TY < best_tx * best_ty || px < best_px) { best_tx = TX; best_ty = TY; best_px = px; }
             }
-        if (best_tx) {
-            // one more halo pixel when the same tiling still fits: with n_points = 4 the initial sampling pattern reaches 4 px (+ 1 for the
-            // right / lower bilinear corner), so a halo of 5 keeps it inside the window (measured at 640x480, 2 x 2 tiles: 376 -> 362 us,
-            // 13.57 -> 13.50 ms per step; a halo of 6 gives the gain back to the larger windows: 380 us)
-            if (grow_halo && halo == halo_hi) {
-                size_t q = 0;
-                const size_t px5 = tile_footprint(p, L, best_tx, best_ty, halo + 1, &q);
-                if (px5 + extra_px <= px_budget && q <= 8000) { halo += 1; best_px = px5; }
-            }
-            tp.TX = best_tx; tp.TY = best_ty; tp.HALO = halo; tp.skip = 0;
-            return best_px + extra_px;
-        }
+        if (best_tx) { tp.TX = best_tx; tp.TY = best_ty; tp.HALO = halo; tp.skip = 0; return best_px + extra_px; }
     }
     return 0;
 }
@@ -1315,7 +1308,8 @@ static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
         }
     }
     // 150 KB of int32 windows (one 1024-thread workgroup per CU) + 1 pad pixel + 8 dummy pixels (see the kernel)
-    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 9, 4, 2, 2, true) * 16 * 4;
+    static const int halos[3] = {5, 4, 2};
+    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 9, halos, 3) * 16 * 4;
 }
 
 template <typename TV, typename TQ, int L, bool BWD>
@@ -1339,7 +1333,9 @@ static bool launch_win(const MsdaP& p, int P, hipStream_t st) {
     // noisy samples -- half of all (wave, sample) steps -- would take the global-memory path
     int halo_hi = 5;
     { const char* e = getenv("POET_WIN_HALO"); if (e && atoi(e) >= 2 && atoi(e) <= 12) halo_hi = atoi(e); }
-    const size_t px = plan_tiles_px(p, L, tp, (size_t)(78 * 1024) / (32 * hpw), 0, halo_hi, min(halo_hi, 4), 1);
+    int halos[16], n_halos = 0;
+    for (int h = halo_hi; h >= min(halo_hi, 4); --h) halos[n_halos++] = h;
+    const size_t px = plan_tiles_px(p, L, tp, (size_t)(78 * 1024) / (32 * hpw), 0, halos, n_halos);
     if (!px) return false;
     gp.TX = tp.TX; gp.TY = tp.TY; gp.HALO = tp.HALO; gp.HPW = hpw;
     const size_t lds = px * 32 * hpw;
