@@ -1242,6 +1242,8 @@ __global__ __launch_bounds__(WIN_NT, 2) void msda_win_kernel(const MsdaP p, cons
 
 // host: pick the tile grid / halo so the windows fit the LDS budget; returns window PIXELS of the largest tile (0 = no plan).
 // px_budget: pixels that fit; extra_px: pixels reserved behind the windows.
+// int32 windows of one workgroup (dynamic LDS; + pad / dummy pixels and a few static words: under the CU's 160 KB)
+constexpr int POET_DV_LDS_BYTES = 157 * 1024;
 static size_t tile_footprint(const MsdaP& p, int L, int TX, int TY, int halo, size_t* max_q) {
     size_t worst = 0, worst_q = 0;
     for (int ty = 0; ty < TY; ++ty)
@@ -1304,12 +1306,12 @@ static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
                     }
                     worst = max(worst, px);
                 }
-            if (worst + 9 <= (size_t)(150 * 1024 / 64)) { tp.TX = tx; tp.TY = ty; tp.HALO = halo; tp.skip = 0; return (worst + 9) * 64; }
+            if (worst + 9 <= (size_t)(POET_DV_LDS_BYTES / 64)) { tp.TX = tx; tp.TY = ty; tp.HALO = halo; tp.skip = 0; return (worst + 9) * 64; }
         }
     }
     // 150 KB of int32 windows (one 1024-thread workgroup per CU) + 1 pad pixel + 8 dummy pixels (see the kernel)
     static const int halos[3] = {5, 4, 2};
-    return plan_tiles_px(p, L, tp, 150 * 1024 / (16 * 4), 9, halos, 3) * 16 * 4;
+    return plan_tiles_px(p, L, tp, POET_DV_LDS_BYTES / (16 * 4), 9, halos, 3) * 16 * 4;
 }
 
 template <typename TV, typename TQ, int L, bool BWD>
@@ -1363,7 +1365,7 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
     if (!lds) return false;
     auto kern = msda_bwd_dv_tiled_kernel<TQ, L>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048); attr_set = true; }
     hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
     return true;
     }
