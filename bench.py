@@ -122,7 +122,23 @@ def _pmc_key(tag):
     return best
 
 
-def pmc_traffic_bytes(tag, config="ycbv"):
+def pmc_source(config="ycbv", kind="hbm"):
+    """Where `roofline.traffic` comes from: the committed counter summary (collected by profiles/collect.sh in separate
+    --pmc passes on an EARLIER box, not in this run) and a content hash of that file, so a reader can tell which one."""
+    import glob, hashlib, re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{config}_pmc_{kind}.csv")),
+                   key=lambda p: int(re.search(r"round(\d+)_", os.path.basename(p)).group(1)))
+    if not paths:
+        return None
+    return {"file": "profiles/" + os.path.basename(paths[-1]), "sha256_12": hashlib.sha256(open(paths[-1], "rb").read()).hexdigest()[:12],
+            "measured_in_this_run": False, "fetch_correction": FETCH_CORRECTION_NOTE}
+
+
+FETCH_CORRECTION_NOTE = ("traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB: the guide's gfx950 correction (FETCH_SIZE counts half of a wide "
+                         "coalesced read); traffic_raw = (FETCH_SIZE + WRITE_SIZE) KiB; per-pattern calibration: profiles/probes/fetch_calib.hip")
+
+
+def pmc_traffic_bytes(tag, config="ycbv", fetch_factor=2.0):
     tag = _pmc_key(tag)
     key = _PMC_NAMES.get(tag)
     _, rows = _pmc_rows(config, "hbm")
@@ -133,7 +149,7 @@ def pmc_traffic_bytes(tag, config="ycbv"):
     for alt in key.split("|"):                          # first alternative present in the summary; launch-weighted mean over
         for r in rows[1:]:                              # its symbols
             if alt in r[0] and flt in r[0]:
-                tot += float(r[1]) * (2 * float(r[2]) + float(r[4])) * 1024
+                tot += float(r[1]) * (fetch_factor * float(r[2]) + float(r[4])) * 1024
                 n += float(r[1])
         if n:
             break
@@ -411,6 +427,8 @@ def main():
         if prof is not None:
             out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)
             out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"], args.config)
+            out["roofline"]["traffic_raw"] = pmc_traffic_bytes(out["roofline"]["kernel"], args.config, fetch_factor=1.0)
+            out["roofline"]["traffic_source"] = pmc_source(args.config)
             # the three kernels (symbol x shape) that take the most time, each against its own roof, with the counter traffic
             # of the committed PMC summary next to the algorithmic bytes
             top = []
@@ -434,6 +452,11 @@ def main():
                 out["roofline"]["limiter"] = "VALU issue, not HBM: ~310 instructions per 4 queries x 64 corners x 16 channels, 160 of them half-rate DPP / convert (2.5 per ds_add_u32 wave-instruction, 26 M of those per launch); with the LDS atomics compiled out the accumulate phase is only 7 % faster: DESIGN.md section 5/9"
             out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
                                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+            bsum = sum(v["total_ms"] for v in prof.values()) / prof_steps
+            out["kernel_breakdown_note"] = (f"EAGER launches timed by per-launch HIP events over {prof_steps} extra steps after the timed region; "
+                                            f"NOT additive: the sum ({bsum:.3f} ms) exceeds ms_per_step ({ms:.3f} ms, hipGraph replay) because "
+                                            "each of the ~400 small launches carries event overhead and replayed kernels overlap head-to-tail; "
+                                            "the large kernels agree with the rocprofv3 kernel trace under profiles/")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

@@ -221,6 +221,53 @@ def _run_inference(name, batch=3):
     print("wrote", f"{name}_b{batch}_infer", "n_boxes", list(n_boxes))
 
 
+def _matcher_cases(seed=5):
+    """Inputs for the evaluation-side matcher (bbox_mode='backbone'): per image a set of detector boxes (queries) and
+    ground-truth boxes -- jittered copies that overlap (GIoU above and below the 0.5 threshold), wrong-class detections,
+    spurious detections, an image without detections and one without targets."""
+    rng = np.random.default_rng(seed)
+    nq = 12
+    imgs = []
+    for n_t, n_d, jit, flip in ((5, 7, 0.02, 1), (8, 8, 0.10, 2), (3, 12, 0.25, 0), (0, 4, 0.0, 0), (6, 0, 0.0, 0), (9, 5, 0.05, 3)):
+        tb = np.concatenate([rng.uniform(0.2, 0.8, (n_t, 2)), rng.uniform(0.05, 0.3, (n_t, 2))], 1).astype(np.float32)
+        tl = rng.integers(1, 6, n_t).astype(np.int64)
+        k = min(n_t, n_d)
+        perm = rng.permutation(n_t)[:k]
+        db = tb[perm] + (rng.standard_normal((k, 4)) * jit * np.array([1, 1, 0.5, 0.5])).astype(np.float32)
+        db[:, 2:] = np.abs(db[:, 2:]) + 1e-3
+        dl = tl[perm].copy()
+        dl[:flip] = (dl[:flip] % 5) + 1                    # wrong class on the first `flip` detections
+        extra = n_d - k
+        db = np.concatenate([db, np.concatenate([rng.uniform(0.1, 0.9, (extra, 2)), rng.uniform(0.05, 0.3, (extra, 2))], 1)]).astype(np.float32)
+        dl = np.concatenate([dl, rng.integers(1, 6, extra)]).astype(np.int64)
+        order = rng.permutation(n_d)
+        pb = -np.ones((nq, 4), np.float32)
+        pc = -np.ones((nq,), np.int64)
+        pb[:n_d], pc[:n_d] = db[order], dl[order]
+        imgs.append(dict(pred_boxes=pb, pred_classes=pc, n_boxes=n_d, boxes=tb, labels=tl))
+    return imgs
+
+
+def _run_matcher():
+    """matcher.py:104-229 in 'backbone' mode (the mode pose_evaluate / bop_evaluate use, engine.py:127,212), both class modes."""
+    from models.matcher import PoseMatcher
+    imgs = _matcher_cases()
+    outputs = {"pred_boxes": torch.from_numpy(np.stack([i["pred_boxes"] for i in imgs])),
+               "pred_classes": torch.from_numpy(np.stack([i["pred_classes"] for i in imgs]))}
+    targets = [{"boxes": torch.from_numpy(i["boxes"]), "labels": torch.from_numpy(i["labels"])} for i in imgs]
+    n_boxes = [i["n_boxes"] for i in imgs]
+    rec = {"pred_boxes": outputs["pred_boxes"].numpy(), "pred_classes": outputs["pred_classes"].numpy(), "n_boxes": np.asarray(n_boxes),
+           "n_targets": np.asarray([len(i["boxes"]) for i in imgs]),
+           "tgt_boxes": np.concatenate([i["boxes"] for i in imgs]), "tgt_labels": np.concatenate([i["labels"] for i in imgs])}
+    for cm in ("specific", "agnostic"):
+        for thr in (0.5, 0.0):
+            res = PoseMatcher(bbox_mode="backbone", class_mode=cm)(outputs, targets, n_boxes, giou_thresh=thr)
+            flat = np.concatenate([np.stack([np.full(len(s), b), s.numpy(), t.numpy()], 1).reshape(-1, 3) for b, (s, t) in enumerate(res)]).astype(np.int64)
+            rec[f"match_{cm}_{int(thr * 10)}"] = flat
+            print("matcher", cm, thr, [len(s) for s, _ in res])
+    np.savez_compressed(os.path.join(GOLD, "matcher_backbone.npz"), **rec)
+
+
 def _small_units():
     from models.position_encoding import PositionEmbeddingSine, BoundingBoxEmbeddingSine
     from models.pose_estimation_transformer import PoET
@@ -277,6 +324,9 @@ def main():
     if not os.path.isdir(REF):
         raise SystemExit("gen_golden needs /root/reference (build container only)")
     _install_shims()
+    if "--matcher" in sys.argv:               # the evaluation-side matcher (bbox_mode='backbone')
+        _run_matcher()
+        return
     if "--infer" in sys.argv:                 # only the inference goldens (added after the training ones)
         _run_inference("tiny")
         _run_inference("cfg0")
@@ -322,6 +372,7 @@ def main():
     _run_model("tiny", 2, True, True, query_embedding_mode="learned", ref_points_mode="learned")
     _run_inference("tiny")
     _run_inference("cfg0")
+    _run_matcher()
     _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
     _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
     for rm, al in (("quat", False), ("silho_quat", False), ("6d", True)):

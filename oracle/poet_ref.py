@@ -517,13 +517,13 @@ class PoET(nn.Module):
 # models/matcher.py:104-229 PoseMatcher ('gt' mode) and pose_estimation_transformer.py:454-674
 # ----------------------------------------------------------------------------------------------
 class PoseMatcher(nn.Module):
-    def __init__(self, cost_bbox=1.0, cost_class=1.0, bbox_mode="gt"):
+    def __init__(self, cost_bbox=1.0, cost_class=1.0, bbox_mode="gt", class_mode="specific"):
         super().__init__()
-        assert bbox_mode in ("gt", "jitter")
-        self.cost_bbox, self.cost_class, self.bbox_mode = cost_bbox, cost_class, bbox_mode
+        assert bbox_mode in ("gt", "jitter", "backbone")
+        self.cost_bbox, self.cost_class, self.bbox_mode, self.class_mode = cost_bbox, cost_class, bbox_mode, class_mode
 
     @torch.no_grad()
-    def forward(self, outputs, targets, n_boxes):
+    def forward(self, outputs, targets, n_boxes, giou_thresh=0.5):
         from scipy.optimize import linear_sum_assignment
         bs, nq = outputs["pred_boxes"].shape[:2]
         out_bbox = outputs["pred_boxes"].flatten(0, 1)
@@ -533,13 +533,44 @@ class PoseMatcher(nn.Module):
         else:                               # matcher.py:175-181 ('jitter'): class equality only, 0 = same class
             out_class = outputs["pred_classes"].flatten(0, 1)
             tgt_class = torch.cat([t["labels"].type(torch.float32) for t in targets])
-            cost = (self.cost_class * torch.where(out_class[:, None] == tgt_class[None, :], 0.0, 1.0)).view(bs, nq, -1).cpu()
+            cost = self.cost_class * torch.where(out_class[:, None] == tgt_class[None, :], 0.0, 1.0)
+            if self.bbox_mode == "backbone":    # matcher.py:183-192: + L1 between the box CENTRES
+                cost = self.cost_bbox * torch.cdist(out_bbox[:, 0:2], tgt_bbox[:, 0:2], p=1) + cost
+            cost = cost.view(bs, nq, -1).cpu()
         sizes = [len(t["boxes"]) for t in targets]
         res = []
         for i, c in enumerate(cost.split(sizes, -1)):
             r, cidx = linear_sum_assignment(c[i][: n_boxes[i]])
             res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
+        if self.bbox_mode == "backbone":    # matcher.py:204-227: drop matches of the wrong class / with GIoU below the threshold
+            kept = []
+            for b, ((src, tgt), t) in enumerate(zip(res, targets)):
+                ob, oc = outputs["pred_boxes"][b, : n_boxes[b]], outputs["pred_classes"][b]
+                gious = generalized_box_iou(box_cxcywh_to_xyxy(ob), box_cxcywh_to_xyxy(t["boxes"]))
+                keep = [k for k, (i, j) in enumerate(zip(src.tolist(), tgt.tolist()))
+                        if not (self.class_mode == "specific" and oc[i] != t["labels"][j]) and not (gious[i, j] < giou_thresh)]
+                kept.append((src[keep], tgt[keep]))
+            res = kept
         return res
+
+
+def box_cxcywh_to_xyxy(x):
+    """util/box_ops.py:21-25."""
+    xc, yc, w, h = x.unbind(-1)
+    return torch.stack([xc - 0.5 * w, yc - 0.5 * h, xc + 0.5 * w, yc + 0.5 * h], dim=-1)
+
+
+def generalized_box_iou(b1, b2):
+    """util/box_ops.py:68-105 (xyxy boxes -> [N, M] GIoU)."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    wh = (torch.min(b1[:, None, 2:], b2[:, 2:]) - torch.max(b1[:, None, :2], b2[:, :2])).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    union = a1[:, None] + a2 - inter
+    iou = inter / union
+    wh = (torch.max(b1[:, None, 2:], b2[:, 2:]) - torch.min(b1[:, None, :2], b2[:, :2])).clamp(min=0)
+    area = wh[:, :, 0] * wh[:, :, 1]
+    return iou - (area - union) / area
 
 
 def acos_linear_extrapolation(x, lo, hi):

@@ -390,16 +390,18 @@ class PoseMatcher(nn.Module):
         linear_sum_assignment uses, same tie-breaking) and gathers the matched targets there too -- no SciPy call, no
         host-built index arrays between the forward and backward graphs.  forward() below stays the host path."""
         super().__init__()
-        if bbox_mode not in ("gt", "jitter"):
-            raise NotImplementedError("PoseMatcher: bbox_mode 'gt' and 'jitter' are implemented ('backbone' matching is evaluation-side)")
-        self.cost_bbox, self.cost_class, self.bbox_mode = cost_bbox, cost_class, bbox_mode
+        if bbox_mode not in ("gt", "jitter", "backbone"):
+            raise ValueError(f"PoseMatcher: unknown bbox_mode {bbox_mode!r}")
+        self.cost_bbox, self.cost_class, self.bbox_mode, self.class_mode = cost_bbox, cost_class, bbox_mode, class_mode
         self.device_assign = bool(device_assign) and bbox_mode == "gt"
         self._cache = (None, None)
 
     @torch.no_grad()
-    def forward(self, outputs, targets, n_boxes):
+    def forward(self, outputs, targets, n_boxes, giou_thresh=0.5):
         from scipy.optimize import linear_sum_assignment
         pb = outputs["pred_boxes"]
+        if self.bbox_mode == "backbone":
+            return self._forward_backbone(outputs, targets, n_boxes, giou_thresh)
         if self._cache[0] is pb:            # same boxes for every decoder layer: identical assignment
             return self._cache[1]
         bs, nq = pb.shape[:2]
@@ -435,6 +437,45 @@ class PoseMatcher(nn.Module):
             r, cidx = linear_sum_assignment(c)
             res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
         self._cache = (pb, res)
+        return res
+
+    def _forward_backbone(self, outputs, targets, n_boxes, giou_thresh):
+        """matcher.py:183-229, the mode pose_evaluate / bop_evaluate run (engine.py:127,212): the queries are detector boxes,
+        so the cost is the L1 distance of the box CENTRES plus 0 / 1 for equal / different class, and a match survives only
+        if the classes agree (class_mode 'specific') and the generalised IoU reaches `giou_thresh`.  Evaluation-side host
+        code: float32 numpy in the reference's operation order (same cost matrix, same SciPy solver, same GIoU rounding)."""
+        from scipy.optimize import linear_sum_assignment
+        from .modules import _to_host_list
+        pb = outputs["pred_boxes"].detach().cpu().numpy().astype(np.float32, copy=False)
+        pc = outputs["pred_classes"].detach().cpu().numpy()
+        tbl = _to_host_list([t["boxes"] for t in targets], np.float32)
+        tll = _to_host_list([t["labels"] for t in targets], np.int64)
+        f32 = np.float32
+
+        def xyxy(b):
+            return np.stack([b[:, 0] - f32(0.5) * b[:, 2], b[:, 1] - f32(0.5) * b[:, 3],
+                             b[:, 0] + f32(0.5) * b[:, 2], b[:, 1] + f32(0.5) * b[:, 3]], -1)
+
+        res = []
+        for b, (tb, tl) in enumerate(zip(tbl, tll)):
+            nb = int(n_boxes[b])
+            ob, oc = pb[b, :nb], np.asarray(pc[b])
+            tb, tl = np.asarray(tb, np.float32).reshape(-1, 4), np.asarray(tl).reshape(-1)
+            cost = f32(self.cost_bbox) * np.abs(ob[:, None, :2] - tb[None, :, :2]).sum(-1, dtype=np.float32) \
+                + f32(self.cost_class) * (oc[:nb, None].astype(np.float32) != tl[None, :].astype(np.float32)).astype(np.float32)
+            rows, cols = linear_sum_assignment(cost)
+            b1, b2 = xyxy(ob), xyxy(tb)
+            a1, a2 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1]), (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+            wh = np.clip(np.minimum(b1[:, None, 2:], b2[None, :, 2:]) - np.maximum(b1[:, None, :2], b2[None, :, :2]), 0, None)
+            inter = wh[..., 0] * wh[..., 1]
+            union = a1[:, None] + a2[None, :] - inter
+            wh = np.clip(np.maximum(b1[:, None, 2:], b2[None, :, 2:]) - np.minimum(b1[:, None, :2], b2[None, :, :2]), 0, None)
+            area = wh[..., 0] * wh[..., 1]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                giou = inter / union - (area - union) / area
+            keep = [k for k, (i, j) in enumerate(zip(rows, cols))
+                    if not (self.class_mode == "specific" and oc[i] != tl[j]) and not (giou[i, j] < giou_thresh)]
+            res.append((torch.as_tensor(rows[keep], dtype=torch.int64), torch.as_tensor(cols[keep], dtype=torch.int64)))
         return res
 
 
@@ -934,7 +975,10 @@ class GraphedTrainer(Trainer):
         crit = self.criterion
         self.graph_loss = bool(getattr(crit, "default_terms", False) and getattr(getattr(crit, "matcher", None), "device_assign", False)
                                and getattr(m, "bbox_mode", "gt") == "gt" and hasattr(crit, "total") and getattr(m, "aux_loss", True)
-                               and os.environ.get("POET_EAGER_LOSS", "0") in ("", "0"))
+                               and os.environ.get("POET_EAGER_LOSS", "0") in ("", "0")
+                               # poet_lsa_boxes solves <= 64 x 64 per image (targets per image <= Q in 'gt' mode); more queries take
+                               # the eager loss with the SciPy matcher instead of a captured kernel that would leave matches at -1
+                               and self.s_boxes.shape[1] <= 64)
         if self.graph_loss:
             N, Q = self.s_boxes.shape[:2]
             cap = N * Q

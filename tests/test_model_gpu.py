@@ -986,6 +986,45 @@ def test_inference_path_vs_reference_golden(gpu, golden_dir, name, precision, to
     assert dt < tol_t and dr < tol_r, (dt, dr)
 
 
+def test_eval_matcher_backbone_mode_on_device_outputs(gpu, golden_dir):
+    """The evaluation loop of engine.py:120-130 in 'backbone' mode on the HIP path: PoET(eval, detector rows on the GPU) ->
+    PoseMatcher(bbox_mode='backbone') with outputs AND targets living on the device (one batched D2H per field, SciPy +
+    class / GIoU filter on the host, matcher.py:183-229).  (a) the matcher golden of the real reference holds for device
+    tensors; (b) on the model's own outputs, targets that repeat the selected detections match one-to-one, a wrong label or
+    a far-away box removes exactly that match."""
+    import poet_amd
+    from oracle.formula import CONFIGS, make_predictions
+    g = np.load(os.path.join(golden_dir, "matcher_backbone.npz"))
+    outputs = {"pred_boxes": torch.from_numpy(g["pred_boxes"]).cuda(), "pred_classes": torch.from_numpy(g["pred_classes"]).cuda()}
+    nt = [int(x) for x in g["n_targets"]]
+    tb, tl = np.split(g["tgt_boxes"], np.cumsum(nt)[:-1]), np.split(g["tgt_labels"], np.cumsum(nt)[:-1])
+    targets = [{"boxes": torch.from_numpy(b.reshape(-1, 4)).cuda(), "labels": torch.from_numpy(l).cuda()} for b, l in zip(tb, tl)]
+    for cm in ("specific", "agnostic"):
+        res = poet_amd.PoseMatcher(bbox_mode="backbone", class_mode=cm)(outputs, targets, [int(x) for x in g["n_boxes"]])
+        flat = np.concatenate([np.stack([np.full(len(s), b), s.numpy(), t.numpy()], 1).reshape(-1, 3) for b, (s, t) in enumerate(res)])
+        np.testing.assert_array_equal(flat, g[f"match_{cm}_5"])
+    cfg = CONFIGS["tiny"]
+    preds = [None if p is None else p.cuda() for p in make_predictions(cfg, seed=77, batch=3)]
+    r = gpu("tiny", 3, False, "fp32", bbox_mode="backbone", predictions=preds)
+    r["model"].eval()
+    with torch.no_grad():
+        out, n_boxes = r["model"](r["samples"])
+    tg = []
+    for b, n in enumerate(n_boxes):
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(b)).cuda()
+        tg.append({"boxes": out["pred_boxes"][b, :n][perm].clone(), "labels": out["pred_classes"][b, :n][perm].long().clone()})
+    m = poet_amd.PoseMatcher(bbox_mode="backbone", class_mode="specific")
+    res = m({k: v for k, v in out.items() if k != "aux_outputs"}, tg, n_boxes)
+    for b, (src, tgt) in enumerate(res):
+        assert len(src) == n_boxes[b]
+        assert torch.equal(out["pred_boxes"][b, src.cuda()], tg[b]["boxes"][tgt.cuda()])
+    b0 = next(b for b, n in enumerate(n_boxes) if n >= 2)
+    tg[b0]["labels"][0] += 1                              # wrong class on one target, another moved out of reach
+    tg[b0]["boxes"][1, :2] += 0.9
+    res2 = m({k: v for k, v in out.items() if k != "aux_outputs"}, tg, n_boxes)
+    assert len(res2[b0][0]) == n_boxes[b0] - 2 and 0 not in res2[b0][1].tolist() and 1 not in res2[b0][1].tolist()
+
+
 def test_graphed_inference_matches_eager(gpu):
     """HIP-graph replay of the inference forward == the eager launch sequence, across calls whose detections change."""
     import poet_amd

@@ -201,3 +201,39 @@ def test_poet_rotation_modes_vs_reference(golden_dir, rotation_mode, aleatoric):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0
         else:
             np.testing.assert_allclose(checksum(p.grad), cs, rtol=2e-4, atol=2e-6 * max(1.0, abs(cs[0])), err_msg=str(n))
+
+
+def _matcher_inputs(g):
+    outputs = {"pred_boxes": torch.from_numpy(g["pred_boxes"]), "pred_classes": torch.from_numpy(g["pred_classes"])}
+    nt = [int(x) for x in g["n_targets"]]
+    tb, tl = np.split(g["tgt_boxes"], np.cumsum(nt)[:-1]), np.split(g["tgt_labels"], np.cumsum(nt)[:-1])
+    targets = [{"boxes": torch.from_numpy(b.reshape(-1, 4)), "labels": torch.from_numpy(l)} for b, l in zip(tb, tl)]
+    return outputs, targets, [int(x) for x in g["n_boxes"]]
+
+
+def _flat_matches(res):
+    rows = [np.stack([np.full(len(s), b), s.numpy(), t.numpy()], 1).reshape(-1, 3) for b, (s, t) in enumerate(res)]
+    return np.concatenate(rows).astype(np.int64)
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_matcher_backbone_mode_vs_reference(golden_dir, which):
+    """PoseMatcher(bbox_mode='backbone') -- centre-L1 + class cost, then the class / GIoU filter (matcher.py:183-229; called
+    by pose_evaluate / bop_evaluate, engine.py:127,212) -- against the imported reference's matches: jittered, wrong-class and
+    spurious detections, an image without detections, one without targets; both class modes, two thresholds.  The product's
+    matcher is host code (numpy + SciPy), so it is checked here on CPU tensors as well."""
+    g = _load(golden_dir, "matcher_backbone.npz")
+    outputs, targets, n_boxes = _matcher_inputs(g)
+    if which == "oracle":
+        cls = poet_ref.PoseMatcher
+    else:
+        import poet_amd
+        cls = poet_amd.PoseMatcher
+    total = 0
+    for cm in ("specific", "agnostic"):
+        for thr in (0.5, 0.0):
+            res = cls(bbox_mode="backbone", class_mode=cm)(outputs, targets, n_boxes, giou_thresh=thr)
+            want = g[f"match_{cm}_{int(thr * 10)}"]
+            np.testing.assert_array_equal(_flat_matches(res), want)
+            total += len(want)
+    assert total >= 20                       # the cases do exercise kept AND removed matches
