@@ -1240,6 +1240,368 @@ __global__ __launch_bounds__(WIN_NT, 2) void msda_win_kernel(const MsdaP p, cons
     }
 }
 
+// ====================================================================================================================
+// d(value) for GRID queries on the MATRIX cores: the scatter as a sparse-as-dense product (bf16 storage, D = 16, P = 4).
+// Same workgroup = (spatial tile, head, image) with int32 fixed-point LDS windows as msda_bwd_dv_tiled_kernel above, but
+//   * ONE LANE OWNS ONE QUERY: its softmax, its 16 sample points and their corner weights are plain per-lane arithmetic on
+//     registers it loaded itself (10 x 16-byte loads) -- no DPP softmax, no per-point lanes, no broadcast chain; the sample
+//     geometry costs ~40 instructions per point for 64 queries at once instead of ~150 per 4 queries;
+//   * a wave works on an 8 x 8 block of queries = four 4 x 4 SUB-BLOCKS of 16 queries.  For one (level, point) the 16 samples
+//     of a sub-block fall into a few adjacent pixels, so the sub-block's contribution is a small dense product
+//         dV[8 x 8 pixel tile, 16 channels] = Wt[64 pixels, 16 queries] x G[16 queries, 16 channels]
+//     with Wt = bilinear corner weight x attention weight (4 nonzeros per column, written as fp16 by the owning lanes into a
+//     2 KB LDS tile, origin = the sub-block's first sample - margin) and G = the queries' grad_out rows (bf16 x 2^k: exact in
+//     fp16).  It runs as up to four v_mfma_f32_16x16x16_f16 (only the 2-row pixel strips some sample touches), and the 16 x 16
+//     fp32 result tiles are added into the int32 window: one v_cvt + one ds_add_u32 per (pixel, channel) of the strip instead
+//     of 2.5 half-rate VALU + one ds_add per (corner, channel) of every sample;
+//   * samples that do not fit their sub-block's tile (coarse-level queries sampling a fine level: 2 .. 8 px apart; learned
+//     offsets that scatter) or that leave the window take a per-lane path: the lane adds its 16 channels itself (LDS atomics
+//     inside the window, global atomics for in-image pixels outside it), so the result never depends on tile or halo.
+constexpr int MF_NW = 8, MF_NT = MF_NW * 64;
+constexpr int MF_TPX = 64;                                   // W tile of a sub-block: 8 rows x 8 pixels
+constexpr int MF_WT_BYTES = MF_TPX * 16 * 2;                 // [pixel][16 queries] fp16
+constexpr int MF_PAD = 8;                                    // pad pixels in front of / behind the windows (a strip may start 7 px left of a row)
+constexpr int MF_HDR = 80;                                   // ints in front of the pad (uniform tables, see the kernel)
+
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef short mf_v4s_t __attribute__((ext_vector_type(4)));
+typedef uint32_t mf_u32x16_t __attribute__((ext_vector_type(16)));
+typedef float mf_f32x16_t __attribute__((ext_vector_type(16)));
+typedef float mf_f32x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) mf_v4s_t mf_lds_v4s_t;
+
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+
+template <typename TQ, int L>
+__global__ __launch_bounds__(MF_NT) void msda_bwd_dv_mfma_kernel(const MsdaP p, const TileP tp) {
+    static_assert(sizeof(TQ) == 2, "bf16 storage only");
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr int P = 4, D = 16, LP = L * P;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m = blockIdx.y, n = blockIdx.z;
+    // header (ints): [0] next block, [1] number of blocks, [4 .. 4 + MF_NW) reduction scratch,
+    // [16 + 8 l ..) level l: W, H, start, window x0, y0, width, height, first pixel; [48 + 8 l ..) its query rectangle: x0, y0, w, h,
+    // 8-blocks per row, first block.  (Uniform values read back through LDS + v_readfirstlane where they are used: kept live in
+    // SGPRs across the block loop, the ~60 of them push the kernel into scratch memory.)
+    int* hdr = smem;
+    int* win = smem + MF_HDR;                                // pixel x of the allocation = win[16 x .. 16 x + 16)
+    auto U = [&](int i) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(hdr[i]); };
+    int win_px;
+    {
+        int lo = MF_PAD, cb = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int W = p.W[l], H = p.H[l];
+            const int ax = max((tx * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((tx + 1) * W, tp.TX) + tp.HALO, W);
+            const int ay = max((ty * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((ty + 1) * H, tp.TY) + tp.HALO, H);
+            const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
+            const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
+            const int qw = qx1 - qx0, qh = qy1 - qy0, nbx = max((qw + 7) >> 3, 1);
+            if (tid == 0) {
+                int* t = hdr + 16 + 8 * l;
+                t[0] = W; t[1] = H; t[2] = p.start[l]; t[3] = ax; t[4] = ay; t[5] = bx - ax; t[6] = by - ay; t[7] = lo;
+                int* r = hdr + 48 + 8 * l;
+                r[0] = qx0; r[1] = qy0; r[2] = qw; r[3] = qh; r[4] = nbx; r[5] = cb;
+            }
+            lo += (bx - ax) * (by - ay);
+            cb += (qw > 0 && qh > 0) ? nbx * ((qh + 7) >> 3) : 0;
+        }
+        if (tid == 0) { hdr[0] = 0; hdr[1] = cb; hdr[2] = lo; }
+        win_px = lo + MF_PAD;
+    }
+    char* const wt = reinterpret_cast<char*>(win + win_px * D) + wid * MF_WT_BYTES;     // this wave's W tile (all zero between uses)
+    {
+        int4* w4 = reinterpret_cast<int4*>(win);
+        const int n4 = win_px * (D / 4) + MF_NW * (MF_WT_BYTES / 16);
+        for (int i = tid; i < n4; i += MF_NT) w4[i] = make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const int row0 = n * p.Lq;
+    const uint32_t g_row = (uint32_t)(p.M * D) * 2u, q_row = (uint32_t)p.ldq * 2u;
+
+    // pass 1: max |grad_out| over this tile's queries -> power-of-two scale (lanes = [query slot][channel], coalesced 32-byte pieces)
+    float gm = (tp.skip & 1) ? 4.f : 0.f;
+    {
+        const int c = tid & 15, slot = tid >> 4;
+        constexpr int NSLOT = MF_NT / 16;
+        const uint32_t g_lane = (uint32_t)(m * D + c) * 2u;
+#pragma unroll 1
+        for (int lq = 0; lq < ((tp.skip & 1) ? 0 : L); ++lq) {
+            const int W = U(16 + 8 * lq), qw = U(48 + 8 * lq + 2), nq = qw * U(48 + 8 * lq + 3);
+            const float inv_qw = 1.f / (float)max(qw, 1);
+            const int qbase = row0 + U(16 + 8 * lq + 2) + U(48 + 8 * lq + 1) * W + U(48 + 8 * lq);
+            auto g_of = [&](int i) __attribute__((always_inline)) {
+                const int iy = idiv_small(i, qw, inv_qw);
+                return fabsf(bf2f(ldg32<TQ>(p.grad_out, (uint32_t)(qbase + iy * W + (i - iy * qw)) * g_row + g_lane)));
+            };
+            int i = slot;
+            for (; i + 3 * NSLOT < nq; i += 4 * NSLOT) {
+                const float g0 = g_of(i), g1 = g_of(i + NSLOT), g2 = g_of(i + 2 * NSLOT), g3 = g_of(i + 3 * NSLOT);
+                gm = fmaxf(fmaxf(gm, fmaxf(g0, g1)), fmaxf(g2, g3));
+            }
+            for (; i < nq; i += NSLOT) gm = fmaxf(gm, g_of(i));
+        }
+    }
+    gm = wave_max(gm);
+    if (lane == 0) reinterpret_cast<float*>(hdr)[4 + wid] = gm;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < MF_NW; ++w) gm = fmaxf(gm, reinterpret_cast<float*>(hdr)[4 + w]);
+    if (!(gm > 0.f) || !(gm < 3.0e38f)) return;               // nothing to scatter (uniform across the workgroup)
+    int ex;
+    (void)frexpf(gm, &ex);                                    // gm in [2^(ex-1), 2^ex)
+    // window fixed point: w g 2^(18-ex) per contribution, as in the tiled kernel.  Split: G' = g 2^(15-ex) (|G'| < 2^15: fp16), W' = 8 w
+    const float gscale = ldexpf(1.f, 15 - ex), inv = ldexpf(1.f, ex - 18);
+    const int nblk = (tp.skip & 2) ? 0 : U(1);
+
+    const int sbl = lane >> 4, j16 = lane & 15;               // sub-block of the lane, its query inside it
+    const int jx = (j16 & 3) + ((sbl & 1) << 2), jy = (j16 >> 2) + ((sbl >> 1) << 2);      // position in the 8 x 8 block
+    float* gvb = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m;
+    bf16_t* gvb16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m;       // (gv_bf16)
+    // read addresses of the MFMA operands in the wave's tile: A = Wt rows (pixel = lane & 15 of the strip, 4 queries of k-group lane >> 4)
+    const int a_rd = (lane & 15) * 32 + (lane >> 4) * 8;
+    // transposing read of the staged grad_out rows [query][channel]: source lane r of 16-lane block b points at row 4 b + (r >> 2), piece r & 3
+    const int g_rd = ((lane >> 4) * 4 + (j16 >> 2)) * 32 + (j16 & 3) * 8;
+
+#pragma unroll 1
+    for (;;) {
+        int blk = 0;
+        if (lane == 0) blk = atomicAdd(&hdr[0], 1);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+        if (blk >= nblk) break;
+        int lq = 0;                                            // the LAST non-empty level whose first block is <= blk
+#pragma unroll
+        for (int l = 1; l < L; ++l) if (blk >= U(48 + 8 * l + 5) && U(48 + 8 * l + 2) > 0 && U(48 + 8 * l + 3) > 0) lq = l;
+        const int* rq = hdr + 48 + 8 * lq;
+        const int rx0 = __builtin_amdgcn_readfirstlane(rq[0]), ry0 = __builtin_amdgcn_readfirstlane(rq[1]), rw = __builtin_amdgcn_readfirstlane(rq[2]),
+                  rh = __builtin_amdgcn_readfirstlane(rq[3]), nbx = __builtin_amdgcn_readfirstlane(rq[4]), bl = blk - __builtin_amdgcn_readfirstlane(rq[5]);
+        const int Wq = U(16 + 8 * lq), startq = U(16 + 8 * lq + 2);
+        const int by = bl / nbx, bx = bl - by * nbx;
+        const int qxl = bx * 8 + jx, qyl = by * 8 + jy;       // inside the tile's rectangle of level lq
+        const bool active = qxl < rw && qyl < rh && (!(tp.skip & 64) || sbl == ((tp.skip >> 8) & 3));     // (skip bit 64: debugging aid, one sub-block only)
+        const int q = startq + (ry0 + (active ? qyl : 0)) * Wq + rx0 + (active ? qxl : 0);
+        const uint32_t row = (uint32_t)(row0 + q);
+
+        // ---- this lane's operands: 16 bytes of offsets and 8 of logits per level, 32 of grad_out, the reference points ----
+        // (LLVM vectors, not C arrays: the level loop below is ROLLED -- unrolled, the kernel is 50 KB of code -- and indexes them with
+        // the wave-uniform level number, which the backend turns into v_movrels; a C array would go to scratch memory)
+        mf_u32x16_t ofv;
+        mf_f32x16_t a;
+        mf_f32x8_t rfv;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const uint4 o = ldg32<uint4>(p.q1, row * q_row + (uint32_t)((m * LP + l * P) * 2) * 2u);
+            const uint2 g = ldg32<uint2>(p.q1, row * q_row + (uint32_t)(p.logit_col + m * LP + l * P) * 2u);
+            const float2 r = ldg32<float2>(p.ref, (uint32_t)(n * p.ref_bs + (q * L + l) * 2) * 4u);
+            ofv[4 * l] = o.x; ofv[4 * l + 1] = o.y; ofv[4 * l + 2] = o.z; ofv[4 * l + 3] = o.w;
+            a[4 * l] = bf_lo(g.x); a[4 * l + 1] = bf_hi(g.x); a[4 * l + 2] = bf_lo(g.y); a[4 * l + 3] = bf_hi(g.y);
+            rfv[2 * l] = r.x; rfv[2 * l + 1] = r.y;
+        }
+        const uint4 gv0 = ldg32<uint4>(p.grad_out, row * g_row + (uint32_t)(m * D) * 2u);
+        const uint4 gv1 = ldg32<uint4>(p.grad_out, row * g_row + (uint32_t)(m * D + 8) * 2u);
+
+        // grad_out row -> fp16 x 2^(15-ex) (exact: 8 significant bits), staged [query][channel] in the (all-zero) W tile, read back
+        // TRANSPOSED as the four sub-blocks' MFMA B operands (B[k = query][n = channel]: 4 consecutive queries of one channel per lane)
+        const float gs_ = active ? gscale : 0.f;
+        f16x2_t gh[8];
+        {
+            const uint32_t gw[8] = {gv0.x, gv0.y, gv0.z, gv0.w, gv1.x, gv1.y, gv1.z, gv1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gh[i] = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz(bf_lo(gw[i]) * gs_, bf_hi(gw[i]) * gs_));
+            uint4* st = reinterpret_cast<uint4*>(wt + lane * 32);
+            st[0] = make_uint4(__builtin_bit_cast(uint32_t, gh[0]), __builtin_bit_cast(uint32_t, gh[1]), __builtin_bit_cast(uint32_t, gh[2]), __builtin_bit_cast(uint32_t, gh[3]));
+            st[1] = make_uint4(__builtin_bit_cast(uint32_t, gh[4]), __builtin_bit_cast(uint32_t, gh[5]), __builtin_bit_cast(uint32_t, gh[6]), __builtin_bit_cast(uint32_t, gh[7]));
+        }
+        asm volatile("" ::: "memory");
+        // (scalars, not an array: selecting Bf[s] by the run-time sub-block index would pin an array in scratch memory)
+        const uint2 B0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 0 * 512 + g_rd)));
+        const uint2 B1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 1 * 512 + g_rd)));
+        const uint2 B2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 2 * 512 + g_rd)));
+        const uint2 B3 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 3 * 512 + g_rd)));
+        asm volatile("" ::: "memory");
+        {
+            uint4* st = reinterpret_cast<uint4*>(wt + lane * 32);
+            st[0] = make_uint4(0, 0, 0, 0);
+            st[1] = make_uint4(0, 0, 0, 0);
+        }
+
+        // softmax over the (query, head)'s L*P logits, x 8 (the W' scale), 0 for lanes without a query
+        {
+            float mx = a[0];
+#pragma unroll
+            for (int i = 1; i < LP; ++i) mx = fmaxf(mx, a[i]);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < LP; ++i) { a[i] = __expf(a[i] - mx); s += a[i]; }
+            const float r = active ? 8.f * __builtin_amdgcn_rcpf(s) : 0.f;
+#pragma unroll
+            for (int i = 0; i < LP; ++i) a[i] *= r;
+        }
+
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) {
+            const int Wl = U(16 + 8 * l), Hl = U(16 + 8 * l + 1), startl = U(16 + 8 * l + 2);
+            const float WlF = (float)Wl, HlF = (float)Hl;
+            const int lwx0 = U(16 + 8 * l + 3), lwy0 = U(16 + 8 * l + 4), lww = U(16 + 8 * l + 5), lwh = U(16 + 8 * l + 6), lo = U(16 + 8 * l + 7);
+            // queries of a coarser level sit 2 .. 8 px apart at this one: a 4 x 4 sub-block then spans >= 7 px, no margin to give
+            const int margin = (l >= lq) ? 2 : 0;
+            // per-lane part of a result strip's window address: strip rows 2 t + (lane >> 5), pixel ((lane >> 4) & 1) * 4 + r, channel lane & 15
+            const int lc = (((lane >> 5) * lww + ((lane >> 4) & 1) * 4) << 6) + (lane & 15) * 4;
+            const float bxf = fmaf(rfv[2 * l], WlF, -0.5f), byf = fmaf(rfv[2 * l + 1], HlF, -0.5f);
+#pragma unroll 1
+            for (int pt = 0; pt < P; ++pt) {
+                const float aj = a[4 * l + pt];
+                const uint32_t ofw = ofv[4 * l + pt];
+                const float px = bxf + bf_lo(ofw), py = byf + bf_hi(ofw);
+                const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
+                const int x0 = (int)x0f, y0 = (int)y0f;         // v_cvt saturates; every use below is an unsigned range test
+                const int lx0 = x0 - lwx0, ly0 = y0 - lwy0;
+                const bool wxi0 = (unsigned)lx0 < (unsigned)lww, wxi1 = (unsigned)(lx0 + 1) < (unsigned)lww;
+                const bool wyi0 = (unsigned)ly0 < (unsigned)lwh, wyi1 = (unsigned)(ly0 + 1) < (unsigned)lwh;
+                const bool ixi0 = (unsigned)x0 < (unsigned)Wl, ixi1 = (unsigned)(x0 + 1) < (unsigned)Wl;
+                const bool iyi0 = (unsigned)y0 < (unsigned)Hl, iyi1 = (unsigned)(y0 + 1) < (unsigned)Hl;
+                // a corner inside the image but outside the window (the windows are clipped to the image: in-window implies in-image)
+                const bool far = (((ixi0 && !wxi0) || (ixi1 && !wxi1)) && (iyi0 || iyi1)) || (((iyi0 && !wyi0) || (iyi1 && !wyi1)) && (ixi0 || ixi1));
+                const bool anyw = (wxi0 || wxi1) && (wyi0 || wyi1);
+                const float wx_0 = wxi0 ? 1.f - fx : 0.f, wx_1 = wxi1 ? fx : 0.f;
+                const float wy_0 = wyi0 ? (1.f - fy) * aj : 0.f, wy_1 = wyi1 ? fy * aj : 0.f;
+                // tile coordinates relative to the sub-block's first sample (its lane 0, broadcast within the 16-lane DPP row)
+                // (the broadcasts are made opaque: folded into the subtraction as v_subrev_u32_dpp the difference came out NEGATED on
+                // gfx950 / ROCm 7.2 -- found with the W-tile dump of profiles/probes/dv_mfma_dbg2.py)
+                int fx0 = row_bcast<0>(lx0), fy0 = row_bcast<0>(ly0);
+                asm volatile("" : "+v"(fx0), "+v"(fy0));
+                const int tcx = lx0 - fx0 + margin, tcy = ly0 - fy0 + margin;
+                const bool fit = active && !far && (unsigned)tcx <= 6u && (unsigned)tcy <= 6u && !(tp.skip & 8);      // (skip bit 8: debugging aid, every sample on the per-lane path)
+                const bool slow = active && !fit && (far || anyw);
+                const int wofs = ((tcy * 8 + tcx) * 16 + j16) * 2;
+                const _Float16 h00 = (_Float16)(wy_0 * wx_0), h01 = (_Float16)(wy_0 * wx_1), h10 = (_Float16)(wy_1 * wx_0), h11 = (_Float16)(wy_1 * wx_1);
+                // 2-row strips (of 16 tile pixels) some fitting sample touches, per sub-block: bits 16 s .. 16 s + 15 of the ballots
+                const unsigned long long bt0 = __ballot(fit && tcy <= 1), bt1 = __ballot(fit && tcy >= 1 && tcy <= 3),
+                                         bt2 = __ballot(fit && tcy >= 3 && tcy <= 5), bt3 = __ballot(fit && tcy >= 5);
+                if (bt0 | bt1 | bt2 | bt3) {
+                    // window pixel of the tile origin, per sub-block (uniform): origin = first sample - margin
+                    const int org = lo + (fy0 - margin) * lww + fx0 - margin;
+                    const int orow = fy0 - margin;
+#pragma unroll 1
+                    for (int s = 0; s < 4; ++s) {
+                        const unsigned m0 = (unsigned)(bt0 >> (16 * s)) & 0xffffu, m1 = (unsigned)(bt1 >> (16 * s)) & 0xffffu,
+                                       m2 = (unsigned)(bt2 >> (16 * s)) & 0xffffu, m3 = (unsigned)(bt3 >> (16 * s)) & 0xffffu;
+                        if (!(m0 | m1 | m2 | m3)) continue;
+                        const bool mine = fit && sbl == s;
+                        if (tp.skip & 32) {          // (debug: the two lanes of a dword write in separate instructions)
+                            if (mine && !(lane & 1)) { _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs); wp[0] = h00; wp[16] = h01; wp[128] = h10; wp[144] = h11; }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if (mine && (lane & 1)) { _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs); wp[0] = h00; wp[16] = h01; wp[128] = h10; wp[144] = h11; }
+                        } else
+                        if (mine) {
+                            _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs);
+                            wp[0] = h00; wp[16] = h01; wp[128] = h10; wp[144] = h11;
+                        }
+                        if (tp.skip & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if ((tp.skip & 128) && blockIdx.x == 0 && m == 0 && n == 0) {       // (debug: dump the W tile of (l, pt, s) = (0, 0, skip >> 8))
+                            if (l == 0 && pt == 0 && s == ((tp.skip >> 8) & 3) && blk == 0) {
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                for (int i = lane; i < 1024; i += 64) p.grad_value[i] = (float)reinterpret_cast<const _Float16*>(wt)[i];
+                                p.grad_value[1024 + lane] = (float)(fit ? 1 : 0) + 2.f * (float)tcx + 32.f * (float)tcy + 1024.f * (mine ? 1.f : 0.f);
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                        const uint32_t bsx = s == 0 ? B0.x : s == 1 ? B1.x : s == 2 ? B2.x : B3.x, bsy = s == 0 ? B0.y : s == 1 ? B1.y : s == 2 ? B2.y : B3.y;
+                        const f16x4_t Bs = __builtin_bit_cast(f16x4_t, make_uint2(bsx, bsy));
+                        const int sorg = __builtin_amdgcn_readlane(org, s * 16), srow = __builtin_amdgcn_readlane(orow, s * 16);
+                        const unsigned ms[4] = {m0, m1, m2, m3};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (!ms[t]) continue;
+                            const f16x4_t A = *reinterpret_cast<const f16x4_t*>(wt + t * 512 + a_rd);
+                            const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x16f16(A, Bs, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            const int rr = srow + 2 * t + (lane >> 5);
+                            if ((unsigned)rr < (unsigned)lwh) {
+                                int* ap = reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (((sorg + 2 * t * lww) << 6) + lc));
+                                // (compiler-visible conversions: the hazard recogniser does not look inside inline assembly, and a v_cvt_rpi
+                                // placed right behind the MFMA would read its result registers before the matrix pipe has written them)
+                                atomicAdd(ap, __float2int_rn(d[0]));
+                                atomicAdd(ap + 16, __float2int_rn(d[1]));
+                                atomicAdd(ap + 32, __float2int_rn(d[2]));
+                                atomicAdd(ap + 48, __float2int_rn(d[3]));
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                        if (mine) {
+                            _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs);
+                            wp[0] = (_Float16)0.f; wp[16] = (_Float16)0.f; wp[128] = (_Float16)0.f; wp[144] = (_Float16)0.f;
+                        }
+                    }
+                }
+                if (__ballot(slow)) {
+                    if (slow) {
+                        // the lane adds its sample itself: 16 channels x the corners that lie in the image
+                        const int wb = lo + ly0 * lww + lx0, gp0 = startl + y0 * Wl + x0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool inw = ((k & 1) ? wxi1 : wxi0) && ((k >> 1) ? wyi1 : wyi0);
+                            const bool inimg = ((k & 1) ? ixi1 : ixi0) && ((k >> 1) ? iyi1 : iyi0);
+                            const float wk = ((k >> 1) ? fy : 1.f - fy) * ((k & 1) ? fx : 1.f - fx) * aj;
+                            if (inw) {
+                                int* ap = win + (wb + (k & 1) + (k >> 1) * lww) * D;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    atomicAdd(ap + 2 * i, cvt_rpi(wk * (float)gh[i][0]));
+                                    atomicAdd(ap + 2 * i + 1, cvt_rpi(wk * (float)gh[i][1]));
+                                }
+                            } else if (inimg) {
+                                const int64_t pe = (int64_t)(gp0 + (k & 1) + (k >> 1) * Wl) * p.gs_s;
+                                const float wi = wk * inv;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    if (p.gv_bf16) gv16_add2(gvb16 + pe + 2 * i, wi * (float)gh[i][0], wi * (float)gh[i][1]);
+                                    else { atomicAdd(gvb + pe + 2 * i, wi * (float)gh[i][0]); atomicAdd(gvb + pe + 2 * i + 1, wi * (float)gh[i][1]); }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tp.skip & 4) return;
+    // flush (as in the tiled kernel): one coalesced pass per level, packed bf16x2 or fp32 memory-side atomics for the nonzero words
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const int W = U(16 + 8 * l), start = U(16 + 8 * l + 2), ax = U(16 + 8 * l + 3), ay = U(16 + 8 * l + 4), wpf = U(16 + 8 * l + 5),
+                  lofff = U(16 + 8 * l + 7);
+        const int cnt = wpf * U(16 + 8 * l + 6) * D;
+        const float inv_wp = 1.f / (float)wpf;
+        if (p.gv_bf16) {
+            bf16_t* gl16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + (int64_t)start * p.gs_s;
+            const int2* w2 = reinterpret_cast<const int2*>(win + lofff * D);
+            for (int i = tid; i < (cnt >> 1); i += MF_NT) {
+                const int2 v = w2[i];
+                if (v.x | v.y) {
+                    const int cc = (i & 7) * 2, pix = i >> 3;
+                    const int py = idiv_small(pix, wpf, inv_wp);
+                    const int xx = ax + pix - py * wpf, yy = ay + py;
+                    gv16_add2(gl16 + (int64_t)(yy * W + xx) * p.gs_s + cc, (float)v.x * inv, (float)v.y * inv);
+                }
+            }
+        } else {
+            float* gl = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + (int64_t)start * p.gs_s;
+            for (int i = tid; i < cnt; i += MF_NT) {
+                const int v = win[lofff * D + i];
+                if (v != 0) {
+                    const int cc = i & 15, pix = i >> 4;
+                    const int py = idiv_small(pix, wpf, inv_wp);
+                    const int xx = ax + pix - py * wpf, yy = ay + py;
+                    atomicAdd(gl + (int64_t)(yy * W + xx) * p.gs_s + cc, (float)v * inv);
+                }
+            }
+        }
+    }
+}
+
 // host: pick the tile grid / halo so the windows fit the LDS budget; returns window PIXELS of the largest tile (0 = no plan).
 // px_budget: pixels that fit; extra_px: pixels reserved behind the windows.
 // int32 windows of one workgroup (dynamic LDS; + pad / dummy pixels and a few static words: under the CU's 160 KB)
@@ -1371,12 +1733,46 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
     }
 }
 
+// The matrix-core scatter (opt-in while it is being measured: POET_DV_MFMA=1).  Windows + pads + a 2 KB tile per wave must fit.
+template <typename TQ, int L>
+static bool launch_dv_mfma(const MsdaP& p, int P, hipStream_t st) {
+    if constexpr (sizeof(TQ) != 2) return false;
+    else {
+    { const char* e = getenv("POET_DV_MFMA"); if (!(e && atoi(e))) return false; }
+    if (P != 4 || p.D != 16) return false;
+    const int64_t rows = (int64_t)p.N * p.Lq;
+    if (rows * p.M * p.D * 2 >= (1ll << 32) || rows * p.ldq * 2 >= (1ll << 32) || (p.ldq & 7) || (p.logit_col & 3) ||
+        ((int64_t)(p.N - 1) * p.ref_bs + (int64_t)p.Lq * L * 2) * 4 >= (1ll << 32) || (p.ref_bs & 1)) return false;
+    TileP tp{};
+    static const int halos[3] = {5, 4, 2};
+    const size_t budget = (size_t)POET_DV_LDS_BYTES - MF_HDR * 4 - (size_t)MF_NW * MF_WT_BYTES;
+    size_t px = 0;
+    if (const char* e = getenv("POET_DV_TILES")) {               // experiment: "TX,TY,HALO" (ignored when it does not fit)
+        int tx = 0, ty = 0, halo = 0;
+        if (sscanf(e, "%d,%d,%d", &tx, &ty, &halo) == 3 && tx > 0 && ty > 0 && halo >= 0) {
+            const size_t w = tile_footprint(p, L, tx, ty, halo, nullptr);
+            if (w + 2 * MF_PAD <= budget / 64) { tp.TX = tx; tp.TY = ty; tp.HALO = halo; px = w + 2 * MF_PAD; }
+        }
+    }
+    if (!px) px = plan_tiles_px(p, L, tp, budget / 64, 2 * MF_PAD, halos, 3);
+    if (!px) return false;
+    { const char* e = getenv("POET_DV_SKIP"); tp.skip = e ? atoi(e) : 0; }
+    const size_t lds = MF_HDR * 4 + px * 64 + (size_t)MF_NW * MF_WT_BYTES;
+    auto kern = msda_bwd_dv_mfma_kernel<TQ, L>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(MF_NT), lds, st, p, tp);
+    return true;
+    }
+}
+
 template <typename TV, typename TQ, int L, bool FUSED, bool BWD>
 static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     dim3 grid(cdiv(p.total, 256)), block(256);
     dim3 gridv(cdiv(p.total * 8, 256)), gridf(cdiv(p.total * 2, 256));
     bool dv_done = !(p.parts & 2);
     if constexpr (BWD && FUSED) {
+        if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_mfma<TQ, L>(p, P, st);
         if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
     }
     if (BWD && !dv_done) {
