@@ -50,11 +50,15 @@
 extern "C" {
 #endif
 
-#define POET_ABI_VERSION 2
+#define POET_ABI_VERSION 3
 #define POET_SQNORM_SCRATCH 1024
 
 #define POET_F32 0
 #define POET_BF16 1
+#define POET_F16 2   /* IEEE half STORAGE (11 significant bits in the same 2 bytes as bf16's 8): accepted only as the q_dtype of
+                        poet_msda_fused_fwd / _bwd -- the sampling offsets and attention logits, values of a few units that no GEMM
+                        ever reads as an operand -- produced by poet_gemm with c_dtype = POET_BF16 and c_f16 = 1.  Gradients of
+                        such a buffer are bf16. */
 
 #define POET_OK 0
 #define POET_ERR_ARG (-1)
@@ -115,7 +119,8 @@ typedef struct PoetGemmDesc {
                               the activation operand stays plain bf16 (needs b_dtype f32, compute bf16, b_kmajor 0).  Weight
                               rounding is the same perturbation for every token and does not average out downstream the way
                               per-token activation rounding does: DESIGN.md section 3. */
-    int32_t reserved0;
+    int32_t c_f16;         /* 1 with c_dtype = POET_BF16: the 2-byte outputs are written as IEEE fp16 instead of bfloat16 (plain or
+                              head-major stores; no add_src / gate_ref).  Was reserved0 (= 0) up to ABI version 2. */
     void* workspace;       /* optional scratch owned by the caller (16-byte aligned); used by the weight-gradient form to merge its
                               partial tiles with plain stores + one reduction launch instead of fp32 atomics.  Contents are
                               undefined afterwards; calls sharing it must be ordered on one stream. */
@@ -277,6 +282,12 @@ int poet_zero_masked_rows(void* x, int64_t ld, const uint8_t* row_mask, int64_t 
 /* NCHW (N,C,H,W) <-> token-major rows [tok_off, tok_off+H*W) of (N, tok_stride, C). */
 int poet_nchw_to_tokens(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
                         int src_dtype, int dst_dtype, void* stream);
+/* src (N,C,HW) fp32 -> dst (N*HW, 2 C) bf16 rows [hi | lo], hi = bf16(x), lo = bf16(x - hi): the input projection's activation
+ * operand with 16 significant bits -- [hi | lo] [W | W]^T = x W^T as one product with K = 2 C (models/pose_estimation_transformer.py
+ * :100-135: the 1x1 input_proj convolutions read the backbone's fp32 maps). */
+int poet_nchw_to_tokens_split(const float* src, void* dst, int N, int C, int HW, void* stream);
+/* the same split of a row-major fp32 matrix: src (rows, K) -> dst (rows, 2 K) bf16 [hi | lo] */
+int poet_split_rows(const float* src, void* dst, int64_t rows, int K, void* stream);
 int poet_tokens_to_nchw(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride,
                         int src_dtype, int dst_dtype, void* stream);
 /* im2col for the 3x3 stride-2 pad-1 conv of the extra level: src NCHW -> (N*Ho*Wo, C*9) with

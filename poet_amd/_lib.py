@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpoet_hip.so")
-ABI_VERSION = 2                                # POET_ABI_VERSION of include/poet_hip.h this binding was written against
+ABI_VERSION = 3                                # POET_ABI_VERSION of include/poet_hip.h this binding was written against
 
 F32, BF16 = 0, 1
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int32), ("atomic", C.c_int32), ("act", C.c_int32),
         ("alpha", f32), ("gate_scale", f32), ("drop_p", f32), ("seed", u32),
         ("out_mode", C.c_int32), ("hm_M", C.c_int32), ("hm_S", C.c_int32), ("hm_D", C.c_int32),
-        ("seed_dev", vp), ("b_split", C.c_int32), ("reserved0", C.c_int32), ("workspace", vp), ("workspace_bytes", i64),
+        ("seed_dev", vp), ("b_split", C.c_int32), ("c_f16", C.c_int32), ("workspace", vp), ("workspace_bytes", i64),
         ("B_lo", vp),
     ]
 
@@ -60,6 +60,8 @@ _PROTOS = {
     "poet_vgrad_to_rows": ([vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_zero_masked_rows": ([vp, i64, vp, i64, i32, i32, vp], i32),
     "poet_nchw_to_tokens": ([vp, vp, i32, i32, i32, i64, i64, i32, i32, vp], i32),
+    "poet_nchw_to_tokens_split": ([vp, vp, i32, i32, i32, vp], i32),
+    "poet_split_rows": ([vp, vp, i64, i32, vp], i32),
     "poet_tokens_to_nchw": ([vp, vp, i32, i32, i32, i64, i64, i32, i32, vp], i32),
     "poet_im2col3x3s2": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_groupnorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, i32, vp, i64, vp], i32),

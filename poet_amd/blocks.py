@@ -118,7 +118,11 @@ def _pair(so_w, like):
 def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P, act=None, split=False, grid_queries=False):
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
-    OA = empty((rows, ldq), act or q2d.dtype, q2d)
+    odt = act or q2d.dtype
+    # offsets | logits in fp16 where their readers take it (ops.oa_f16): the sampling offsets are the largest single rounding site of
+    # the bf16 policy (1/32 px at |offset| ~ 4), fp16 stores them 8x finer in the same bytes
+    oa16 = odt == torch.bfloat16 and V.dtype == torch.bfloat16 and ops.oa_f16(M, D, geom.L, P, grid_queries)
+    OA = empty((rows, ldq), torch.float16 if oa16 else odt, q2d)
     pr = getattr(so_w, "_pair", None)
     if pr is not None:                        # offsets | logits = ONE Linear over the adjacent parameters
         Wt, sp = Wf(pr["w"], q2d, split)
@@ -130,7 +134,7 @@ def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P
         ops.linear_fwd(q2d, Wt, so_b, OA, ldc=ldq, split=sp)
         Wt, sp = Wf(aw_w, q2d, split)
         ops.linear_fwd(q2d, Wt, aw_b, OA[:, 2 * mlp:], ldc=ldq, split=sp)
-    out = empty((rows, M * D), OA.dtype, q2d)
+    out = empty((rows, M * D), odt, q2d)
     ops.msda_fused_fwd(V, vstrides_of(V), geom, OA, ldq, 2 * mlp, ref, ref_bs, out, N, M, D, P, Lq, grid_queries=grid_queries)
     return out, OA
 
@@ -142,7 +146,7 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
     mlp = M * geom.L * P
     ldq, rows = 3 * mlp, N * Lq
     if dOA is None:
-        dOA = torch.empty_like(OA)
+        dOA = torch.empty(OA.shape, dtype=torch.bfloat16 if OA.dtype == torch.float16 else OA.dtype, device=OA.device)    # (gradients of an fp16 buffer are bf16)
     ldg = dOA.stride(0)
     gvs = vstrides_of(dV)                                              # (the decoder scatters into token-major rows: its own strides)
     ops.msda_fused_bwd(V, vstrides_of(V), geom, OA, ldq, 2 * mlp, ref, ref_bs, d_out, dV, dOA, N, M, D, P, Lq,
@@ -297,13 +301,13 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
                                 g("norm1.weight"), g("norm1.bias"))
     # grid queries + bf16 storage + D = 16: the LDS-tiled scatter can hand over the value gradient in bf16 (packed bf16x2
     # atomics; its consumer, the value projection's backward, rounds it to bf16 anyway) -- half the atomics, zero-fill and read
-    gv16 = (sv["V"].dtype == torch.bfloat16 and sv["OA"].dtype == torch.bfloat16 and D == 16 and npts == 4 and geom.L * npts <= 16
+    gv16 = (sv["V"].dtype == torch.bfloat16 and sv["OA"].dtype in (torch.bfloat16, torch.float16) and D == 16 and npts == 4 and geom.L * npts <= 16
             and ops.tiled_scatter_bf16())
     dV = torch.zeros(sv["V"].shape, dtype=torch.bfloat16 if gv16 else torch.float32, device=dx2.device)
     mlp = M * geom.L * npts
     seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
     so_w = P_["self_attn.sampling_offsets.weight"]
-    tri = getattr(so_w, "_triple", None) if sv["OA"].dtype == torch.bfloat16 and sv["V"].dtype == torch.bfloat16 else None
+    tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and sv["V"].dtype == torch.bfloat16 else None
     if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d):
         tri = None
     G2 = None

@@ -40,6 +40,23 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
+// fp32 pair -> packed IEEE fp16 (v_cvt_pk_f16_f32, round-to-nearest-even) and back
+typedef _Float16 f16x2h_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2h_t));
+}
+__device__ __forceinline__ float h_lo(uint32_t v) { return (float)__builtin_bit_cast(f16x2h_t, v)[0]; }
+__device__ __forceinline__ float h_hi(uint32_t v) { return (float)__builtin_bit_cast(f16x2h_t, v)[1]; }
+// 8 consecutive 2-byte outputs as fp16 (PoetGemmDesc.c_f16) -- the bf16 form is vec<bf16_t, 8>::st
+__device__ __forceinline__ void st8_f16(uint16_t* p, const float* o) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]), pack_h2(o[4], o[5]), pack_h2(o[6], o[7]));
+}
+
+// IEEE fp16 STORAGE type of GEMM outputs (PoetGemmDesc.c_f16): a distinct type, so kernels specialised on their output
+// type carry either conversion and no run-time switch
+struct f16_t { uint16_t v; };
+
 template <typename T> struct io;
 template <> struct io<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -93,6 +110,19 @@ template <> struct vec<bf16_t, 8> {
         *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]),
                                                   pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
     }
+};
+
+template <> struct io<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return h_lo((uint32_t)p->v); }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { p->v = (uint16_t)(pack_h2(v, 0.f) & 0xffffu); }
+};
+template <> struct vec<f16_t, 8> {
+    static __device__ __forceinline__ void ld(const f16_t* p, float* o) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        o[0] = h_lo(v.x); o[1] = h_hi(v.x); o[2] = h_lo(v.y); o[3] = h_hi(v.y);
+        o[4] = h_lo(v.z); o[5] = h_hi(v.z); o[6] = h_lo(v.w); o[7] = h_hi(v.w);
+    }
+    static __device__ __forceinline__ void st(f16_t* p, const float* o) { st8_f16(reinterpret_cast<uint16_t*>(p), o); }
 };
 
 // ---- counter-based dropout RNG -------------------------------------------------------------------

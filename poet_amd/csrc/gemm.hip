@@ -352,6 +352,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;
         }
+        if constexpr (sizeof(TC) == 2) {
+            if (d.c_f16) {                                      // 2-byte outputs as IEEE fp16 (PoetGemmDesc.c_f16)
+                uint16_t* C16 = reinterpret_cast<uint16_t*>(C);
+                if (full) st8_f16(C16 + off, v);
+                else if (d.out_mode == 1) {
+                    for (int e = 0; e < 8; ++e) if (gcol + e < d.N) {
+                        const int cc = gcol + e, hn = grow / d.hm_S, hs = grow - hn * d.hm_S, hm = cc / d.hm_D, hd = cc - hm * d.hm_D;
+                        C16[(((int64_t)hn * d.hm_M + hm) * d.hm_S + hs) * d.hm_D + hd] = (uint16_t)(pack_h2(v[e], 0.f) & 0xffffu);
+                    }
+                } else {
+                    for (int e = 0; e < 8; ++e) if (gcol + e < d.N) C16[off + e] = (uint16_t)(pack_h2(v[e], 0.f) & 0xffffu);
+                }
+                continue;
+            }
+        }
         if (full) {
             vec<TC, 8>::st(C + off, v);
         } else if (d.out_mode == 1) {
@@ -465,6 +480,9 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
                    "poet_gemm: atomic/split-K allows no epilogue");
     }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
+    if (d.c_f16)
+        POET_CHECK(d.c_dtype == POET_BF16 && !d.add_src && !d.gate_ref && !atomic, POET_ERR_ARG,
+                   "poet_gemm: c_f16 needs a 2-byte C (c_dtype POET_BF16) and no add_src / gate_ref / split-K");
     if (d.out_mode == 1) POET_CHECK(d.hm_M > 0 && d.hm_S > 0 && d.hm_D > 0 && d.hm_M * d.hm_D == d.N, POET_ERR_ARG, "poet_gemm: head-major dims");
     if (d.b_split && d.B_lo)
         POET_CHECK(d.b_dtype == POET_BF16 && d.compute == POET_BF16 && !atomic, POET_ERR_ARG,

@@ -73,7 +73,10 @@ __device__ __forceinline__ int swz_km(int krow) { return (krow & 3) | (((krow >>
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes from `base + voff[lane]` to LDS bytes [lds, lds + 1024) in lane order
 __device__ __forceinline__ void dma16(uint32_t voff, const void* base, uint32_t lds) {
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory", "m0");
+    // (M0 is written behind the compiler's back: hipcc rejects "m0" on the clobber list as a reserved register -- "may lead to
+    // undefined behaviour" -- so the guarantee is structural instead: nothing else in gemm_pipe_kernel uses M0 (no movrel indexing,
+    // no LDS-DMA builtin, no ds_gws / sendmsg); tests/test_abi_cpu.py::test_pipe_kernel_m0_only_in_dma greps the ISA for it)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void gload16(f32x4_t& dst, uint32_t voff, const void* base) {
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");

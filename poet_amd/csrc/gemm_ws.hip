@@ -51,6 +51,14 @@ template <> struct run8<bf16_t> {
         o[6] = __uint_as_float(r[0].w << 16); o[7] = __uint_as_float(r[0].w & 0xffff0000u);
     }
 };
+template <> struct run8<f16_t> {                           // (fp16 outputs have no add_src / gate_ref: ld / dec exist for the type's sake)
+    static constexpr int NV = 1;
+    static __device__ __forceinline__ void ld(const f16_t* p, uint4* r) { r[0] = *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ void dec(const uint4* r, float* o) {
+        o[0] = h_lo(r[0].x); o[1] = h_hi(r[0].x); o[2] = h_lo(r[0].y); o[3] = h_hi(r[0].y);
+        o[4] = h_lo(r[0].z); o[5] = h_hi(r[0].z); o[6] = h_lo(r[0].w); o[7] = h_hi(r[0].w);
+    }
+};
 template <> struct run8<float> {
     static constexpr int NV = 2;
     static __device__ __forceinline__ void ld(const float* p, uint4* r) {
@@ -625,6 +633,11 @@ template <typename TC>
 bool ws_kind(const GemmK& p, int nblocks, hipStream_t st) {
     const PoetGemmDesc& d = p.d;
     const int kind = (d.gate_ref ? WS_GATE : 0) | (d.add_src ? WS_ADD : 0) | (d.row_mask ? WS_MASK : 0);
+    if constexpr (sizeof(TC) == 2) {
+        // fp16 outputs (c_f16): the split-weight forward without epilogue operands, specialised on the output type; anything else
+        // goes to the generic kernel
+        if (d.c_f16) return (d.b_split && kind == 0) ? ws_launch_split<f16_t, 0>(p, st) : false;
+    }
     if (d.b_split) {
         switch (kind) {
             case 0: return ws_launch_split<TC, 0>(p, st);
@@ -688,7 +701,7 @@ bool gemm_ws_try(const GemmK& p, hipStream_t st) {
         // (single-weight forms are still faster on the tiled kernel: the W chunk restaging of a one-workgroup-per-CU kernel is
         // exposed; POET_GEMM_WSK_ALL=1 routes them here anyway)
         static const int all = [] { const char* e = getenv("POET_GEMM_WSK_ALL"); return e && atoi(e) ? 1 : 0; }();
-        if (no_wsk || d.K % 128 != 0 || d.K > 4096 || (!d.b_split && !all)) return false;
+        if (no_wsk || d.K % 128 != 0 || d.K > 4096 || (!d.b_split && !all) || d.c_f16) return false;
         return d.c_dtype == POET_BF16 ? wsk_kind<bf16_t>(p, st) : wsk_kind<float>(p, st);
     }
     const int NT = d.N / 128;

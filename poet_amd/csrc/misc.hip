@@ -146,6 +146,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ sr
     }
 }
 
+// NCHW fp32 map -> token-major rows [hi | lo] of 2 C bf16 each: hi = bf16(x), lo = bf16(x - hi).  The row is the activation
+// operand of the input projection taken with 16 significant bits: [hi | lo] [W | W]^T = (hi + lo) W^T in ONE product with K = 2 C.
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, hw = hw0 + tx;
+        tile[i][tx] = (c < C && hw < HW) ? src[((int64_t)n * C + c) * HW + hw] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int hw = hw0 + i, c = c0 + tx;
+        if (c < C && hw < HW) {
+            const float x = tile[tx][i];
+            const bf16_t hi = f2bf(x);
+            bf16_t* row = dst + ((int64_t)n * HW + hw) * (2 * C);
+            row[c] = hi;
+            row[C + c] = f2bf(x - bf2f(hi));
+        }
+    }
+}
+
+// the same split for a row-major fp32 matrix (rows, K) -> (rows, 2 K) bf16 [hi | lo] (the im2col matrix of the extra level)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int K, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int64_t row = t / K;
+    const int k = (int)(t - row * K);
+    const float x = src[t];
+    const bf16_t hi = f2bf(x);
+    dst[row * 2 * K + k] = hi;
+    dst[row * 2 * K + K + k] = f2bf(x - bf2f(hi));
+}
+
 // ---- im2col for the 3x3 stride-2 pad-1 extra-level conv -----------------------------------------
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void im2col_kernel(const S* __restrict__ src, D* __restrict__ dst, int C, int H, int W,
@@ -750,6 +786,19 @@ static int transpose_dispatch(const void* src, void* dst, int N, int C, int HW, 
 }
 extern "C" int poet_nchw_to_tokens(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride, int sd, int dd, void* stream) {
     return transpose_dispatch<true>(src, dst, N, C, HW, tok_off, tok_stride, sd, dd, stream);
+}
+extern "C" int poet_nchw_to_tokens_split(const float* src, void* dst, int N, int C, int HW, void* stream) {
+    POET_CHECK(src && dst && N > 0 && C > 0 && HW > 0, POET_ERR_ARG, "nchw_to_tokens_split: bad args");
+    hipLaunchKernelGGL(transpose_split_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, ST, src, (bf16_t*)dst, C, HW);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+extern "C" int poet_split_rows(const float* src, void* dst, int64_t rows, int K, void* stream) {
+    POET_CHECK(src && dst && rows > 0 && K > 0, POET_ERR_ARG, "split_rows: bad args");
+    const int64_t total = rows * K;
+    hipLaunchKernelGGL(split_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, src, (bf16_t*)dst, K, total);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
 }
 extern "C" int poet_tokens_to_nchw(const void* src, void* dst, int N, int C, int HW, int64_t tok_off, int64_t tok_stride, int sd, int dd, void* stream) {
     return transpose_dispatch<false>(src, dst, N, C, HW, tok_off, tok_stride, sd, dd, stream);

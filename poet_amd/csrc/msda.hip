@@ -43,7 +43,13 @@ struct MsdaP {
     int grid_queries;    // queries are the pixels of the flattened levels, in order (encoder self-attention)
     int parts;           // backward: bit0 = d(offsets|logits)/d(loc,attn) kernel, bit1 = d(value) scatter kernel
     int gv_bf16;         // grad_value is bf16 (LDS-tiled scatter only): windows and far corners leave through packed bf16x2 atomics
+    int q_f16;           // fused, encoder shape: the offsets | logits buffer q1 holds IEEE fp16 (POET_F16), its gradient g1 stays bf16
 };
+
+// a packed pair of 2-byte storage values -> two floats: bf16 (shift / mask) or fp16 (v_cvt_f32_f16); QH is a kernel template
+// parameter, so each kernel carries one form
+template <bool QH> __device__ __forceinline__ float q_lo(uint32_t v) { if constexpr (QH) return h_lo(v); else return __uint_as_float(v << 16); }
+template <bool QH> __device__ __forceinline__ float q_hi(uint32_t v) { if constexpr (QH) return h_hi(v); else return __uint_as_float(v & 0xffff0000u); }
 
 template <typename TQ, int P>
 __device__ __forceinline__ void load_p(const TQ* p, float* o, int n) {
@@ -425,16 +431,16 @@ __device__ __forceinline__ ShRaw sh_load(const MsdaP& p, int row, int m, int o) 
     r.off = *reinterpret_cast<const uint4*>(qrow + (m * 4 + o) * 8);
     return r;
 }
-template <bool KEEP>
+template <bool KEEP, bool QH>
 __device__ __forceinline__ void sh_prepare(const MsdaP& p, const ShRaw& raw, float2 rf, int n, int m, int lane, char* wlds, ShGeo& gk) {
     const int pair = lane >> 2, o = lane & 3;
     float lg[4], off[8];
-    lg[0] = __uint_as_float(raw.lg.x << 16); lg[1] = __uint_as_float(raw.lg.x & 0xffff0000u);
-    lg[2] = __uint_as_float(raw.lg.y << 16); lg[3] = __uint_as_float(raw.lg.y & 0xffff0000u);
-    off[0] = __uint_as_float(raw.off.x << 16); off[1] = __uint_as_float(raw.off.x & 0xffff0000u);
-    off[2] = __uint_as_float(raw.off.y << 16); off[3] = __uint_as_float(raw.off.y & 0xffff0000u);
-    off[4] = __uint_as_float(raw.off.z << 16); off[5] = __uint_as_float(raw.off.z & 0xffff0000u);
-    off[6] = __uint_as_float(raw.off.w << 16); off[7] = __uint_as_float(raw.off.w & 0xffff0000u);
+    lg[0] = q_lo<QH>(raw.lg.x); lg[1] = q_hi<QH>(raw.lg.x);
+    lg[2] = q_lo<QH>(raw.lg.y); lg[3] = q_hi<QH>(raw.lg.y);
+    off[0] = q_lo<QH>(raw.off.x); off[1] = q_hi<QH>(raw.off.x);
+    off[2] = q_lo<QH>(raw.off.y); off[3] = q_hi<QH>(raw.off.y);
+    off[4] = q_lo<QH>(raw.off.z); off[5] = q_hi<QH>(raw.off.z);
+    off[6] = q_lo<QH>(raw.off.w); off[7] = q_hi<QH>(raw.off.w);
     // softmax over the 16 logits of (query, head): 4 per lane, quad reductions
     float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
     mx = fmaxf(mx, quad_xor1(mx)); mx = fmaxf(mx, quad_xor2(mx));
@@ -499,7 +505,7 @@ struct ShMap {
     }
 };
 
-template <int QG>
+template <int QG, bool QH>
 __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const MsdaP p) {
     __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
         const int m = pass * (16 / QG) + mp.hh;
         ShGeo unused;
         const ShRaw raw = sh_load(p, mp.row, m, lane & 3);
-        sh_prepare<false>(p, raw, rf, mp.n, m, lane, wlds, unused);
+        sh_prepare<false, QH>(p, raw, rf, mp.n, m, lane, wlds, unused);
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
     }
 }
 
-template <int QG>
+template <int QG, bool QH>
 __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const MsdaP p) {
     __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
         const int m = pass * (16 / QG) + mp.hh;
         ShGeo gk;
         const ShRaw raw = sh_load(p, mp.row, m, o);
-        sh_prepare<true>(p, raw, rf, mp.n, m, lane, wlds, gk);
+        sh_prepare<true, QH>(p, raw, rf, mp.n, m, lane, wlds, gk);
         // grad_out stays packed: <grad_out, value> over a lane's 8 channels is 4 v_dot2c_f32_bf16 (exact bf16 products, fp32 sum)
         const u32x4_t g = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.grad_out) + (int64_t)mp.row * 256 + m * 16 + dsub * 8);
 #pragma unroll 1
@@ -742,7 +748,7 @@ __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off) {
 }
 
 // D == 16, P == 4 (one DPP row of 16 lanes = the 16 channels of a head = the <= 16 sample points of a query).
-template <typename TQ, int L>
+template <typename TQ, int L, bool QH>
 __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP p, const TileP tp) {
     // LDS windows are INT32 FIXED POINT: ds_add_u32 sustains ~6.8 T lane-ops/s on MI355X, ds_add_f32 only ~0.2 T/s
     // (measured), i.e. float LDS atomics are no faster than L2 atomics.  Scale = 2^k per workgroup with
@@ -878,9 +884,9 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
             const uint32_t row_ = (uint32_t)(row0 + q_);                                                              \
             n_g = bf2f(ldg32<TQ>(p.grad_out, row_ * g_row + g_lane));                                                 \
             const uint32_t oxy_ = ldg32<uint32_t>(p.q1, row_ * q_row + of_lane);   /* (off_x, off_y) bf16 pair */      \
-            n_lg = has ? bf2f(ldg32<TQ>(p.q1, row_ * q_row + lg_lane)) : -3.0e38f;                                    \
-            n_ox = __uint_as_float(oxy_ << 16);                                                                       \
-            n_oy = __uint_as_float(oxy_ & 0xffff0000u);                                                               \
+            n_lg = has ? q_lo<QH>((uint32_t)ldg32<TQ>(p.q1, row_ * q_row + lg_lane)) : -3.0e38f;                      \
+            n_ox = q_lo<QH>(oxy_);                                                                                    \
+            n_oy = q_hi<QH>(oxy_);                                                                                    \
             const float2 rf_ = ldg32<float2>(p.ref, (uint32_t)q_ * rf_q + rf_lane);                                   \
             n_rx = rf_.x; n_ry = rf_.y;                                                                               \
         } while (0)
@@ -1273,6 +1279,8 @@ typedef __attribute__((address_space(3))) mf_v4s_t mf_lds_v4s_t;
 
 __device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ float qs_lo(uint32_t v, int f16) { return f16 ? h_lo(v) : bf_lo(v); }      // offsets | logits: bf16 or fp16 storage
+__device__ __forceinline__ float qs_hi(uint32_t v, int f16) { return f16 ? h_hi(v) : bf_hi(v); }
 
 template <typename TQ, int L>
 __global__ __launch_bounds__(MF_NT) void msda_bwd_dv_mfma_kernel(const MsdaP p, const TileP tp) {
@@ -1396,7 +1404,7 @@ __global__ __launch_bounds__(MF_NT) void msda_bwd_dv_mfma_kernel(const MsdaP p, 
             const uint2 g = ldg32<uint2>(p.q1, row * q_row + (uint32_t)(p.logit_col + m * LP + l * P) * 2u);
             const float2 r = ldg32<float2>(p.ref, (uint32_t)(n * p.ref_bs + (q * L + l) * 2) * 4u);
             ofv[4 * l] = o.x; ofv[4 * l + 1] = o.y; ofv[4 * l + 2] = o.z; ofv[4 * l + 3] = o.w;
-            a[4 * l] = bf_lo(g.x); a[4 * l + 1] = bf_hi(g.x); a[4 * l + 2] = bf_lo(g.y); a[4 * l + 3] = bf_hi(g.y);
+            a[4 * l] = qs_lo(g.x, p.q_f16); a[4 * l + 1] = qs_hi(g.x, p.q_f16); a[4 * l + 2] = qs_lo(g.y, p.q_f16); a[4 * l + 3] = qs_hi(g.y, p.q_f16);
             rfv[2 * l] = r.x; rfv[2 * l + 1] = r.y;
         }
         const uint4 gv0 = ldg32<uint4>(p.grad_out, row * g_row + (uint32_t)(m * D) * 2u);
@@ -1454,7 +1462,7 @@ __global__ __launch_bounds__(MF_NT) void msda_bwd_dv_mfma_kernel(const MsdaP p, 
             for (int pt = 0; pt < P; ++pt) {
                 const float aj = a[4 * l + pt];
                 const uint32_t ofw = ofv[4 * l + pt];
-                const float px = bxf + bf_lo(ofw), py = byf + bf_hi(ofw);
+                const float px = bxf + qs_lo(ofw, p.q_f16), py = byf + qs_hi(ofw, p.q_f16);
                 const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
                 const int x0 = (int)x0f, y0 = (int)y0f;         // v_cvt saturates; every use below is an unsigned range test
                 const int lx0 = x0 - lwx0, ly0 = y0 - lwy0;
@@ -1680,7 +1688,7 @@ template <typename TV, typename TQ, int L, bool BWD>
 static bool launch_win(const MsdaP& p, int P, hipStream_t st) {
     if constexpr (sizeof(TV) != 2 || sizeof(TQ) != 2) return false;
     else {
-    if (P != 4 || p.D != 16 || L * P % 8 != 0 || !p.grid_queries || p.Lq != p.S || p.vs_s != 16) return false;
+    if (P != 4 || p.D != 16 || L * P % 8 != 0 || !p.grid_queries || p.Lq != p.S || p.vs_s != 16 || p.q_f16) return false;
     // OPT-IN (POET_WIN_GATHER=1).  Measured at 640x480, bs 16, M = 16: forward 267 us / backward 359 us
     // at the best configuration against 250 / 330 us for the L1-served gathers below -- per-lane random 32-B LDS reads
     // conflict 3-4 ways and a lane's offset / logit / output rows are 1.5 KB apart in HBM.
@@ -1725,10 +1733,14 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
     { const char* e = getenv("POET_NO_TILED_SCATTER"); if (e && atoi(e)) return false; }
     { const char* e = getenv("POET_DV_SKIP"); tp.skip = e ? atoi(e) : 0; }
     if (!lds) return false;
-    auto kern = msda_bwd_dv_tiled_kernel<TQ, L>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_dv_tiled_kernel<TQ, L, false>), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_dv_tiled_kernel<TQ, L, true>), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048);
+        attr_set = true;
+    }
+    if (p.q_f16) hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, true>), dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
+    else hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, false>), dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
     return true;
     }
 }
@@ -1766,6 +1778,10 @@ static bool launch_dv_mfma(const MsdaP& p, int P, hipStream_t st) {
     }
 }
 
+// fp16 offsets | logits (MsdaP::q_f16) are read by the shared-geometry gathers and the LDS-tiled scatters only: a launch that would
+// fall through to a general kernel (which reads q1 as bf16) is refused instead
+static thread_local bool g_f16_refused = false;
+
 template <typename TV, typename TQ, int L, bool FUSED, bool BWD>
 static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     dim3 grid(cdiv(p.total, 256)), block(256);
@@ -1775,6 +1791,7 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
         if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_mfma<TQ, L>(p, P, st);
         if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
     }
+    if (p.q_f16 && BWD && !dv_done) { g_f16_refused = true; return; }
     if (BWD && !dv_done) {
         if (P == 4) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 4, FUSED>), gridv, block, 0, st, p);
         else if (P == 2) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 2, FUSED>), gridv, block, 0, st, p);
@@ -1797,14 +1814,16 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
             const dim3 grid((unsigned)((rows + SH_WAVES * qg - 1) / (SH_WAVES * qg))), blk(SH_WAVES * 64);
             const char* pad_ = getenv("POET_SH_PADLDS");          // experiment: extra LDS per workgroup (lowers the occupancy)
             const size_t dyn = pad_ ? (size_t)atoi(pad_) : 0;
-#define POET_SH_LAUNCH(Q) do { if (BWD) hipLaunchKernelGGL(msda_bwd_shared_kernel<Q>, grid, blk, dyn, st, p); \
-                               else hipLaunchKernelGGL(msda_fwd_shared_kernel<Q>, grid, blk, dyn, st, p); } while (0)
-            if (qg == 1) POET_SH_LAUNCH(1);
-            else POET_SH_LAUNCH(4);
+#define POET_SH_LAUNCH(Q, H) do { if (BWD) hipLaunchKernelGGL((msda_bwd_shared_kernel<Q, H>), grid, blk, dyn, st, p); \
+                                  else hipLaunchKernelGGL((msda_fwd_shared_kernel<Q, H>), grid, blk, dyn, st, p); } while (0)
+            if (p.q_f16) { if (qg == 1) POET_SH_LAUNCH(1, true); else POET_SH_LAUNCH(4, true); }
+            else if (qg == 1) POET_SH_LAUNCH(1, false);
+            else POET_SH_LAUNCH(4, false);
 #undef POET_SH_LAUNCH
             return;
         }
     }
+    if (p.q_f16) { g_f16_refused = true; return; }
     if (P == 4) {
         if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
         else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
@@ -1836,7 +1855,16 @@ static int dispatch(const MsdaP& p, int L, int P, int v_dtype, int q_dtype, hipS
                    POET_ERR_UNSUPPORTED, "msda: value maps of %lld bytes exceed the 4 GiB (32-bit offset) limit of the gather kernels",
                    (long long)span);
     }
-    if (v_dtype == POET_BF16 && q_dtype == POET_BF16) launch_l<bf16_t, bf16_t, FUSED, BWD>(p, L, P, st);
+    g_f16_refused = false;
+    if (v_dtype == POET_BF16 && q_dtype == POET_F16 && FUSED) {
+        MsdaP ph = p;
+        ph.q_f16 = 1;
+        launch_l<bf16_t, bf16_t, FUSED, BWD>(ph, L, P, st);
+        POET_CHECK(!g_f16_refused, POET_ERR_UNSUPPORTED,
+                   "msda_fused: fp16 offsets | logits (q_dtype POET_F16) need the encoder shape (bf16 value maps, 16 heads x 16 channels, 4 levels x 4 points, "
+                   "grid queries) served by the shared-geometry gathers and the LDS-tiled scatter");
+    }
+    else if (v_dtype == POET_BF16 && q_dtype == POET_BF16) launch_l<bf16_t, bf16_t, FUSED, BWD>(p, L, P, st);
     else if (v_dtype == POET_F32 && q_dtype == POET_F32) launch_l<float, float, FUSED, BWD>(p, L, P, st);
     else if (v_dtype == POET_BF16 && q_dtype == POET_F32) launch_l<bf16_t, float, FUSED, BWD>(p, L, P, st);
     else { set_error("msda: unsupported dtype pair v=%d q=%d", v_dtype, q_dtype); return POET_ERR_UNSUPPORTED; }

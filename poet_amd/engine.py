@@ -889,6 +889,10 @@ class GraphedTrainer(Trainer):
         if segment_backward is None:         # per-bucket backward graphs: needed (only) to overlap all-reduces with backward
             segment_backward = (self.reducer is not None and self.reducer.active) or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
         self.segment_backward = bool(segment_backward)
+        # POET_DP_SINGLE_COLLECTIVE=1: backward stays ONE graph (without the optimiser) and the whole gradient arena is all-reduced
+        # in ONE collective behind it (BucketReducer.finish() coalesces every un-announced range) -- no per-bucket segments (they
+        # cost ~0.25 ms per step at one rank and buy only overlap); the default keeps one segment per bucket.
+        self.single_collective = self.segment_backward and os.environ.get("POET_DP_SINGLE_COLLECTIVE", "0") not in ("", "0")
         if not self.segment_backward and self.reducer is not None and self.reducer.active:
             raise ValueError("GraphedTrainer: world > 1 needs segment_backward=True (the single backward graph contains no "
                              "all-reduce: the replicas would drift apart silently)")
@@ -1044,13 +1048,19 @@ class GraphedTrainer(Trainer):
                 return torch.autograd.grad([rot, trans, *self.s_extra], [hs], [self.s_drot, self.s_dtrans, *self.s_dextra], retain_graph=True)[0]
 
             from .functional import enc_bucket_tag
-            dhs = seg(first, ["0_heads"])
+            if self.single_collective:
+                def whole():
+                    self.arena.zero_grad()
+                    torch.autograd.backward([rot, trans, *self.s_extra], [self.s_drot, self.s_dtrans, *self.s_dextra])
+                seg(whole, [])                    # no bucket is announced: BucketReducer.finish() reduces the whole arena at once
+                n_enc = 0
+            dhs = None if self.single_collective else seg(first, ["0_heads"])
             # (learned query embeddings / reference points: their nodes hang off the decoder node, not off the path to the
             # memory -- ask for those leaves too so that their backward programs run in this segment; they write into the arena
             # views themselves and hand autograd None)
             extra = [p for n, p in m.named_parameters() if n.startswith("query_embed.") or
                      (n.startswith("transformer.reference_points.") and getattr(m, "ref_points_mode", "bbox") == "learned")]
-            dx = seg(lambda: torch.autograd.grad([hs], [outs[-1]] + extra, [dhs], retain_graph=True, allow_unused=True)[0], ["1_decoder"])
+            dx = None if self.single_collective else seg(lambda: torch.autograd.grad([hs], [outs[-1]] + extra, [dhs], retain_graph=True, allow_unused=True)[0], ["1_decoder"])
             keep = [dhs, dx]
             for i in reversed(range(n_enc)):
                 tags = [enc_bucket_tag(n_enc, i)] + (["2_encoder_99"] if i == 0 else [])
@@ -1059,7 +1069,8 @@ class GraphedTrainer(Trainer):
                     keep.append(dx)
                 else:
                     seg(lambda dx=dx: torch.autograd.backward([outs[1]], [dx], inputs=None), tags)
-            seg(lambda: torch.autograd.backward([outs[0]], [dx]), ["3_input_proj"])
+            if not self.single_collective:
+                seg(lambda: torch.autograd.backward([outs[0]], [dx]), ["3_input_proj"])
             self._seg_keep = keep
         else:
             self.g_bwd = torch.cuda.CUDAGraph()

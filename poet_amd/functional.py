@@ -467,11 +467,25 @@ class InputProjFn(torch.autograd.Function):
             if lvl < len(feats):
                 f = feats[lvl].contiguous()
                 C = f.shape[1]
-                if (act_dtype == torch.bfloat16 and N * HW >= 4096 and C % 128 == 0 and d % 128 == 0
+                exact = split and f.dtype == torch.float32 and C % 8 == 0 and ops.inproj_exact()
+                if (act_dtype == torch.bfloat16 and (exact or (N * HW >= 4096 and C % 128 == 0 and d % 128 == 0))
                         and os.environ.get("POET_INPROJ_NCHW_GEMM", "0") in ("", "0")):
                     # 1x1 conv = Linear over token rows: transpose + round the NCHW map once (the GEMM rounds it to bf16 anyway) and
                     # run the streaming kernels on row-major operands -- forward here, weight gradient in backward -- instead of
                     # the tiled kernel's K-major fp32 loads (94 us for the 118 MB of the 60 x 80 level)
+                    if exact:
+                        # the operand with 16 significant bits: rows [hi | lo] against [W | W] (K = 2 C, split weights), fp32
+                        # accumulators kept up to the GroupNorm (the input projection was the second largest
+                        # rounding site of the bf16 policy); the bf16 copy of the output is what backward reads
+                        f2 = torch.empty((N * HW, 2 * C), dtype=torch.bfloat16, device=src.device)
+                        ops.nchw_to_tokens_split(f, f2, N, C, HW)
+                        pre32 = torch.empty((N, HW, d), dtype=torch.float32, device=src.device)
+                        ops.linear_fwd(f2, torch.cat([W.view(d, C), W.view(d, C)], 1), b, pre32.view(N * HW, d), split=True)
+                        stats = torch.empty((N, n_groups, 2), dtype=torch.float32, device=src.device)
+                        ops.groupnorm_fwd(pre32, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S)
+                        ops.cast(pre32, pre)
+                        saved.append((f2, None, pre, stats))
+                        continue
                     f16 = torch.empty((N * HW, C), dtype=torch.bfloat16, device=src.device)
                     ops.nchw_to_tokens(f, f16, N, C, HW, 0, HW)
                     ops.linear_fwd(f16, W.view(d, C), b, pre.view(N * HW, d), split=split)
@@ -488,6 +502,20 @@ class InputProjFn(torch.autograd.Function):
                     inp = torch.empty((N, d, Hp, Wp), dtype=act_dtype, device=src.device)
                     ops.tokens_to_nchw(src, inp, N, d, Hp * Wp, geom.starts[lvl - 1], S)
                 C, Hi, Wi = inp.shape[1:]
+                if split and inp.dtype == torch.float32 and ops.inproj_exact():
+                    # same as above for the 3x3 stride-2 convolution of the extra level: im2col in fp32, [hi | lo] rows, K = 18 C
+                    col32 = torch.empty((N * HW, C * 9), dtype=torch.float32, device=src.device)
+                    ops.im2col3x3s2(inp, col32, N, C, Hi, Wi, H, Wd)
+                    col = torch.empty((N * HW, C * 18), dtype=torch.bfloat16, device=src.device)
+                    ops.split_rows(col32, col)
+                    pre32 = torch.empty((N, HW, d), dtype=torch.float32, device=src.device)
+                    Wc = W.view(d, C * 9)
+                    ops.linear_fwd(col, torch.cat([Wc, Wc], 1), b, pre32.view(N * HW, d), split=True)
+                    stats = torch.empty((N, n_groups, 2), dtype=torch.float32, device=src.device)
+                    ops.groupnorm_fwd(pre32, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S)
+                    ops.cast(pre32, pre)
+                    saved.append((None, col, pre, stats))
+                    continue
                 col = torch.empty((N * HW, C * 9), dtype=act_dtype, device=src.device)
                 ops.im2col3x3s2(inp, col, N, C, Hi, Wi, H, Wd)
                 ops.linear_fwd(col, W.view(d, C * 9), b, pre, split=split)
@@ -517,7 +545,8 @@ class InputProjFn(torch.autograd.Function):
                               0, HW, geom.starts[lvl], S)
             gW = G(f"{lvl}.0.weight")
             if f is not None and f.dim() == 2:                 # token-major bf16 copy of the feature map (see forward): dW + db in one pass
-                ops.linear_dw(dpre.view(N * HW, d), f, gW.view(d, -1), rows=N * HW, db=G(f"{lvl}.0.bias"))
+                # ([hi | lo] rows: the weight gradient takes the hi half, row stride 2 C)
+                ops.linear_dw(dpre.view(N * HW, d), f, gW.view(d, -1), rows=N * HW, db=G(f"{lvl}.0.bias"), ldx=f.shape[1])
                 continue
             ops.colsum(dpre, d, G(f"{lvl}.0.bias"), 1, N * HW, d)
             if f is not None:
@@ -525,7 +554,7 @@ class InputProjFn(torch.autograd.Function):
                 ops.gemm(dpre, f, gW, d, C, HW, lda=d, ldb=HW, ldc=C, a_kmajor=True, b_kmajor=False, batch=N,
                          strideA=HW * d, strideB=C * HW, strideC=0, atomic=True, splitk=max(1, min(8, HW // 512)))
             else:
-                ops.linear_dw(dpre.view(N * HW, d), col, gW.view(d, -1), rows=N * HW)
+                ops.linear_dw(dpre.view(N * HW, d), col, gW.view(d, -1), rows=N * HW, ldx=col.shape[1])     # ([hi | lo] rows: the hi half)
         ops.SIDE.join()
         announce("3_input_proj")
         return (None, None, None, None, None, *G.ret)

@@ -13,7 +13,8 @@ from ._lib import BF16, F32, GemmDesc
 
 import struct as _struct
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+F16 = 2                                        # POET_F16: IEEE half STORAGE of the offsets | logits buffer (include/poet_hip.h)
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 # PoetGemmDesc as one packed record (natural C layout of include/poet_hip.h; checked against ctypes below)
 _GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i Q q Q")     # native alignment inserts the same padding as the C compiler
 assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 40 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
@@ -224,6 +225,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     if not (A.is_cuda and B.is_cuda and Cout.is_cuda):
         raise _lib.PoetHipError("poet_amd: GEMM operands must live on the GPU (no CPU path exists)")
     ad, bd, cd = _DT[A.dtype], _DT[B.dtype], _DT[Cout.dtype]
+    c_f16 = 0
+    if cd == F16:           # an fp16 OUTPUT: 2-byte slots of a bf16-typed C written as IEEE half (PoetGemmDesc.c_f16)
+        cd, c_f16 = BF16, 1
+    if ad == F16 or bd == F16:
+        raise TypeError("poet_amd: fp16 is a storage format of GEMM outputs only (offsets | logits), never an operand")
     if compute is None:     # bf16 MFMA as soon as any operand is stored in bf16; pure-fp32 calls use the f32 MFMA
         compute = BF16 if (ad | bd | cd) else F32
     if bias is not None and bias.dtype != torch.float32:
@@ -238,7 +244,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                          M, N, K, lda, ldb, ldc, ld_add, int(a_kmajor), int(b_kmajor), ad, bd, cd, compute, batch,
                          strideA, strideB, strideC, stride_bias, splitk, int(atomic), act, alpha, gate_scale, drop_p,
                          seed & 0xFFFFFFFF, 1 if head_major is not None else 0, hm[0], hm[1], hm[2],
-                         (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), 0, ws, _WORKSPACE_BYTES if ws else 0,
+                         (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), c_f16, ws, _WORKSPACE_BYTES if ws else 0,
                          0 if B_lo is None else B_lo.data_ptr())
     if PROFILE.on:
         e0 = PROFILE.begin()
@@ -398,7 +404,7 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
         try:
             if parts in (2, 3, 0):
                 e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=2, ld_grad=ld_grad, gv_strides=gv_strides)
-                PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype == torch.bfloat16) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * grad_value.element_size())
+                PROFILE.end("msda_bwd_dvalue_scatter_tiled" if (grid_queries and offattn.dtype in (torch.bfloat16, torch.float16)) else "msda_bwd_dvalue_scatter", e0, 0.0, offattn.numel() * offattn.element_size() + grad_out.numel() * grad_out.element_size() + grad_value.numel() * grad_value.element_size())
             if parts in (1, 3, 0):
                 e0 = PROFILE.begin(); msda_fused_bwd(*a, grid_queries=grid_queries, parts=1, ld_grad=ld_grad, gv_strides=gv_strides)
                 PROFILE.end("msda_bwd_dq" + ("_small" if N * Lq < 4096 else ""), e0, 0.0, nb_q)
@@ -541,6 +547,16 @@ def pipe_split() -> bool:
     return os.environ.get("POET_GEMM_NO_PIPE", "0") in ("", "0") and os.environ.get("POET_NO_PIPE_SPLIT", "0") in ("", "0")
 
 
+def oa_f16(M, D, L, P, grid_queries) -> bool:
+    """fp16 storage of the encoder's sampling offsets | attention logits (8x the resolution of bf16 at the same 2 bytes: the
+    offsets are pixel distances of a few units, bf16 resolves them to 1/32 px): where the kernels that read them as fp16 run --
+    the shared-geometry gathers and the LDS-tiled scatter at the encoder shape -- and POET_OA_BF16=1 does not ask for bf16."""
+    env = os.environ.get
+    return bool(grid_queries and M == 16 and D == 16 and L == 4 and P == 4 and env("POET_OA_BF16", "0") in ("", "0")
+                and env("POET_MSDA_NO_SHARED", "0") in ("", "0") and env("POET_NO_TILED_SCATTER", "0") in ("", "0")
+                and env("POET_WIN_GATHER", "0") in ("", "0"))
+
+
 def tiled_scatter_bf16() -> bool:
     """bf16 value-gradient maps out of the encoder's LDS-tiled scatter (POET_DV_FP32=1 or POET_NO_TILED_SCATTER=1: fp32)."""
     return os.environ.get("POET_DV_FP32", "0") in ("", "0") and os.environ.get("POET_NO_TILED_SCATTER", "0") in ("", "0")
@@ -563,6 +579,28 @@ def nchw_to_tokens(src, dst, N, Cc, HW, tok_off, tok_stride):
     lib = _lib.load()
     _lib.check(lib.poet_nchw_to_tokens(_req(src, "src").data_ptr(), dst.data_ptr(), N, Cc, HW, tok_off, tok_stride, dcode(src),
                                        dcode(dst), _stream()), "poet_nchw_to_tokens")
+
+
+def nchw_to_tokens_split(src, dst, N, Cc, HW):
+    """src (N, C, HW) fp32 -> dst (N*HW, 2C) bf16 rows [hi | lo] (hi = bf16(x), lo = bf16(x - hi))."""
+    lib = _lib.load()
+    if src.dtype != torch.float32 or dst.dtype != torch.bfloat16:
+        raise TypeError("nchw_to_tokens_split: fp32 map -> bf16 [hi | lo] rows")
+    _lib.check(lib.poet_nchw_to_tokens_split(_req(src, "src").data_ptr(), dst.data_ptr(), N, Cc, HW, _stream()), "poet_nchw_to_tokens_split")
+
+
+def split_rows(src, dst):
+    """src (rows, K) fp32 -> dst (rows, 2K) bf16 rows [hi | lo]."""
+    lib = _lib.load()
+    if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or dst.shape[-1] != 2 * src.shape[-1]:
+        raise TypeError("split_rows: fp32 (rows, K) -> bf16 (rows, 2K)")
+    _lib.check(lib.poet_split_rows(_req(src, "src").data_ptr(), dst.data_ptr(), src.numel() // src.shape[-1], src.shape[-1], _stream()), "poet_split_rows")
+
+
+def inproj_exact() -> bool:
+    """bf16 policy: the input projection reads the backbone's fp32 maps as bf16 hi + lo (16 significant bits) and keeps its
+    output in fp32 up to the GroupNorm (POET_INPROJ_BF16=1: single bf16 operand + bf16 output, the round-3 form)."""
+    return os.environ.get("POET_INPROJ_BF16", "0") in ("", "0")
 
 
 def tokens_to_nchw(src, dst, N, Cc, HW, tok_off, tok_stride):

@@ -1,0 +1,28 @@
+"""Isolated timing of the split-weight streaming forward GEMM (offsets | logits: N = 768, FFN1: N = 1024; 102 080 rows, K = 256).
+LIB=path loads another build of the library (ABI check relaxed) for same-box A/B.  Usage: python profiles/probes/ws_split_bench.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from poet_amd import _lib
+if os.environ.get("LIB"):
+    _lib.LIB_PATH = os.environ["LIB"]
+    _lib.ABI_VERSION = int(os.environ.get("LIB_ABI", "2"))
+    for k in ("poet_nchw_to_tokens_split", "poet_split_rows"):      # (entry points newer than the other build)
+        _lib._PROTOS.pop(k, None)
+from poet_amd import ops
+rows, K = 102080, 256
+x = torch.randn(rows, K, device="cuda").to(torch.bfloat16)
+def timeit(fn, n=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for N in (768, 1024, 256):
+    w = torch.randn(N, K, device="cuda") / 16
+    b = torch.randn(N, device="cuda")
+    for odt in (torch.bfloat16,) + ((torch.float16,) if not os.environ.get("LIB") else ()):
+        out = torch.empty(rows, N, dtype=odt, device="cuda")
+        t = timeit(lambda: ops.linear_fwd(x, w, b, out, split=True, act=1 if N == 1024 else 0))
+        print(f"split fwd 256 -> {N} out {str(odt)[6:]:9s}: {t:7.1f} us")

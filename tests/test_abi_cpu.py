@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/poet_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "ctypes prototype table and header drifted apart"
-    assert lib.poet_hip_version() == 2
+    assert lib.poet_hip_version() == 3
 
 
 def test_gemm_descriptor_layout_matches_header():
@@ -133,3 +133,21 @@ def test_graft_entry_build_passes():
     (it asserted version 1 after the header had moved to 2) and resolve every declared symbol."""
     import __graft_entry__
     __graft_entry__.build()
+
+
+def test_pipe_kernel_m0_only_in_dma(tmp_path):
+    """gemm_pipe.hip sets M0 by hand inside its LDS-DMA inline asm (hipcc accepts no "m0" clobber: reserved register).  That is
+    safe only while nothing else in that translation unit uses M0: the compiled ISA may mention m0 only as `s_mov_b32 m0, sN`
+    (the asm's own write) -- no movrel / gpr-index, no compiler-generated M0 reads."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "pipe.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
+                           "-S", "--cuda-device-only", os.path.join(ROOT, "poet_amd", "csrc", "gemm_pipe.hip"), "-o", out], stderr=subprocess.DEVNULL)
+    lines = [l.strip() for l in open(out) if re.search(r"\bm0\b", l) and not l.lstrip().startswith((";", "//"))]
+    assert lines, "expected the DMA's M0 writes"
+    bad = [l for l in lines if not re.fullmatch(r"s_mov_b32 m0, s\d+", l)]
+    assert not bad, bad[:5]
+    assert not any(re.search(r"v_movrel|s_set_gpr_idx", l) for l in open(out))

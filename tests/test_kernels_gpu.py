@@ -734,6 +734,79 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     assert torch.equal(rows16.view(n, S, m, d).cpu(), gv16.permute(0, 2, 1, 3).cpu())
 
 
+@pytest.mark.parametrize("rows", [5000 + 7, 700])
+def test_gemm_fp16_output_storage(ops, rows):
+    """PoetGemmDesc.c_f16: the 2-byte outputs of a bf16-typed C written as IEEE fp16 (the offsets | logits buffer of the encoder's
+    MSDeformAttn: values of a few units that only the MSDA kernels read) -- streaming kernel (>= 4096 rows, split weights) and
+    tiled kernel (< 4096 rows), row-major and head-major stores; the result is the fp16 rounding of the bf16-operand product."""
+    K, N = 256, 768
+    x = _rand(rows, K, seed=190).to(torch.bfloat16)
+    w = _rand(N, K, seed=191, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=192)
+    hi = w.to(torch.bfloat16).float()
+    w2 = hi + (w - hi).to(torch.bfloat16).float()                       # split weights: hi + lo
+    ref = (x.float().double() @ w2.double().t() + b.double())
+    out = torch.empty(rows, N, dtype=torch.float16, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), out, split=True)
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= 2.0 ** -11 * ref.abs().max().item() + 2e-4, err                 # half an fp16 ulp of the largest value + the fp32 accumulation
+    assert (out.cpu() == ref.to(torch.float16)).float().mean().item() > 0.98       # almost everywhere THE fp16 rounding of the exact product
+    out_bf = torch.empty(rows, N, dtype=torch.bfloat16, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), out_bf, split=True)
+    assert (out_bf.double().cpu() - ref).abs().max().item() > 4 * err              # the same call in bf16 storage is >= 4x coarser
+    with pytest.raises(TypeError):
+        ops.linear_fwd(dev(x).to(torch.float16), dev(w), dev(b), out_bf)
+
+
+def test_msda_fp16_offsets_logits_vs_explicit(ops):
+    """The encoder's MSDA kernels reading the offsets | logits buffer as fp16 (q_dtype POET_F16: shared-geometry forward and
+    d(offsets | logits), LDS-tiled d(value) scatter; gradients stay bf16) against the float64 closed form evaluated on the SAME
+    fp16 values -- and the accuracy this buys: the sampled output of bf16-stored offsets is several times further from the
+    output of the unrounded offsets than that of fp16-stored ones."""
+    m, d, p = 16, 16, 4
+    shapes, n = [(60, 80), (30, 40), (15, 20), (8, 10)], 2
+    L = len(shapes)
+    geom = ops.LevelGeom(shapes)
+    S = geom.S
+    rng = np.random.default_rng(29)
+    mlp = m * L * p
+    value = torch.from_numpy(rng.standard_normal((n, S, m, d)).astype(np.float32)).to(torch.bfloat16)
+    th = np.arange(m) * (2 * np.pi / m)
+    grid = np.stack([np.cos(th), np.sin(th)], -1)
+    grid = grid / np.abs(grid).max(-1, keepdims=True)
+    base = (grid[:, None, None, :] * (np.arange(p) + 1)[None, None, :, None]).repeat(L, 1)
+    off = base[None, None] + 0.3 * rng.standard_normal((n, S, m, L, p, 2))
+    lg = rng.standard_normal((n, S, mlp))
+    oa32 = torch.from_numpy(np.concatenate([off.reshape(n, S, 2 * mlp), lg], -1).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((n, S, m * d)).astype(np.float32)).to(torch.bfloat16)
+    ref = torch.empty(n, S, L, 2, device="cuda")
+    ops.enc_ref_points(dev(torch.ones(n, L, 2)), geom, ref, n)
+    vdev = dev(value.permute(0, 2, 1, 3).contiguous())
+    vstr = (m * S * d, d, S * d)
+    res = {}
+    for qdt in (torch.float16, torch.bfloat16):
+        oa = oa32.to(qdt)
+        out_ref, dv_ref, doa_ref, kink = _explicit_from_fused(shapes, value.float(), oa.float(), ref.cpu(), gout.float(), m, p)
+        out = torch.empty(n, S, m * d, dtype=torch.bfloat16, device="cuda")
+        ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
+        gv = torch.zeros(n, m, S, d, device="cuda")
+        goa = torch.empty(n, S, 3 * mlp, dtype=torch.bfloat16, device="cuda")
+        ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv, goa, n, m, d, p, S, grid_queries=True)
+        e_out = (out.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item()
+        e_dv = (gv.double().cpu().permute(0, 2, 1, 3) - dv_ref).abs().max().item() / dv_ref.abs().max().item()
+        dq = goa.double().cpu()
+        e_off = ((dq[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs() * (~kink)).max().item() / doa_ref[..., : 2 * mlp].abs().max().item()
+        e_lg = (dq[..., 2 * mlp:] - doa_ref[..., 2 * mlp:]).abs().max().item() / doa_ref[..., 2 * mlp:].abs().max().item()
+        print(f"offsets | logits stored as {qdt}: rel max err out {e_out:.2e} dV {e_dv:.2e} d(off) {e_off:.2e} d(logit) {e_lg:.2e}")
+        assert e_out < 6e-3 and e_dv < 1e-3 and e_off < 8e-3 and e_lg < 8e-3, (qdt, e_out, e_dv, e_off, e_lg)
+        res[qdt] = out_ref
+    exact, _, _, _ = _explicit_from_fused(shapes, value.float(), oa32, ref.cpu(), gout.float(), m, p)
+    d16 = (res[torch.float16] - exact).pow(2).mean().sqrt().item()
+    dbf = (res[torch.bfloat16] - exact).pow(2).mean().sqrt().item()
+    print(f"   rms distance of the sampled output from the one of the unrounded offsets | logits: fp16 storage {d16:.2e}, bf16 storage {dbf:.2e}")
+    assert d16 < 0.25 * dbf
+
+
 # ------------------------------------------------------------------------- streaming (weight-stationary) GEMM
 @pytest.mark.parametrize("cdtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("wdtype", [torch.bfloat16, torch.float32])

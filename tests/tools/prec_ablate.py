@@ -2,7 +2,7 @@
 Emulates the HIP bf16 policy on the oracle (fp32 math, operands/stores rounded to bf16 where the policy does).
 Usage: python tests/tools/prec_ablate.py [input_seed init_seed]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from oracle import poet_ref
 from oracle.formula import CONFIGS, make_inputs, make_samples
@@ -15,6 +15,8 @@ ALL = ["pos", "q", "src16", "Wv", "V", "Woa", "off", "logit", "out_m", "Wo", "tm
 def R(x, key):
     if not FL.get(key, False):
         return x
+    if FL.get(key) == "f16":                  # stored in fp16 instead of bf16 (11 significant bits at the same 2 bytes)
+        return x.half().float()
     if key in WKEYS and FL.get("split_w", False) and key not in FL.get("nosplit", ()):          # weight = bf16 hi + bf16 lo (two MFMAs)
         hi = x.bfloat16().float()
         return hi + (x - hi).bfloat16().float()
@@ -136,6 +138,41 @@ def main():
             "P3 P2 + Hd exact": ("tmp1", "tmp2", "src16", "x16", "q", "Hd"),
             "P4 P2 + decA exact": ("tmp1", "tmp2", "src16", "x16", "q", "decA"),
             "P5 P1 + decA exact": ("tmp1", "tmp2", "decA")}
+    if os.environ.get("NSITE"):
+        # n-site table: today's policy (P1) with one, two, three ... rounding sites made exact ON TOP of each other
+        base = ("tmp1", "tmp2")
+        pols = {"Q0 policy (P1)": base,
+                "Q1 + offsets fp32": base + ("off",),
+                "Q2 + offsets, logits fp32": base + ("off", "logit"),
+                "Q3 + offsets + input_proj operands": base + ("off", "inprojA"),
+                "Q4 + offsets + input_proj + value maps": base + ("off", "inprojA", "V"),
+                "Q5 + offsets + input_proj + stream operands": base + ("off", "inprojA", "src16", "x16", "q"),
+                "Q6 + offsets + input_proj + FFN hidden": base + ("off", "inprojA", "Hd"),
+                "Q7 + offsets + input_proj + MSDA out": base + ("off", "inprojA", "out_m"),
+                "Q8 input_proj operands only": base + ("inprojA",),
+                "Q9 + all encoder activations (dec only)": base + ("off", "logit", "inprojA", "V", "src16", "x16", "q", "Hd", "out_m", "pos"),
+                "QA offsets, logits in fp16": base + ("off:f16", "logit:f16"),
+                "QB offsets, logits fp16 + input_proj": base + ("off:f16", "logit:f16", "inprojA"),
+                "QC QB + MSDA out, FFN hidden in fp16": base + ("off:f16", "logit:f16", "inprojA", "out_m:f16", "Hd:f16"),
+                "QD QB + value maps fp16": base + ("off:f16", "logit:f16", "inprojA", "V:f16")}
+        if os.environ.get("QSEL"):
+            pols = {k: v for k, v in pols.items() if k.split()[0] in os.environ["QSEL"].split(",")}
+        for rep in range(int(os.environ.get("REPS", "3"))):
+            if rep:
+                g = torch.Generator().manual_seed(rep)
+                for f in feats:
+                    f.mul_(1 + 3e-7 * torch.randn(f.shape, generator=g))
+                FL.clear()
+                t_ref, r_ref = run(model, samples, targets)
+                mem_ref = cap["mem"]
+            for tag, off in pols.items():
+                FL.clear()
+                for k in ALL: FL[k] = k not in off
+                for k in off:
+                    if k.endswith(":f16"): FL[k[:-4]] = "f16"
+                FL["split_w"] = True
+                measure(f"rep{rep} {tag}")
+        return
     if os.environ.get("ONLY"):
         for k in ALL:
             FL.clear(); FL[k] = True; FL["split_w"] = False
