@@ -134,11 +134,17 @@ def pmc_source(config="ycbv", kind="hbm"):
             "measured_in_this_run": False, "fetch_correction": FETCH_CORRECTION_NOTE}
 
 
-FETCH_CORRECTION_NOTE = ("traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB: the guide's gfx950 correction (FETCH_SIZE counts half of a wide "
-                         "coalesced read); traffic_raw = (FETCH_SIZE + WRITE_SIZE) KiB; per-pattern calibration: profiles/probes/fetch_calib.hip")
+FETCH_CORRECTION_NOTE = ("traffic = (f x FETCH_SIZE + WRITE_SIZE) KiB with f calibrated per access pattern (profiles/probes/fetch_calib.hip, "
+                         "round 4): FETCH_SIZE counts 64 B per memory-side read request, so it is EXACT for the 32 / 64-byte segment reads of the "
+                         "MSDA kernels (f = 1: 2 B and 4 B per lane, 16 B per lane at row stride) and HALF of a wide coalesced 16-B-per-lane stream "
+                         "(128-byte requests: f = 2, the guide's gfx950 correction, used for the GEMM / LayerNorm kernels); traffic_raw = f = 1")
+# kernels whose reads are 32 / 64-byte segments of strided rows (calibrated: the raw counter is their real traffic)
+_FETCH_FACTOR_1 = ("msda_",)
 
 
-def pmc_traffic_bytes(tag, config="ycbv", fetch_factor=2.0):
+def pmc_traffic_bytes(tag, config="ycbv", fetch_factor=None):
+    if fetch_factor is None:
+        fetch_factor = 1.0 if tag.startswith(_FETCH_FACTOR_1) else 2.0
     tag = _pmc_key(tag)
     key = _PMC_NAMES.get(tag)
     _, rows = _pmc_rows(config, "hbm")

@@ -504,6 +504,41 @@ def test_arena_paths_match_plain_model_at_full_size(gpu):
     assert not bad, bad[:8]
 
 
+def test_decoder_value_gradient_bf16_atomics_with_piled_up_boxes(gpu, monkeypatch):
+    """in the bf16 policy the decoder's d(value) of all layers is scattered straight into bf16 token rows with packed
+    bf16x2 memory-side atomics (every contribution rounded to 8 mantissa bits, order dependent) instead of an fp32 staging map that
+    is rounded once.  Worst case for that: every object of the image has (almost) the SAME box, so all queries of all decoder layers
+    pile their 16 samples onto the same few pixels.  The encoder gradients -- everything downstream of d(memory) -- must stay as close
+    to the fp32 POLICY's as the fp32-staging variant (POET_DEC_DV_F32=1) does."""
+    import poet_amd
+    grads = {}
+    for mode in ("fp32", "bf16_atomics", "fp32_staging"):
+        if mode == "fp32_staging":
+            monkeypatch.setenv("POET_DEC_DV_F32", "1")
+        r = gpu("ycbv", 1, False, "fp32" if mode == "fp32" else "bf16", dropout=0.0)
+        model, crit = r["model"], r["crit"]
+        for t in r["targets"]:                                # all boxes on top of each other (1e-3 apart so that the matching stays unique)
+            n = t["boxes"].shape[0]
+            t["boxes"][:] = torch.tensor([0.5, 0.5, 0.2, 0.2], device=t["boxes"].device) + 1e-3 * torch.arange(n, device=t["boxes"].device)[:, None]
+        model.train()
+        tr = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, distributed=False)
+        tr.arena.zero_grad()
+        out, nb = model(r["samples"], r["targets"])
+        ls = crit(out, r["targets"], nb)
+        sum(ls[k] * crit.weight_dict[k] for k in ls if k in crit.weight_dict).backward()
+        torch.cuda.synchronize()
+        grads[mode] = {n: p._grad_view.detach().float().cpu().clone() for n, p in model.named_parameters() if getattr(p, "_grad_view", None) is not None}
+        monkeypatch.delenv("POET_DEC_DV_F32", raising=False)
+    names = [n for n in grads["fp32"] if n.startswith("transformer.encoder.") or n.startswith("input_proj.") or "cross_attn.value_proj" in n]
+    def l2(mode):
+        num = sum(float(((grads[mode][n] - grads["fp32"][n]).double() ** 2).sum()) for n in names)
+        den = sum(float((grads["fp32"][n].double() ** 2).sum()) for n in names)
+        return (num / max(den, 1e-30)) ** 0.5
+    a, b = l2("bf16_atomics"), l2("fp32_staging")
+    print(f"piled-up boxes, gradients downstream of d(memory) vs the fp32 policy (relative L2 over {len(names)} tensors): bf16 atomics {a:.4f}, fp32 staging {b:.4f}")
+    assert a < 1.25 * b + 2e-3, (a, b)
+
+
 def test_msdeformattn_dropin_matches_oracle(gpu):
     """`from deformable_attention import MSDeformAttn` -- same ctor/forward/parameter names as upstream's module."""
     from deformable_attention import MSDeformAttn
