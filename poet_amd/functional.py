@@ -502,15 +502,19 @@ class InputProjFn(torch.autograd.Function):
                     inp = torch.empty((N, d, Hp, Wp), dtype=act_dtype, device=src.device)
                     ops.tokens_to_nchw(src, inp, N, d, Hp * Wp, geom.starts[lvl - 1], S)
                 C, Hi, Wi = inp.shape[1:]
-                if split and inp.dtype == torch.float32 and ops.inproj_exact():
-                    # same as above for the 3x3 stride-2 convolution of the extra level: im2col in fp32, [hi | lo] rows, K = 18 C
+                if split and inp.dtype == torch.float32 and C % 16 == 0 and ops.inproj_exact():
+                    # the 3x3 stride-2 convolution of the extra level in fp32 end to end: a few hundred token rows (80 per image at
+                    # 640 x 480) with K = 9 C -- the latency-oriented fp32 kernels of the decoder (gemm_small.hip: <= 1024 rows per
+                    # call, the reduction split over the 4 waves of a workgroup) run it in ~30 us where the tiled bf16 kernel walks
+                    # 18 (with [hi | lo] rows: 36) dependent K stages on 80 workgroups (78-146 us)
                     col32 = torch.empty((N * HW, C * 9), dtype=torch.float32, device=src.device)
                     ops.im2col3x3s2(inp, col32, N, C, Hi, Wi, H, Wd)
-                    col = torch.empty((N * HW, C * 18), dtype=torch.bfloat16, device=src.device)
-                    ops.split_rows(col32, col)
                     pre32 = torch.empty((N, HW, d), dtype=torch.float32, device=src.device)
-                    Wc = W.view(d, C * 9)
-                    ops.linear_fwd(col, torch.cat([Wc, Wc], 1), b, pre32.view(N * HW, d), split=True)
+                    p2, Wc = pre32.view(N * HW, d), W.view(d, C * 9)
+                    for r0 in range(0, N * HW, 1024):
+                        ops.linear_fwd(col32[r0:r0 + 1024], Wc, b, p2[r0:r0 + 1024])
+                    col = torch.empty((N * HW, C * 9), dtype=torch.bfloat16, device=src.device)     # (backward's operand copy)
+                    ops.cast(col32, col)
                     stats = torch.empty((N, n_groups, 2), dtype=torch.float32, device=src.device)
                     ops.groupnorm_fwd(pre32, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S)
                     ops.cast(pre32, pre)
