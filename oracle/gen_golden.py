@@ -61,14 +61,14 @@ def _install_shims():
 
 
 def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
-               ref_points_mode="bbox", query_embedding_mode="bbox"):
+               ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine"):
     """Build the reference's own PoET around a Joiner-like synthetic backbone."""
     import torch.nn as nn
     import torch.nn.functional as F
     from models.deformable_transformer import DeformableTransformer
     from models.pose_estimation_transformer import PoET, SetCriterion
     from models.matcher import PoseMatcher
-    from models.position_encoding import PositionEmbeddingSine
+    from models.position_encoding import PositionEmbeddingSine, PositionEmbeddingLearned
     from util.misc import NestedTensor
     from oracle.poet_ref import build_weight_dict, losses_for
 
@@ -76,7 +76,13 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specifi
         def __init__(self):
             super().__init__()
             self.strides, self.num_channels = cfg["strides"], cfg["num_channels"]
-            self.pe = PositionEmbeddingSine(cfg["d_model"] // 2, normalize=True)
+            # (registered as "1" like the second entry of the reference's Joiner = nn.Sequential(backbone, position_embedding))
+            self.add_module("1", PositionEmbeddingLearned(cfg["d_model"] // 2) if position_embedding == "learned"
+                            else PositionEmbeddingSine(cfg["d_model"] // 2, normalize=True))
+
+        @property
+        def pe(self):
+            return self._modules["1"]
 
         def __getitem__(self, i):
             return self if i == 0 else self.pe
@@ -107,7 +113,7 @@ INIT_SEED = 4321
 
 
 def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class_mode="specific", rotation_mode="6d", aleatoric=False,
-               ref_points_mode="bbox", query_embedding_mode="bbox"):
+               ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine"):
     from oracle.formula import CONFIGS, formula_fill, make_inputs, make_samples, checksum
     from util.misc import nested_tensor_from_tensor_list
 
@@ -126,7 +132,8 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
             assert torch.equal(v, osd[k]), f"default init differs at {k}"
     else:
         model, crit = _ref_model(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode, rotation_mode=rotation_mode, aleatoric=aleatoric,
-                                 ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode)
+                                 ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode,
+                                 position_embedding=position_embedding)
         formula_fill(model)
     model.eval()
     crit.eval()
@@ -194,6 +201,8 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
             rec["aux_translation_aleatoric"] = np.stack([a["pred_translation_aleatoric"].detach().numpy() for a in out["aux_outputs"]])
             rec["pred_translation_aleatoric"] = out["pred_translation_aleatoric"].detach().numpy()
             rec["pred_rotation_aleatoric"] = out["pred_rotation_aleatoric"].detach().numpy()
+    if position_embedding != "sine":
+        tag += f"_pe{position_embedding}"
     np.savez_compressed(os.path.join(GOLD, f"poet_{tag}.npz"), **rec)
     print("wrote", tag, "loss", float(total))
 
@@ -340,6 +349,9 @@ def main():
         _run_model("lmo", 2, True, False)
         _run_model("hires", 1, False, False)
         return
+    if "--pelearned" in sys.argv:             # --position_embedding learned (main.py:67, position_encoding.py:87-112)
+        _run_model("tiny", 2, True, True, position_embedding="learned")
+        return
     if "--learned" in sys.argv:               # --query_embedding learned / --reference_points learned (main.py:76-79)
         _run_model("tiny", 2, True, True, query_embedding_mode="learned")
         _run_model("tiny", 2, True, True, query_embedding_mode="learned", ref_points_mode="learned")
@@ -370,6 +382,7 @@ def main():
     _run_model("tiny", 2, True, True, default_init=True)
     _run_model("tiny", 2, True, True, query_embedding_mode="learned")
     _run_model("tiny", 2, True, True, query_embedding_mode="learned", ref_points_mode="learned")
+    _run_model("tiny", 2, True, True, position_embedding="learned")
     _run_inference("tiny")
     _run_inference("cfg0")
     _run_matcher()

@@ -341,19 +341,45 @@ def rotation_6d_to_matrix(rot_6d):
     return torch.stack((x, y, z), dim=2).view(bs, nq, 3, 3)          # x,y,z are the COLUMNS
 
 
+class PositionEmbeddingLearned(nn.Module):
+    """models/position_encoding.py:87-112: learned absolute encoding, [col_embed(x) | row_embed(y)] per pixel (selected by
+    `--position_embedding learned`, position_encoding.py:115-127; nn.Embedding(50, .): feature maps up to 50 x 50)."""
+
+    def __init__(self, num_pos_feats=256):
+        super().__init__()
+        self.row_embed = nn.Embedding(50, num_pos_feats)
+        self.col_embed = nn.Embedding(50, num_pos_feats)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def forward(self, tensor_list):
+        x = tensor_list.tensors
+        h, w = x.shape[-2:]
+        x_emb = self.col_embed(torch.arange(w, device=x.device))
+        y_emb = self.row_embed(torch.arange(h, device=x.device))
+        pos = torch.cat([x_emb.unsqueeze(0).repeat(h, 1, 1), y_emb.unsqueeze(1).repeat(1, w, 1)], dim=-1)
+        return pos.permute(2, 0, 1).unsqueeze(0).repeat(x.shape[0], 1, 1, 1)
+
+
 class SyntheticBackbone(nn.Module):
     """Stands at the backbone interface (models/backbone.py:26-50 ``Joiner``): frozen, returns
     pre-made multi-scale feature maps as NestedTensors, their sine encodings, and the detections given at
     construction (``predictions``: per image None or rows (x0, y0, x1, y1, score, class) in pixels; None = a training
     backbone).  ``self[1]`` is the position embedding (pose_estimation_transformer.py:332)."""
 
-    def __init__(self, features: List[torch.Tensor], strides, num_channels, pos_feats=128, predictions=None):
+    def __init__(self, features: List[torch.Tensor], strides, num_channels, pos_feats=128, predictions=None, position_embedding="sine"):
         super().__init__()
         self.features = features
         self.predictions = predictions
         self.strides, self.num_channels = list(strides), list(num_channels)
-        self.position_embedding = PositionEmbeddingSine(pos_feats, normalize=True)
+        # registered as "1": the reference's Joiner is nn.Sequential(backbone, position_embedding), so a learned encoding's
+        # parameters are `backbone.1.row_embed.weight` / `backbone.1.col_embed.weight` (backbone.py:26-33)
+        self.add_module("1", PositionEmbeddingLearned(pos_feats) if position_embedding == "learned" else PositionEmbeddingSine(pos_feats, normalize=True))
         self.train_backbone = False
+
+    @property
+    def position_embedding(self):
+        return self._modules["1"]
 
     def __getitem__(self, idx):
         return self if idx == 0 else self.position_embedding
@@ -678,10 +704,11 @@ def param_groups(model, lr=2e-4, lr_backbone=2e-5, proj_names=("reference_points
 
 
 def build_poet(cfg, features, bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
-               ref_points_mode="bbox", query_embedding_mode="bbox"):
+               ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine"):
     """cfg: dict(d_model, nheads, enc_layers, dec_layers, d_ffn, n_levels, n_points, num_queries,
     n_classes, dropout, strides, num_channels)."""
-    bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions)
+    bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions,
+                           position_embedding=position_embedding)
     tr = DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"],
                                cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"])
     model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, class_mode, True,

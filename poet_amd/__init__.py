@@ -9,7 +9,7 @@ from ._lib import PoetHipError, load as load_library  # noqa: F401
 from .modules import (BoundingBoxEmbeddingSine, DeformableTransformer, DeformableTransformerDecoder,  # noqa: F401
                       DeformableTransformerDecoderLayer, DeformableTransformerEncoder,
                       DeformableTransformerEncoderLayer, MLP, MSDeformAttn, NestedTensor, PoET,
-                      PositionEmbeddingSine)
+                      PositionEmbeddingLearned, PositionEmbeddingSine)
 from .engine import (BucketReducer, losses_for, GraphedTrainer, GraphedInference, ParamArena, PoseMatcher, SetCriterion, Trainer,  # noqa: F401
                      build_weight_dict, reduce_dict)
 from .blocks import manual_seed  # noqa: F401

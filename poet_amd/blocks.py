@@ -287,8 +287,10 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
     return x2, x2_16, saved
 
 
-def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_level):
-    """G: GradSink; pre: name prefix of this layer's params.  Returns d(src)."""
+def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_level, dpos=None):
+    """G: GradSink; pre: name prefix of this layer's params.  Returns d(src).  dpos: optional (N*S, d) fp32 OUTPUT that receives
+    d(src + pos) of this layer's offsets | logits projection -- the gradient of a learned position encoding (then the query
+    gradient is its own product instead of a block of the stacked K = 1024 one)."""
     S, d = geom.S, dx2.shape[1]
     D = d // M
     pd, seeds = sv["pd"], sv["seeds"]
@@ -308,7 +310,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
     seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
     so_w = P_["self_attn.sampling_offsets.weight"]
     tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and sv["V"].dtype == torch.bfloat16 else None
-    if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d):
+    if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d or dpos is not None):
         tri = None
     G2 = None
     if tri is not None:
@@ -320,7 +322,10 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
                sv["V"], geom, ref, ref_bs, N, S, M, D, npts, dV,
                g("self_attn.sampling_offsets.weight"), g("self_attn.sampling_offsets.bias"),
                g("self_attn.attention_weights.weight"), g("self_attn.attention_weights.bias"),
-               None if G2 is not None else dsrc, True, seg_sums=seg, grid_queries=True, dOA=None if G2 is None else G2[:, : 3 * mlp])
+               None if G2 is not None else (dsrc if dpos is None else dpos), dpos is None, seg_sums=seg, grid_queries=True,
+               dOA=None if G2 is None else G2[:, : 3 * mlp])
+    if dpos is not None:                      # d(q) went to its own buffer: q = src + pos, so it is d(pos) and one more term of d(src)
+        ops.add(dsrc, dpos, dsrc)
     # d(level_embed)[l] += colsum_l(dOA) @ [W_so ; W_aw]   (pos = sine + level_embed, q = src + pos)
     if g_level is not None:
         so_w, aw_w = P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"]

@@ -18,7 +18,9 @@ from . import ops
 
 ALIGN = 64   # elements (256 B): every parameter starts on a 16-B-aligned, vector-friendly offset
 # parameter-name prefixes of the hot path (pose_estimation_transformer.py:85-144 heads / input_proj; the transformer)
-HOT_PREFIXES = ("input_proj.", "transformer.", "translation_head", "rotation_head", "query_embed.")
+HOT_PREFIXES = ("input_proj.", "transformer.", "translation_head", "rotation_head", "query_embed.", "backbone.1.")
+# ("backbone.1." = the Joiner's position embedding when it is a learned one (position_encoding.py:87-112): trained by the path's
+# own backward (functional.PosEmbedFn); like every "backbone" parameter it steps at lr_backbone, main.py:253-271)
 
 
 _ENC_LAYER = re.compile(r"^transformer\.encoder\.layers\.(\d+)\.")
@@ -54,7 +56,7 @@ class ParamArena:
     """
 
     def __init__(self, model: nn.Module, lr=2e-4, lr_proj_mult=0.1, proj_names=("reference_points", "sampling_offsets"),
-                 weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, exclude=("transformer.reference_points",)):
+                 weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, exclude=("transformer.reference_points",), lr_backbone_mult=0.1):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not any(e in n for e in exclude)]
         # Only the hot path's own parameters live here (their gradients are written by the HIP backward programs).  Anything
         # else that is trainable -- e.g. a real backbone, which the reference trains at lr_backbone (main.py:253-271) -- would
@@ -116,7 +118,7 @@ class ParamArena:
                 cur, start = b, off
             self.entries.append((n, p, off))
             size = -(-p.numel() // ALIGN) * ALIGN
-            scale += [lr_proj_mult if is_proj(n) else 1.0] * (size // ALIGN)
+            scale += [lr_proj_mult if is_proj(n) else (lr_backbone_mult if n.startswith("backbone.") else 1.0)] * (size // ALIGN)
             off += size
         self.buckets.append((cur, start, off))
         self.n_main = off
@@ -893,6 +895,10 @@ class GraphedTrainer(Trainer):
         # in ONE collective behind it (BucketReducer.finish() coalesces every un-announced range) -- no per-bucket segments (they
         # cost ~0.25 ms per step at one rank and buy only overlap); the default keeps one segment per bucket.
         self.single_collective = self.segment_backward and os.environ.get("POET_DP_SINGLE_COLLECTIVE", "0") not in ("", "0")
+        if self.segment_backward and any(n.startswith("backbone.1.") for n, _, _ in self.arena.entries):
+            raise NotImplementedError("GraphedTrainer: a learned position encoding (backbone.1.*) with per-bucket backward segments "
+                                      "(world > 1 / POET_SEGMENT_BWD): its gradient node hangs off every encoder layer; use the eager "
+                                      "Trainer for data-parallel runs of that mode")
         if not self.segment_backward and self.reducer is not None and self.reducer.active:
             raise ValueError("GraphedTrainer: world > 1 needs segment_backward=True (the single backward graph contains no "
                              "all-reduce: the replicas would drift apart silently)")

@@ -75,10 +75,8 @@ class EncoderLayerFn(torch.autograd.Function):
         the previous layer's last LayerNorm already produced it (else None); pos2 (N*S,d); ref (N,S,L,2) fp32; mask (N*S) uint8
         or None; cfg dict(M,P,p,training,n_layers,act,split,N).  Returns (y, y16, q_next): q_next = y + pos for the next layer
         (an empty tensor when not produced)."""
-        if pos2.requires_grad:
-            raise NotImplementedError("EncoderLayerFn: a position embedding that requires grad (learned positional encoding) is not "
-                                      "supported: its gradient would be dropped silently (only level_embed is differentiated)")
         N, S = cfg["N"], geom.S
+        ctx.need_pos, ctx.pos_dtype = pos2.requires_grad, pos2.dtype          # a learned position encoding (position_encoding.py:87-112): backward returns d(pos)
         P_ = _pdict(names, params, "")
         emit = idx + 1 < cfg["n_layers"]
         out = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
@@ -102,14 +100,17 @@ class EncoderLayerFn(torch.autograd.Function):
             raise RuntimeError("EncoderLayerFn.backward: no gradient for the layer output")
         G = B.GradSink(list(names) + ["level_embed"], list(params) + [ctx.level_embed])
         g_level = G("level_embed") if ctx.level_embed.requires_grad else None
+        dpos = torch.empty((N * S, dy.shape[1]), dtype=torch.float32, device=dy.device) if ctx.need_pos else None
         dx = B.enc_layer_bwd(dy.contiguous(), ctx.saved, _pdict(names, params, ""), G, "", ctx.ref, S * geom.L * 2, ctx.mask, geom,
-                             N, cfg["M"], cfg["P"], g_level)
+                             N, cfg["M"], cfg["P"], g_level, dpos=dpos)
         ctx.saved = None
         ops.SIDE.join()
         announce(enc_bucket_tag(cfg["n_layers"], i))
         if i == 0:
             announce("2_encoder_99")                      # level_embed (+ anything of the encoder outside its layers)
-        return (dx if ctx.need_x else None, None, None, None, G.ret[-1], None, None, None, None, None, None, *G.ret[:-1])
+        if dpos is not None and dpos.dtype != ctx.pos_dtype:
+            dpos = dpos.to(ctx.pos_dtype)
+        return (dx if ctx.need_x else None, None, None, dpos, G.ret[-1], None, None, None, None, None, None, *G.ret[:-1])
 
 
 def encoder_forward(src, pos, level_embed, ref, mask, geom, cfg, layers_named):
@@ -162,6 +163,39 @@ class QueryEmbedFn(torch.autograd.Function):
         if dtgt is not None:
             gw[:, d:] += dtgt.sum(0)
         return G.ret[0], None
+
+
+class PosEmbedFn(torch.autograd.Function):
+    """Learned position encoding (models/position_encoding.py:87-112) as token rows: pos[n, start_l + y W_l + x] =
+    [col_embed[x] | row_embed[y]] + level_embed[l] for every image.  A node of its own for the reason QueryEmbedFn is one: the
+    tables' gradients -- d(pos) summed over the batch, then over the rows / columns of every level -- go straight into their
+    gradient views (arena or autograd) instead of through AccumulateGrad nodes."""
+
+    @staticmethod
+    def forward(ctx, row_w, col_w, level_embed, shapes, N, dtype):
+        ctx.row_w, ctx.col_w, ctx.shapes = row_w, col_w, shapes
+        rw, cw = row_w.detach(), col_w.detach()
+        rows = []
+        for l, (h, w) in enumerate(shapes):
+            if h > rw.shape[0] or w > cw.shape[0]:
+                raise ValueError(f"PositionEmbeddingLearned: a {h} x {w} feature map exceeds the {rw.shape[0]}-entry tables "
+                                 "(models/position_encoding.py:93-94)")
+            rows.append(torch.cat([cw[:w][None].expand(h, -1, -1), rw[:h][:, None].expand(-1, w, -1)], -1).reshape(h * w, -1) + level_embed[l])
+        return torch.cat(rows, 0)[None].expand(N, -1, -1).to(dtype).contiguous()
+
+    @staticmethod
+    def backward(ctx, dpos):
+        G = B.GradSink(["row", "col"], [ctx.row_w, ctx.col_w])
+        gr, gc = G("row"), G("col")
+        F_ = gc.shape[1]
+        d = dpos.float().sum(0)                                   # (S, 2F)
+        o = 0
+        for h, w in ctx.shapes:
+            blk = d[o:o + h * w].view(h, w, 2 * F_)
+            gc[:w] += blk[..., :F_].sum(0)
+            gr[:h] += blk[..., F_:].sum(1)
+            o += h * w
+        return G.ret[0], G.ret[1], None, None, None, None
 
 
 _WH_CACHE = {}

@@ -122,6 +122,35 @@ class PositionEmbeddingSine(nn.Module):
         return out
 
 
+class PositionEmbeddingLearned(nn.Module):
+    """models/position_encoding.py:87-112 (`--position_embedding learned`, position_encoding.py:115-127): [col_embed(x) | row_embed(y)]
+    per pixel; nn.Embedding(50, .) tables, so feature maps up to 50 x 50.  `forward` returns NCHW like the reference; PoET itself
+    takes `tokens(h, w)` -- the (h w, 2 F) token-major rows, differentiable -- and the encoder's backward returns d(pos) (the sum
+    over layers of d(src + pos), blocks.enc_layer_bwd) so that the tables train."""
+
+    def __init__(self, num_pos_feats=256):
+        super().__init__()
+        self.row_embed = nn.Embedding(50, num_pos_feats)
+        self.col_embed = nn.Embedding(50, num_pos_feats)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def tokens(self, h: int, w: int):
+        if h > self.row_embed.num_embeddings or w > self.col_embed.num_embeddings:
+            raise ValueError(f"PositionEmbeddingLearned: a {h} x {w} feature map exceeds the {self.row_embed.num_embeddings}-entry tables "
+                             "(models/position_encoding.py:93-94)")
+        x_emb, y_emb = self.col_embed.weight[:w], self.row_embed.weight[:h]
+        return torch.cat([x_emb[None].expand(h, -1, -1), y_emb[:, None].expand(-1, w, -1)], dim=-1).reshape(h * w, -1)
+
+    def forward(self, tensor_list: NestedTensor):
+        x = tensor_list.tensors
+        h, w = x.shape[-2:]
+        return self.tokens(h, w).view(h, w, -1).permute(2, 0, 1)[None].expand(x.shape[0], -1, -1, -1).contiguous()
+
+
 class BoundingBoxEmbeddingSine(nn.Module):
     """models/position_encoding.py:63-84."""
 
@@ -501,10 +530,16 @@ class PoET(nn.Module):
         names, params = _named(self.input_proj)
         src = Fn.InputProjFn.apply(feats, geom, 32, (act, stream, tr.split_w), names, *params)
         self._last_src = src                          # autograd-node boundaries: the graphed trainer splits backward here
-        pos = torch.empty((N, geom.S, self.hidden_dim), dtype=act, device=dev)
         lvl_embed = tr.level_embed.detach().contiguous()
-        for l, (h, w) in enumerate(geom.shapes):
-            ops.pos_sine(masks[l], pos, lvl_embed[l], N, h, w, self.hidden_dim // 2, geom.starts[l], geom.S)
+        pe = self.backbone[1] if hasattr(self.backbone, "__getitem__") else None
+        if isinstance(pe, PositionEmbeddingLearned):
+            # learned encoding (position_encoding.py:87-112): token rows from the embedding tables (Fn.PosEmbedFn); every encoder layer
+            # hands back d(pos), level_embed keeps its own gradient path (added here as a constant)
+            pos = Fn.PosEmbedFn.apply(pe.row_embed.weight, pe.col_embed.weight, lvl_embed, tuple(geom.shapes), N, act)
+        else:
+            pos = torch.empty((N, geom.S, self.hidden_dim), dtype=act, device=dev)
+            for l, (h, w) in enumerate(geom.shapes):
+                ops.pos_sine(masks[l], pos, lvl_embed[l], N, h, w, self.hidden_dim // 2, geom.starts[l], geom.S)
         ref_pts = boxes[:, :, :2].contiguous() if self.ref_points_mode == "bbox" else None      # :337-340
         if self.query_embedding_mode == "learned":     # :342-343 and deformable_transformer.py:150-155: (query_pos | tgt) rows, same for every image
             qpos, tgt = Fn.QueryEmbedFn.apply(self.query_embed.weight, N)

@@ -11,18 +11,24 @@ import torch
 from torch import nn
 
 from . import ops
-from .modules import NestedTensor, PositionEmbeddingSine
+from .modules import NestedTensor, PositionEmbeddingLearned, PositionEmbeddingSine
 
 
 class SyntheticBackbone(nn.Module):
     def __init__(self, features: List[torch.Tensor], strides: Sequence[int], num_channels: Sequence[int], pos_feats: int = 128,
-                 predictions=None):
+                 predictions=None, position_embedding: str = "sine"):
         super().__init__()
         self.features = features
         self.predictions = predictions
         self.strides, self.num_channels = list(strides), list(num_channels)
-        self.position_embedding = PositionEmbeddingSine(pos_feats, normalize=True)
+        # registered as "1" -- the reference's Joiner is nn.Sequential(backbone, position_embedding) (backbone.py:26-33), so the
+        # state_dict keys of a learned encoding are backbone.1.row_embed.weight / backbone.1.col_embed.weight
+        self.add_module("1", PositionEmbeddingLearned(pos_feats) if position_embedding == "learned" else PositionEmbeddingSine(pos_feats, normalize=True))
         self.train_backbone = False
+
+    @property
+    def position_embedding(self):
+        return self._modules["1"]
 
     def __getitem__(self, idx):
         return self if idx == 0 else self.position_embedding

@@ -10,13 +10,14 @@ INIT_SEED = 4321      # oracle/gen_golden.py: seed of the reference's own defaul
 
 
 def run_oracle(name, batch, pad, seed=1234, backward=True, train=False, default_init=False, bbox_mode="gt", class_mode="specific",
-               rotation_mode="6d", aleatoric=False, ref_points_mode="bbox", query_embedding_mode="bbox"):
+               rotation_mode="6d", aleatoric=False, ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine"):
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
     if default_init:
         torch.manual_seed(INIT_SEED)
     model, crit = poet_ref.build_poet(cfg, feats, bbox_mode=bbox_mode, class_mode=class_mode, rotation_mode=rotation_mode, aleatoric=aleatoric,
-                                      ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode)
+                                      ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode,
+                                      position_embedding=position_embedding)
     if not default_init:
         formula_fill(model)
     model.train(train)

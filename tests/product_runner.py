@@ -8,14 +8,15 @@ from oracle.formula import CONFIGS, formula_fill, make_inputs
 
 def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False,
                   bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
-                  ref_points_mode="bbox", query_embedding_mode="bbox"):
+                  ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine"):
     if not isinstance(precision, str):
         precision = "fp32" if precision == torch.float32 else "bf16"
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
     fd = feat_dtype or torch.float32
     gfeats = [f.cuda().to(fd) for f in feats]
-    bb = SyntheticBackbone(gfeats, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions)
+    bb = SyntheticBackbone(gfeats, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions,
+                           position_embedding=position_embedding)
     p = cfg["dropout"] if dropout is None else dropout
     if default_init:
         torch.manual_seed(4321)          # oracle/gen_golden.py INIT_SEED: the reference's own init order

@@ -141,6 +141,63 @@ def test_modes_fp32_vs_reference_golden(gpu, golden_dir, bbox_mode, class_mode):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("precision,tol,gtol", [("fp32", 1e-3, 3e-3), ("bf16", 1e-2, 8e-2)])
+def test_learned_position_embedding_vs_reference_golden(gpu, golden_dir, precision, tol, gtol):
+    """--position_embedding learned (main.py:67; position_encoding.py:87-112) on the HIP path: PoET takes the token rows of
+    backbone[1] (a poet_amd.PositionEmbeddingLearned, state_dict keys backbone.1.* like the reference's Joiner) through autograd,
+    and every encoder layer's backward returns d(pos) = d(src + pos) of its offsets | logits projection.  Poses, losses and every
+    gradient checksum incl. the two embedding tables against the real reference run in that mode."""
+    g = np.load(os.path.join(golden_dir, "poet_tiny_b2_pad_pelearned.npz"))
+    r = gpu("tiny", 2, True, precision, position_embedding="learned")
+    model, crit = r["model"], r["crit"]
+    model.eval()
+    out, n_boxes = model(r["samples"], r["targets"])
+    dt = (out["pred_translation"].float().cpu() - torch.from_numpy(g["pred_translation"])).abs().max().item()
+    dr = (out["pred_rotation"].float().cpu() - torch.from_numpy(g["pred_rotation"])).abs().max().item()
+    assert dt < tol and dr < tol, (dt, dr)
+    losses = crit(out, r["targets"], n_boxes)
+    names = sorted(losses)
+    assert names == [str(x) for x in g["loss_names"]]
+    np.testing.assert_allclose([float(losses[k]) for k in names], g["loss_values"], rtol=2e-4 if precision == "fp32" else 2e-2, atol=2e-5)
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    model.zero_grad()
+    total.backward()
+    params = dict(model.named_parameters())
+    assert sorted(params) == sorted(str(n) for n in g["grad_names"])          # incl. backbone.1.row_embed.weight / col_embed.weight
+    bad = []
+    for n, ref in zip(g["grad_names"], g["grad_checksums"]):
+        p = params[str(n)]
+        if np.isnan(ref).all():
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        got = checksum(p.grad.float().cpu())
+        if not np.allclose(got, ref, atol=gtol * max(1.0, abs(ref[0]))):
+            bad.append((str(n), float(np.abs(got - ref).max()), float(ref[0])))
+    assert not bad, bad[:10]
+    assert float(params["backbone.1.row_embed.weight"].grad.abs().max()) > 0
+    if precision == "bf16":
+        # training: the arena takes the two tables in (they step at the backbone learning rate, main.py:253-271); HIP-graph replay
+        # == eager at frozen parameters, and a real step moves them
+        import poet_amd
+        runs = {}
+        for mode in ("eager", "graph"):
+            rr = gpu("tiny", 2, True, "bf16", dropout=0.0, position_embedding="learned")
+            rr["model"].train()
+            cls = poet_amd.Trainer if mode == "eager" else poet_amd.GraphedTrainer
+            tr = cls(rr["model"], rr["crit"], lr=0.0, weight_decay=1e-4, max_norm=0.1, **({} if mode == "eager" else dict(warm=1)))
+            runs[mode] = [float(tr.step(rr["samples"], rr["targets"])[0]) for _ in range(3)]
+            assert any(n.startswith("backbone.1.") for n, _, _ in tr.arena.entries)
+        assert runs["graph"] == pytest.approx(runs["eager"], rel=1e-4, abs=1e-4), runs
+        rr = gpu("tiny", 2, True, "bf16", dropout=0.0, position_embedding="learned")
+        rr["model"].train()
+        w0 = rr["model"].backbone[1].row_embed.weight.detach().clone()
+        tr = poet_amd.Trainer(rr["model"], rr["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+        tr.step(rr["samples"], rr["targets"])
+        moved = (rr["model"].backbone[1].row_embed.weight.detach() - w0).abs().max().item()
+        assert 0 < moved <= 2e-5 * 1.05 + 1e-4 * 2e-5, moved          # one AdamW step at lr_backbone = 0.1 lr
+
+
 @pytest.mark.parametrize("qmode,rmode", [("learned", "bbox"), ("learned", "learned")])
 def test_learned_queries_fp32_vs_reference_golden(gpu, golden_dir, qmode, rmode):
     """--query_embedding learned / --reference_points learned (main.py:76-79; pose_estimation_transformer.py:149-150,342-343,

@@ -177,6 +177,28 @@ def test_poet_learned_queries_vs_reference(golden_dir, qmode, rmode):
     assert got_ref_grad == (rmode == "learned")
 
 
+def test_poet_learned_position_embedding_vs_reference(golden_dir):
+    """--position_embedding learned (main.py:67; position_encoding.py:87-112: [col_embed(x) | row_embed(y)], the second entry of
+    the reference's Joiner, state_dict keys backbone.1.*): outputs, losses and gradient checksums -- incl. the two embedding
+    tables' -- equal the real reference's."""
+    g = _load(golden_dir, "poet_tiny_b2_pad_pelearned.npz")
+    r = run_oracle("tiny", 2, True, position_embedding="learned")
+    np.testing.assert_allclose(r["out"]["pred_translation"].detach().numpy(), g["pred_translation"], rtol=1e-5, atol=ATOL)
+    np.testing.assert_allclose(r["out"]["pred_rotation"].detach().numpy(), g["pred_rotation"], rtol=1e-5, atol=ATOL)
+    names = sorted(r["losses"])
+    assert names == list(g["loss_names"])
+    np.testing.assert_allclose([float(r["losses"][k]) for k in names], g["loss_values"], rtol=1e-5, atol=1e-6)
+    grads = dict(r["model"].named_parameters())
+    assert sorted(grads) == sorted(str(n) for n in g["grad_names"])
+    for n, cs in zip(g["grad_names"], g["grad_checksums"]):
+        p = grads[str(n)]
+        if np.isnan(cs[0]):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+        else:
+            np.testing.assert_allclose(checksum(p.grad), cs, rtol=2e-4, atol=2e-6, err_msg=str(n))
+    assert float(grads["backbone.1.row_embed.weight"].grad.abs().max()) > 0 and float(grads["backbone.1.col_embed.weight"].grad.abs().max()) > 0
+
+
 @pytest.mark.parametrize("rotation_mode,aleatoric", [("quat", False), ("silho_quat", False), ("6d", True)])
 def test_poet_rotation_modes_vs_reference(golden_dir, rotation_mode, aleatoric):
     """Quaternion representations (4-wide rotation heads, L2-normalised; losses -log(<q,q*>^2 + eps) and log(1 - |<q,q*>| + eps),
