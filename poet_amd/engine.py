@@ -888,17 +888,23 @@ class GraphedTrainer(Trainer):
         self.arena.world = self.world
         self.warm, self.calls, self.ready = warm, 0, False
         self.persistent_inputs = bool(persistent_inputs)
-        if segment_backward is None:         # per-bucket backward graphs: needed (only) to overlap all-reduces with backward
+        explicit = segment_backward is not None or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
+        if segment_backward is None:         # backward outside the optimiser graph: needed (only) to put all-reduces between them
             segment_backward = (self.reducer is not None and self.reducer.active) or os.environ.get("POET_SEGMENT_BWD", "0") not in ("", "0")
         self.segment_backward = bool(segment_backward)
-        # POET_DP_SINGLE_COLLECTIVE=1: backward stays ONE graph (without the optimiser) and the whole gradient arena is all-reduced
-        # in ONE collective behind it (BucketReducer.finish() coalesces every un-announced range) -- no per-bucket segments (they
-        # cost ~0.25 ms per step at one rank and buy only overlap); the default keeps one segment per bucket.
-        self.single_collective = self.segment_backward and os.environ.get("POET_DP_SINGLE_COLLECTIVE", "0") not in ("", "0")
-        if self.segment_backward and any(n.startswith("backbone.1.") for n, _, _ in self.arena.entries):
+        # Default at world > 1: backward stays ONE graph (without the optimiser) and the whole gradient arena is all-reduced in ONE
+        # collective behind it (BucketReducer.finish() coalesces every un-announced range).  POET_DP_SINGLE_COLLECTIVE=0 selects one
+        # backward segment + one all-reduce per bucket (heads, decoder, every encoder layer, input_proj) on the comm stream instead:
+        # measured on this stack (round 4, 1-rank RCCL group) the segments cost +0.19 ms per step over the single
+        # collective (13.75 against 13.56 ms; 13.50 without collectives) and a kernel trace shows NO kernel of the comm queue ever
+        # running concurrently with a compute-queue kernel, so the segments buy no overlap here.
+        # (an explicit segment_backward=True / POET_SEGMENT_BWD=1 asks for the per-bucket segments; the environment switch wins)
+        sc = os.environ.get("POET_DP_SINGLE_COLLECTIVE")
+        self.single_collective = self.segment_backward and ((sc not in ("", "0")) if sc is not None else not explicit)
+        if self.segment_backward and not self.single_collective and any(n.startswith("backbone.1.") for n, _, _ in self.arena.entries):
             raise NotImplementedError("GraphedTrainer: a learned position encoding (backbone.1.*) with per-bucket backward segments "
-                                      "(world > 1 / POET_SEGMENT_BWD): its gradient node hangs off every encoder layer; use the eager "
-                                      "Trainer for data-parallel runs of that mode")
+                                      "(POET_DP_SINGLE_COLLECTIVE=0): its gradient node hangs off every encoder layer; use the default "
+                                      "single-collective mode or the eager Trainer for data-parallel runs of that mode")
         if not self.segment_backward and self.reducer is not None and self.reducer.active:
             raise ValueError("GraphedTrainer: world > 1 needs segment_backward=True (the single backward graph contains no "
                              "all-reduce: the replicas would drift apart silently)")

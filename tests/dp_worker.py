@@ -13,8 +13,10 @@ import torch.distributed as dist
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     graphed = sys.argv[5] in ("graph", "graph1")
-    if sys.argv[5] == "graph1":                    # ONE backward graph + ONE all-reduce of the whole gradient arena
-        os.environ["POET_DP_SINGLE_COLLECTIVE"] = "1"
+    # "graph1": ONE backward graph + ONE all-reduce of the whole gradient arena (the default at world > 1);
+    # "graph": one backward segment + one all-reduce per bucket on the comm stream (POET_DP_SINGLE_COLLECTIVE=0)
+    if graphed:
+        os.environ["POET_DP_SINGLE_COLLECTIVE"] = "1" if sys.argv[5] == "graph1" else "0"
     backend = sys.argv[6] if len(sys.argv) > 6 else "gloo"
     arith = len(sys.argv) > 7 and sys.argv[7] == "arith"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))

@@ -1059,15 +1059,16 @@ def test_bf16_full_size_seed_sweep(gpu, input_seed, init_seed, conditioned):
         assert mxa < TOL_BF16, (dt, rms, mx, mxa)
 
 
-@pytest.mark.parametrize("mode", ["graph", "eager"])
+@pytest.mark.parametrize("mode", ["graph", "graph1", "eager"])
 def test_data_parallel_two_ranks_one_gpu(gpu, tmp_path, mode):
-    """The world > 1 path end to end (initial broadcast, bucket reducer in the eager warm-up, per-node backward graphs with
-    a bucket all-reduce after each segment, optimiser graph): two ranks share cuda:0 and talk over gloo (RCCL needs one
+    """The world > 1 path end to end (initial broadcast, bucket reducer in the eager warm-up, optimiser graph; "graph1" = the default:
+    one backward graph + ONE all-reduce of the whole arena, "graph" = POET_DP_SINGLE_COLLECTIVE=0: per-node backward graphs with
+    a bucket all-reduce after each segment): two ranks share cuda:0 and talk over gloo (RCCL needs one
     GPU per rank).  Ranks see different data and rank 1 starts from perturbed weights; afterwards their parameters must be
     bit-identical, finite, and different from the initial weights."""
     import subprocess, sys as _sys
     here = os.path.dirname(os.path.abspath(__file__))
-    port = str(29600 + (os.getpid() % 300) + (0 if mode == "graph" else 400))
+    port = str(29600 + (os.getpid() % 300) + {"graph": 0, "graph1": 350, "eager": 700}[mode])
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
     procs = [subprocess.Popen([_sys.executable, os.path.join(here, "dp_worker.py"), str(r), "2", port, outs[r], mode],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
@@ -1283,7 +1284,7 @@ def test_images_without_objects(gpu):
     assert np.isfinite(float(total))
 
 
-@pytest.mark.parametrize("mode", ["graph", "eager"])
+@pytest.mark.parametrize("mode", ["graph", "graph1", "eager"])
 def test_rccl_code_path_one_rank(gpu, tmp_path, mode):
     """The data-parallel machinery over the real backend ('nccl' == RCCL): a 1-rank process group with
     POET_FORCE_COLLECTIVES=1 runs the broadcast, the bucket all-reduces on the comm stream and the segmented backward
@@ -1293,7 +1294,7 @@ def test_rccl_code_path_one_rank(gpu, tmp_path, mode):
     import poet_amd
     from oracle.formula import CONFIGS, make_inputs
     here = os.path.dirname(os.path.abspath(__file__))
-    port = str(29000 + (os.getpid() % 300) + (0 if mode == "graph" else 400))
+    port = str(29000 + (os.getpid() % 300) + {"graph": 0, "graph1": 350, "eager": 700}[mode])
     out = str(tmp_path / "rank0.npz")
     env = dict(os.environ, POET_FORCE_COLLECTIVES="1")
     p = subprocess.run([_sys.executable, os.path.join(here, "dp_worker.py"), "0", "1", port, out, mode, "nccl"],
@@ -1302,8 +1303,8 @@ def test_rccl_code_path_one_rank(gpu, tmp_path, mode):
     a = np.load(out)
     r = gpu("tiny", 2, True, "bf16", dropout=0.0, seed=1234)
     r["model"].train()
-    if mode == "graph":
-        tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1, segment_backward=True)
+    if mode.startswith("graph"):        # (the comparison run: per-bucket segments for "graph", the single backward graph for "graph1")
+        tr = poet_amd.GraphedTrainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1, segment_backward=(mode == "graph"))
     else:
         tr = poet_amd.Trainer(r["model"], r["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
     losses = []
