@@ -30,7 +30,7 @@
  *       nn.MultiheadAttention core over <=64 queries (deformable_transformer.py:277-278).
  *   poet_pos_sine / poet_bbox_sine
  *       models/position_encoding.py:40-60 and :71-84.
- *   poet_groupnorm_* / poet_im2col3x3s2 / poet_nchw_to_tokens / poet_tokens_to_nchw
+ *   poet_groupnorm_* / poet_im2col3x3s2 / poet_col2im3x3s2_add / poet_nchw_to_tokens / poet_tokens_to_nchw
  *       input_proj and the flatten/transposes (pose_estimation_transformer.py:100-135,313-335;
  *       deformable_transformer.py:128-141).
  *   poet_enc_ref_points        deformable_transformer.py:217-230.
@@ -294,6 +294,11 @@ int poet_tokens_to_nchw(const void* src, void* dst, int N, int C, int HW, int64_
  * k = c*9 + ky*3 + kx (the flattening of nn.Conv2d's weight). */
 int poet_im2col3x3s2(const void* src, void* dst, int N, int C, int H, int W, int Ho, int Wo,
                      int src_dtype, int dst_dtype, void* stream);
+/* its adjoint, for the input gradient of a second (third, ...) extra level whose input is the previous PROJECTED level
+ * (pose_estimation_transformer.py:327-330): dcol (N*Ho*Wo, C*9) -> ADDED into rows [tok_off, tok_off + H*W) of the
+ * token-major stream gradient dst (N, tok_stride, C). */
+int poet_col2im3x3s2_add(const void* dcol, void* dst, int N, int C, int H, int W, int Ho, int Wo, int64_t tok_off,
+                         int64_t tok_stride, int src_dtype, int dst_dtype, void* stream);
 
 /* GroupNorm over token-major maps.  x (and dx) live at rows [x_off, x_off+HW) of (N, x_stride, C);
  * y (and dy) at rows [y_off, y_off+HW) of (N, y_stride, C) -- so the conv output can stay compact

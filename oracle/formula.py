@@ -22,6 +22,12 @@ CONFIGS = {
     "tiny": dict(d_model=64, nheads=4, enc_layers=2, dec_layers=2, d_ffn=128, n_levels=3, n_points=4,
                  num_queries=6, n_classes=5, dropout=0.1, strides=[8, 16], num_channels=[32, 48],
                  image_hw=(96, 128), level_hw=[(12, 16), (6, 8), (3, 4)], batch=2),
+    # free parameters of the reference's CLI outside the defaults (main.py:71,100-101): 5 feature levels = 3 backbone maps + TWO
+    # chained 3x3-s2 extra levels (pose_estimation_transformer.py:322-330: the second one reads the first's PROJECTED output) and 3
+    # sampling points: served by the generic MSDA kernels and the chained input-projection backward
+    "tiny5": dict(d_model=64, nheads=4, enc_layers=2, dec_layers=2, d_ffn=128, n_levels=5, n_points=3,
+                  num_queries=6, n_classes=5, dropout=0.1, strides=[8, 16, 32], num_channels=[32, 48, 40],
+                  image_hw=(96, 128), level_hw=[(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)], batch=2),
     # BASELINE.json configs[1]/[2]: YCB-V
     "ycbv": dict(d_model=256, nheads=16, enc_layers=5, dec_layers=5, d_ffn=1024, n_levels=4, n_points=4,
                  num_queries=20, n_classes=21, dropout=0.1, strides=[8, 16, 32], num_channels=[256, 256, 256],

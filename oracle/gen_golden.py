@@ -362,6 +362,9 @@ def main():
         _run_model("hires", 1, False, False, default_init=True)
         _run_model("lmo", 3, True, False)
         return
+    if "--levels" in sys.argv:                # 5 feature levels (two chained extra levels) x 3 sampling points
+        _run_model("tiny5", 2, True, True)
+        return
     if "--modes" in sys.argv:                 # only the jitter / class-agnostic goldens
         _run_model("tiny", 2, True, True, bbox_mode="jitter", class_mode="specific")
         _run_model("tiny", 2, True, True, bbox_mode="gt", class_mode="agnostic")
@@ -383,6 +386,7 @@ def main():
     _run_model("tiny", 2, True, True, query_embedding_mode="learned")
     _run_model("tiny", 2, True, True, query_embedding_mode="learned", ref_points_mode="learned")
     _run_model("tiny", 2, True, True, position_embedding="learned")
+    _run_model("tiny5", 2, True, True)
     _run_inference("tiny")
     _run_inference("cfg0")
     _run_matcher()

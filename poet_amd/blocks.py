@@ -310,7 +310,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
     seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
     so_w = P_["self_attn.sampling_offsets.weight"]
     tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and sv["V"].dtype == torch.bfloat16 else None
-    if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d or dpos is not None):
+    if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d or dpos is not None or (3 * mlp) % 8 != 0):
         tri = None
     G2 = None
     if tri is not None:

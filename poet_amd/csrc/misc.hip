@@ -200,6 +200,35 @@ __global__ __launch_bounds__(256) void im2col_kernel(const S* __restrict__ src, 
     io<D>::st(dst + t, v);
 }
 
+// adjoint of the above for a SECOND (third, ...) extra level, whose input is the previous projected level (reference:
+// pose_estimation_transformer.py:327-330, `self.input_proj[lvl](srcs[-1])`): d(input pixel) = sum of the <= 4 im2col entries
+// that read it, ADDED to the token rows [tok_off, tok_off + H W) of the (N, tok_stride, C) stream gradient -- a gather per
+// input element, no atomics.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void col2im_add_kernel(const S* __restrict__ dcol, D* __restrict__ dst, int C, int H, int W,
+                                                         int Ho, int Wo, int64_t tok_off, int64_t tok_stride, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C);
+    const int64_t pix = t / C;
+    const int n = (int)(pix / ((int64_t)H * W)), o = (int)(pix - (int64_t)n * H * W);
+    const int iy = o / W, ix = o - iy * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + 1 - ky;                          // = 2 oy
+        if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ix + 1 - kx;
+            if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+            acc += io<S>::ld(dcol + ((int64_t)n * Ho * Wo + (int64_t)(ty >> 1) * Wo + (tx >> 1)) * ((int64_t)C * 9) + c * 9 + ky * 3 + kx);
+        }
+    }
+    D* d = dst + ((int64_t)n * tok_stride + tok_off + o) * C + c;
+    io<D>::st(d, io<D>::ld(d) + acc);
+}
+
 // ---- position encodings --------------------------------------------------------------------------
 __device__ __forceinline__ void pair_st(float* o, float a, float b) { *reinterpret_cast<float2*>(o) = make_float2(a, b); }
 __device__ __forceinline__ void pair_st(bf16_t* o, float a, float b) { *reinterpret_cast<uint32_t*>(o) = pack_bf2(a, b); }
@@ -318,7 +347,7 @@ struct RefP {
     const float* vr;
     float* ref;
     int N, L, S;
-    int H[4], W[4], start[4];
+    int H[8], W[8], start[8];
 };
 __global__ __launch_bounds__(256) void enc_ref_kernel(const RefP p) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -804,6 +833,21 @@ extern "C" int poet_tokens_to_nchw(const void* src, void* dst, int N, int C, int
     return transpose_dispatch<false>(src, dst, N, C, HW, tok_off, tok_stride, sd, dd, stream);
 }
 
+extern "C" int poet_col2im3x3s2_add(const void* dcol, void* dst, int N, int C, int H, int W, int Ho, int Wo, int64_t tok_off, int64_t tok_stride,
+                                    int sd, int dd, void* stream) {
+    POET_CHECK(dcol && dst && N > 0 && C > 0 && H > 0 && W > 0, POET_ERR_ARG, "col2im: bad args");
+    POET_CHECK(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, POET_ERR_ARG, "col2im: output size mismatch");
+    POET_CHECK((sd == POET_F32 || sd == POET_BF16) && (dd == POET_F32 || dd == POET_BF16), POET_ERR_UNSUPPORTED, "col2im: dtypes");
+    const int64_t total = (int64_t)N * H * W * C;
+    dim3 grid(cdiv(total, 256)), block(256);
+    if (sd == POET_F32 && dd == POET_F32) hipLaunchKernelGGL((col2im_add_kernel<float, float>), grid, block, 0, ST, (const float*)dcol, (float*)dst, C, H, W, Ho, Wo, tok_off, tok_stride, total);
+    else if (sd == POET_BF16 && dd == POET_F32) hipLaunchKernelGGL((col2im_add_kernel<bf16_t, float>), grid, block, 0, ST, (const bf16_t*)dcol, (float*)dst, C, H, W, Ho, Wo, tok_off, tok_stride, total);
+    else if (sd == POET_BF16 && dd == POET_BF16) hipLaunchKernelGGL((col2im_add_kernel<bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)dcol, (bf16_t*)dst, C, H, W, Ho, Wo, tok_off, tok_stride, total);
+    else hipLaunchKernelGGL((col2im_add_kernel<float, bf16_t>), grid, block, 0, ST, (const float*)dcol, (bf16_t*)dst, C, H, W, Ho, Wo, tok_off, tok_stride, total);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
 extern "C" int poet_im2col3x3s2(const void* src, void* dst, int N, int C, int H, int W, int Ho, int Wo, int sd, int dd, void* stream) {
     POET_CHECK(src && dst && N > 0 && C > 0, POET_ERR_ARG, "im2col: bad args");
     POET_CHECK(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, POET_ERR_ARG, "im2col: output size mismatch");
@@ -868,7 +912,7 @@ extern "C" int poet_add_rowvec(void* x, const float* vec, int batch, int64_t bat
 }
 
 extern "C" int poet_enc_ref_points(const float* valid_ratios, const int64_t* shapes, float* ref, int N, int L, int S, void* stream) {
-    POET_CHECK(valid_ratios && shapes && ref && L >= 1 && L <= 4, POET_ERR_ARG, "enc_ref_points: bad args");
+    POET_CHECK(valid_ratios && shapes && ref && L >= 1 && L <= 8, POET_ERR_ARG, "enc_ref_points: bad args (1 <= n_levels <= 8)");
     RefP p{};
     p.vr = valid_ratios; p.ref = ref; p.N = N; p.L = L; p.S = S;
     int64_t acc = 0;

@@ -19,7 +19,7 @@
 
 namespace poet {
 
-constexpr int MAXL = 4;
+constexpr int MAXL = 8;           // levels a launch may carry (the specialised kernels are instantiated for 1..4, the generic ones take any)
 
 struct MsdaP {
     const void* value;
@@ -1778,6 +1778,208 @@ static bool launch_dv_mfma(const MsdaP& p, int P, hipStream_t st) {
     }
 }
 
+
+// ---- generic kernels: any n_levels <= MAXL, any n_points (L x P <= 64) -------------------------------------------------------
+// `--num_feature_levels`, `--enc_n_points`, `--dec_n_points` are free parameters of the reference (main.py:71,100-101); the
+// specialised kernels above are instantiated for L <= 4 and P in {1, 2, 4}.  Everything else runs here: L and P are run-time
+// values, one thread = 8 channels of one (image, query, head) as in msda_fwd_kernel, scalar operand loads (no alignment
+// requirement on the offset | logit rows), the softmax of the fused form in two passes over the logits instead of a register
+// array, and -- backward -- d(attention) of every point parked in LDS until the softmax Jacobian's dot product is known.
+// Correctness path, not a tuned one.
+struct GenLevel { int H, W, start; };
+__device__ __forceinline__ GenLevel gen_level(const MsdaP& p, int l) {
+    GenLevel g{p.H[0], p.W[0], p.start[0]};                 // select chain: a run-time index into the by-value argument goes to scratch
+#pragma unroll
+    for (int k = 1; k < MAXL; ++k)
+        if (l == k) { g.H = p.H[k]; g.W = p.W[k]; g.start = p.start[k]; }
+    return g;
+}
+struct GenCorner {
+    int pix[4];                                              // pixel index (start + y W + x) of the 4 corners, clamped into the map
+    float w[4];                                              // bilinear weight, 0 where the corner lies outside the map
+    float fx, fy;
+    float m[4];                                              // validity 0 / 1
+};
+__device__ __forceinline__ GenCorner gen_corner(float px, float py, const GenLevel& g) {
+    GenCorner c;
+    px = fminf(fmaxf(px, -2.f), (float)g.W + 1.f);           // (every corner of a sample beyond these bounds is outside the map anyway)
+    py = fminf(fmaxf(py, -2.f), (float)g.H + 1.f);
+    const float x0f = floorf(px), y0f = floorf(py);
+    c.fx = px - x0f; c.fy = py - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float vx0 = (x0 >= 0 && x0 < g.W) ? 1.f : 0.f, vx1 = (x1 >= 0 && x1 < g.W) ? 1.f : 0.f;
+    const float vy0 = (y0 >= 0 && y0 < g.H) ? 1.f : 0.f, vy1 = (y1 >= 0 && y1 < g.H) ? 1.f : 0.f;
+    const int xc0 = min(max(x0, 0), g.W - 1), xc1 = min(max(x1, 0), g.W - 1), yc0 = min(max(y0, 0), g.H - 1), yc1 = min(max(y1, 0), g.H - 1);
+    c.m[0] = vy0 * vx0; c.m[1] = vy0 * vx1; c.m[2] = vy1 * vx0; c.m[3] = vy1 * vx1;
+    c.w[0] = (1.f - c.fy) * (1.f - c.fx) * c.m[0]; c.w[1] = (1.f - c.fy) * c.fx * c.m[1];
+    c.w[2] = c.fy * (1.f - c.fx) * c.m[2];         c.w[3] = c.fy * c.fx * c.m[3];
+    c.pix[0] = g.start + yc0 * g.W + xc0; c.pix[1] = g.start + yc0 * g.W + xc1;
+    c.pix[2] = g.start + yc1 * g.W + xc0; c.pix[3] = g.start + yc1 * g.W + xc1;
+    return c;
+}
+// sample position (pixel units) and attention weight of point (l, i) of (row, head m); mx / inv: the fused form's softmax statistics
+template <typename TQ, bool FUSED>
+__device__ __forceinline__ void gen_point(const MsdaP& p, int L, int P, int64_t row, int n, int q, int m, int l, int i, const GenLevel& g,
+                                          float mx, float inv, float& px, float& py, float& aw) {
+    const int LP = L * P;
+    if constexpr (FUSED) {
+        const TQ* qrow = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq;
+        const TQ* op = qrow + ((int64_t)(m * L + l) * P + i) * 2;
+        const float* rp = p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * L + l) * 2;
+        px = io<TQ>::ld(op) + (rp[0] * (float)g.W - 0.5f);
+        py = io<TQ>::ld(op + 1) + (rp[1] * (float)g.H - 0.5f);
+        aw = __expf(io<TQ>::ld(qrow + p.logit_col + m * LP + l * P + i) - mx) * inv;
+    } else {
+        const TQ* lp = reinterpret_cast<const TQ*>(p.q1) + (((row * p.M + m) * L + l) * P + i) * 2;
+        px = io<TQ>::ld(lp) * (float)g.W - 0.5f;
+        py = io<TQ>::ld(lp + 1) * (float)g.H - 0.5f;
+        aw = io<TQ>::ld(reinterpret_cast<const TQ*>(p.q2) + (row * p.M + m) * LP + l * P + i);
+    }
+}
+template <typename TQ, bool FUSED>
+__device__ __forceinline__ void gen_softmax_stats(const MsdaP& p, int LP, int64_t row, int m, float& mx, float& inv) {
+    mx = 0.f; inv = 1.f;
+    if constexpr (FUSED) {
+        const TQ* lp = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq + p.logit_col + m * LP;
+        mx = io<TQ>::ld(lp);
+        for (int i = 1; i < LP; ++i) mx = fmaxf(mx, io<TQ>::ld(lp + i));
+        float s = 0.f;
+        for (int i = 0; i < LP; ++i) s += __expf(io<TQ>::ld(lp + i) - mx);
+        inv = 1.f / s;
+    }
+}
+
+template <typename TV, typename TQ, bool FUSED>
+__global__ __launch_bounds__(256) void msda_gen_fwd_kernel(const MsdaP p, int L, int P) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total) return;
+    const int64_t row = t / p.groups;
+    const int c8 = (int)(t - row * p.groups);
+    const int m = c8 / p.tpg, dsub = c8 - m * p.tpg;
+    const int n = (int)(row / p.Lq), q = (int)(row - (int64_t)n * p.Lq);
+    float mx, inv;
+    gen_softmax_stats<TQ, FUSED>(p, L * P, row, m, mx, inv);
+    const TV* vb = reinterpret_cast<const TV*>(p.value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const GenLevel g = gen_level(p, l);
+#pragma unroll 1
+        for (int i = 0; i < P; ++i) {
+            float px, py, aw;
+            gen_point<TQ, FUSED>(p, L, P, row, n, q, m, l, i, g, mx, inv, px, py, aw);
+            const GenCorner c = gen_corner(px, py, g);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[8];
+                vec<TV, 8>::ld(vb + (int64_t)c.pix[k] * p.vs_s, v);
+                const float w = aw * c.w[k];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w, v[ch], acc[ch]);
+            }
+        }
+    }
+    vec<TQ, 8>::st(reinterpret_cast<TQ*>(p.out) + row * ((int64_t)p.M * p.D) + m * p.D + dsub * 8, acc);
+}
+
+// backward of the same: p.parts bit 0 = d(offsets | logits) / d(loc), d(attn); bit 1 = the d(value) scatter (fp32 memory-side
+// atomics, or packed bf16x2 ones when grad_value is bf16).  Dynamic LDS: L x P floats per thread (fused form).
+template <typename TV, typename TQ, bool FUSED>
+__global__ __launch_bounds__(256) void msda_gen_bwd_kernel(const MsdaP p, int L, int P) {
+    extern __shared__ float gen_da[];                        // [L P][256]
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t0 < p.total;
+    const int64_t t = live ? t0 : p.total - 1;               // (dead lanes shadow the last thread: the group reductions below are wave-wide)
+    const int64_t row = t / p.groups;
+    const int c8 = (int)(t - row * p.groups);
+    const int m = c8 / p.tpg, dsub = c8 - m * p.tpg;
+    const int n = (int)(row / p.Lq), q = (int)(row - (int64_t)n * p.Lq);
+    const int LP = L * P;
+    float mx, inv;
+    gen_softmax_stats<TQ, FUSED>(p, LP, row, m, mx, inv);
+    const TV* vb = reinterpret_cast<const TV*>(p.value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m + dsub * 8;
+    float* gvb = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + dsub * 8;
+    bf16_t* gvb16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + dsub * 8;
+    float g[8];
+    vec<TQ, 8>::ld(reinterpret_cast<const TQ*>(p.grad_out) + row * ((int64_t)p.M * p.D) + m * p.D + dsub * 8, g);
+    const bool owner = live && dsub == 0 && (p.parts & 1);
+    float dot = 0.f;
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const GenLevel gl = gen_level(p, l);
+#pragma unroll 1
+        for (int i = 0; i < P; ++i) {
+            float px, py, aw;
+            gen_point<TQ, FUSED>(p, L, P, row, n, q, m, l, i, gl, mx, inv, px, py, aw);
+            const GenCorner c = gen_corner(px, py, gl);
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[8];
+                vec<TV, 8>::ld(vb + (int64_t)c.pix[k] * p.vs_s, v);
+                float s = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) s = fmaf(g[ch], v[ch], s);
+                d[k] = s * c.m[k];
+                if ((p.parts & 2) && live && c.w[k] != 0.f) {
+                    const float w = aw * c.w[k];
+                    const int64_t off = (int64_t)c.pix[k] * p.gs_s;
+                    if (p.gv_bf16) {
+#pragma unroll
+                        for (int ch = 0; ch < 8; ch += 2) gv16_add2(gvb16 + off + ch, w * g[ch], w * g[ch + 1]);
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < 8; ++ch) atomicAdd(gvb + off + ch, w * g[ch]);
+                    }
+                }
+            }
+            if (p.parts & 1) {
+                const float fx = c.fx, fy = c.fy;
+                float da = (1.f - fy) * ((1.f - fx) * d[0] + fx * d[1]) + fy * ((1.f - fx) * d[2] + fx * d[3]);
+                float dx = aw * ((1.f - fy) * (d[1] - d[0]) + fy * (d[3] - d[2]));
+                float dy = aw * ((1.f - fx) * (d[2] - d[0]) + fx * (d[3] - d[1]));
+                da = group_sum(da, p.tpg); dx = group_sum(dx, p.tpg); dy = group_sum(dy, p.tpg);
+                if (owner) {
+                    if constexpr (FUSED) {
+                        TQ* gp = reinterpret_cast<TQ*>(p.g1) + row * p.ldg + ((int64_t)(m * L + l) * P + i) * 2;
+                        io<TQ>::st(gp, dx); io<TQ>::st(gp + 1, dy);          // d/d(offset) = (dpx, dpy): the W, H factors cancel
+                        gen_da[(l * P + i) * 256 + threadIdx.x] = da;
+                        dot = fmaf(aw, da, dot);
+                    } else {
+                        TQ* gp = reinterpret_cast<TQ*>(p.g1) + (((row * p.M + m) * L + l) * P + i) * 2;
+                        io<TQ>::st(gp, dx * (float)gl.W); io<TQ>::st(gp + 1, dy * (float)gl.H);
+                        io<TQ>::st(reinterpret_cast<TQ*>(p.g2) + (row * p.M + m) * LP + l * P + i, da);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (FUSED) {
+        if (owner) {                                         // softmax Jacobian: d logit_j = a_j (d a_j - sum_k a_k d a_k)
+            const TQ* lp = reinterpret_cast<const TQ*>(p.q1) + row * p.ldq + p.logit_col + m * LP;
+            TQ* gp = reinterpret_cast<TQ*>(p.g1) + row * p.ldg + p.logit_col + m * LP;
+            for (int j = 0; j < LP; ++j) {
+                const float aj = __expf(io<TQ>::ld(lp + j) - mx) * inv;
+                io<TQ>::st(gp + j, aj * (gen_da[j * 256 + threadIdx.x] - dot));
+            }
+        }
+    }
+}
+
+template <typename TV, typename TQ, bool FUSED, bool BWD>
+static void launch_gen(const MsdaP& p, int L, int P, hipStream_t st) {
+    const dim3 grid(cdiv(p.total, 256)), block(256);
+    if constexpr (BWD) {
+        const size_t lds = FUSED ? (size_t)L * P * 256 * sizeof(float) : 0;
+        auto kern = msda_gen_bwd_kernel<TV, TQ, FUSED>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 4); attr_set = true; }
+        hipLaunchKernelGGL(kern, grid, block, lds, st, p, L, P);
+    } else {
+        hipLaunchKernelGGL((msda_gen_fwd_kernel<TV, TQ, FUSED>), grid, block, 0, st, p, L, P);
+    }
+}
+
 // fp16 offsets | logits (MsdaP::q_f16) are read by the shared-geometry gathers and the LDS-tiled scatters only: a launch that would
 // fall through to a general kernel (which reads q1 as bf16) is refused instead
 static thread_local bool g_f16_refused = false;
@@ -1838,6 +2040,11 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
 
 template <typename TV, typename TQ, bool FUSED, bool BWD>
 static void launch_l(const MsdaP& p, int L, int P, hipStream_t st) {
+    if (L > 4 || !(P == 1 || P == 2 || P == 4)) {             // outside the instantiated kernels: the generic ones
+        if (p.q_f16) { g_f16_refused = true; return; }
+        launch_gen<TV, TQ, FUSED, BWD>(p, L, P, st);
+        return;
+    }
     switch (L) {
         case 1: launch_p<TV, TQ, 1, FUSED, BWD>(p, P, st); break;
         case 2: launch_p<TV, TQ, 2, FUSED, BWD>(p, P, st); break;
@@ -1876,7 +2083,7 @@ static int fill_common(MsdaP& p, const int64_t* shapes, const int64_t* starts, i
     POET_CHECK(D % 8 == 0 && D >= 8, POET_ERR_UNSUPPORTED, "msda: head dim %d must be a multiple of 8", D);
     POET_CHECK((D / 8) <= 64 && (((D / 8) & ((D / 8) - 1)) == 0), POET_ERR_UNSUPPORTED, "msda: head dim %d/8 must be a power of two", D);
     POET_CHECK(L >= 1 && L <= MAXL, POET_ERR_UNSUPPORTED, "msda: n_levels %d not in 1..%d", L, MAXL);
-    POET_CHECK(P == 4 || P == 2 || P == 1, POET_ERR_UNSUPPORTED, "msda: n_points %d not in {1,2,4}", P);
+    POET_CHECK(P >= 1 && L * P <= 64, POET_ERR_UNSUPPORTED, "msda: n_levels x n_points = %d x %d exceeds 64 samples per (query, head)", L, P);
     POET_CHECK(shapes && starts, POET_ERR_ARG, "msda: null shapes");
     int64_t tot = 0;
     for (int l = 0; l < L; ++l) {
@@ -1935,7 +2142,8 @@ extern "C" int poet_msda_bwd(const void* value, const int64_t* shapes, const int
 static int fused_args(MsdaP& p, const void* value, int64_t vs_n, int64_t vs_s, int64_t vs_m, const void* offattn,
                       int64_t ldq, int logit_col, const float* ref, int64_t ref_bs, int M, int L, int P) {
     POET_CHECK(value && offattn && ref, POET_ERR_ARG, "msda_fused: null pointer");
-    POET_CHECK(ldq % 8 == 0 && logit_col % 8 == 0 && logit_col >= M * L * P * 2, POET_ERR_ARG,
+    const bool gen = L > 4 || !(P == 1 || P == 2 || P == 4);     // served by the generic kernels: scalar operand loads, no alignment rule
+    POET_CHECK((gen || (ldq % 8 == 0 && logit_col % 8 == 0)) && logit_col >= M * L * P * 2 && ldq >= logit_col + M * L * P, POET_ERR_ARG,
                "msda_fused: ldq/logit_col must be multiples of 8 and logits must follow the offsets");
     POET_CHECK(vs_s % 8 == 0 && vs_m % 8 == 0 && vs_n % 8 == 0, POET_ERR_ARG, "msda_fused: value strides must be multiples of 8");
     p.value = value; p.vs_n = vs_n; p.vs_s = vs_s; p.vs_m = vs_m;
@@ -1974,7 +2182,7 @@ extern "C" int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s
     POET_CHECK(grad_out && grad_value && grad_offattn, POET_ERR_ARG, "msda_fused_bwd: null pointer");
     POET_CHECK(gv_dtype == POET_F32 || gv_dtype == POET_BF16, POET_ERR_ARG, "msda_fused_bwd: gv_dtype");
     p.ldg = ld_grad > 0 ? ld_grad : ldq;
-    POET_CHECK(p.ldg >= (int64_t)3 * M * L * P && (p.ldg % 8) == 0, POET_ERR_ARG, "msda_fused_bwd: ld_grad %lld", (long long)p.ldg);
+    POET_CHECK(p.ldg >= (int64_t)3 * M * L * P && ((p.ldg % 8) == 0 || L > 4 || !(P == 1 || P == 2 || P == 4)), POET_ERR_ARG, "msda_fused_bwd: ld_grad %lld", (long long)p.ldg);
     p.grad_out = grad_out; p.grad_value = reinterpret_cast<float*>(grad_value); p.g1 = grad_offattn;
     p.gv_bf16 = gv_dtype == POET_BF16;
     p.grid_queries = grid_queries;

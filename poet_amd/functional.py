@@ -571,9 +571,10 @@ class InputProjFn(torch.autograd.Function):
         N, S, d = ctx.dims
         G = B.GradSink(names, params)
         dsrc = dsrc.contiguous()
-        if geom.L > ctx.n_feats + 1:
-            raise NotImplementedError("backward through more than one extra feature level")
-        for lvl in range(geom.L):
+        chained = geom.L > ctx.n_feats + 1        # a second (third, ...) extra level reads the previous PROJECTED level: its input
+        if chained:                                # gradient joins that level's rows of d(src) before their GroupNorm backward runs
+            dsrc = dsrc.clone()                    # (autograd owns the incoming tensor)
+        for lvl in reversed(range(geom.L)):
             f, col, pre, stats = ctx.saved[lvl]
             H, Wd = geom.shapes[lvl]
             HW = H * Wd
@@ -582,6 +583,15 @@ class InputProjFn(torch.autograd.Function):
             ops.groupnorm_bwd(dsrc, pre, stats, gw, dpre, G(f"{lvl}.1.weight"), G(f"{lvl}.1.bias"), N, HW, d, ctx.n_groups,
                               0, HW, geom.starts[lvl], S)
             gW = G(f"{lvl}.0.weight")
+            if lvl > ctx.n_feats:                  # pose_estimation_transformer.py:327-330: input_proj[lvl](srcs[-1])
+                W = params[names.index(f"{lvl}.0.weight")]
+                Wc = getattr(W, "_bf16", None) if dpre.dtype == torch.bfloat16 else W
+                if Wc is None:
+                    Wc = W.to(torch.bfloat16)
+                Hp, Wp = geom.shapes[lvl - 1]
+                dcol = torch.empty((N * HW, d * 9), dtype=dpre.dtype, device=dpre.device)
+                ops.linear_dx(dpre.view(N * HW, d), Wc.view(d, d * 9), dcol, rows=N * HW)
+                ops.col2im3x3s2_add(dcol, dsrc, N, d, Hp, Wp, H, Wd, geom.starts[lvl - 1], S)
             if f is not None and f.dim() == 2:                 # token-major bf16 copy of the feature map (see forward): dW + db in one pass
                 # ([hi | lo] rows: the weight gradient takes the hi half, row stride 2 C)
                 ops.linear_dw(dpre.view(N * HW, d), f, gW.view(d, -1), rows=N * HW, db=G(f"{lvl}.0.bias"), ldx=f.shape[1])

@@ -615,6 +615,13 @@ def im2col3x3s2(src, dst, N, Cc, H, W, Ho, Wo):
                                     _stream()), "poet_im2col3x3s2")
 
 
+def col2im3x3s2_add(dcol, dst, N, Cc, H, W, Ho, Wo, tok_off, tok_stride):
+    """dst[n, tok_off + y W + x, c] += the entries of dcol (N Ho Wo, 9 C) that im2col3x3s2 read from input pixel (n, c, y, x)."""
+    lib = _lib.load()
+    _lib.check(lib.poet_col2im3x3s2_add(_req(dcol, "dcol").data_ptr(), _req(dst, "dst").data_ptr(), N, Cc, H, W, Ho, Wo, tok_off, tok_stride,
+                                        dcode(dcol), dcode(dst), _stream()), "poet_col2im3x3s2_add")
+
+
 def pose_finish_fwd(rot_all, trans_all, cls, rot, trans, R, ncls):
     lib = _lib.load()
     _lib.check(lib.poet_pose_finish_fwd(_req(rot_all, "rot_all").data_ptr(), trans_all.data_ptr(), cls.data_ptr(), rot.data_ptr(),

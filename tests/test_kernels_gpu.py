@@ -180,6 +180,88 @@ def test_msda_fewer_points(ops, npts):
     _close(gl, torch.from_numpy(rl), torch.float32, scale=30, msg="msda dloc")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shapes,m,d,npts", [([(9, 11), (5, 6), (3, 3), (2, 2), (1, 2)], 4, 16, 3), ([(7, 5), (4, 3)], 3, 8, 8),
+                                             ([(6, 8), (5, 7), (4, 6), (3, 4), (3, 3), (2, 3), (2, 2), (1, 1)], 2, 32, 1),
+                                             ([(9, 11), (5, 6), (3, 3)], 4, 16, 3), ([(5, 7)], 2, 64, 5), ([(4, 4), (2, 2)], 1, 128, 6)])
+def test_msda_generic_levels_and_points(ops, dtype, shapes, m, d, npts):
+    """n_levels up to 8 and ANY n_points (`--num_feature_levels`, `--enc_n_points`, `--dec_n_points`: main.py:71,100-101) -- the
+    generic kernels (msda_gen_*) behind the upstream-shaped boundary, against the float64 closed form."""
+    value, loc, attn, gout = _msda_inputs(17, shapes, m=m, d=d, p=npts)
+    geom = ops.LevelGeom(shapes)
+    tv, tl, ta, tg = (torch.from_numpy(a).to(dtype) for a in (value, loc, attn, gout))
+    out = torch.empty(tg.shape, dtype=dtype, device="cuda")
+    ops.msda_fwd(dev(tv), geom, dev(tl), dev(ta), out)
+    ref = msda_explicit.msda_forward(tv.float().numpy(), shapes, tl.float().numpy(), ta.float().numpy())
+    _close(out, torch.from_numpy(ref), dtype, msg="msda generic fwd")
+    gv = torch.empty(tv.shape, dtype=torch.float32, device="cuda")
+    gl = torch.empty(tl.shape, dtype=dtype, device="cuda")
+    ga = torch.empty(ta.shape, dtype=dtype, device="cuda")
+    ops.msda_bwd(dev(tv), geom, dev(tl), dev(ta), dev(tg), gv, gl, ga)
+    rv, rl, ra = msda_explicit.msda_backward(tv.float().numpy(), shapes, tl.float().numpy(), ta.float().numpy(), tg.float().numpy())
+    _close(gv, torch.from_numpy(rv), dtype, scale=3, msg="msda generic dvalue")
+    _close(ga, torch.from_numpy(ra), dtype, scale=3, msg="msda generic dattn")
+    _close(gl, torch.from_numpy(rl), dtype, scale=30, msg="msda generic dloc")
+
+
+@pytest.mark.parametrize("vdt,qdt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("shapes,npts", [([(10, 12), (5, 6), (3, 3), (2, 2), (1, 1)], 3), ([(7, 9), (4, 5)], 5)])
+def test_msda_fused_generic(ops, vdt, qdt, shapes, npts):
+    """The fused form (softmax over L x P logits, loc = ref + offset / (W, H), softmax Jacobian) of the generic kernels: rows of
+    3 M L P = 180 / 120 elements (no 16-byte alignment), head-major value maps, against autograd through the oracle's core."""
+    n, m, d, lq, p = 2, 4, 16, 29, npts
+    L = len(shapes)
+    geom = ops.LevelGeom(shapes)
+    S = geom.S
+    rng = np.random.default_rng(7)
+    value = torch.from_numpy(rng.standard_normal((n, S, m, d)).astype(np.float32)).to(vdt)
+    mlp = m * L * p
+    oa = torch.from_numpy(np.concatenate([rng.standard_normal((n, lq, 2 * mlp)) * 2.0, rng.standard_normal((n, lq, mlp))], -1)
+                          .astype(np.float32)).to(qdt)
+    ref_pts = torch.from_numpy(rng.uniform(-0.1, 1.1, (n, lq, L, 2)).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((n, lq, m * d)).astype(np.float32)).to(qdt)
+    v32 = value.float().requires_grad_()
+    oa32 = oa.float().requires_grad_()
+    off = oa32[..., : 2 * mlp].view(n, lq, m, L, p, 2)
+    w = torch.softmax(oa32[..., 2 * mlp:].view(n, lq, m, L * p), -1).view(n, lq, m, L, p)
+    norm = torch.tensor([[wd, ht] for ht, wd in shapes], dtype=torch.float32)
+    loc = ref_pts[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    out_ref = poet_ref.msda_core(v32, shapes, loc, w)
+    (out_ref * gout.float()).sum().backward()
+    vdev = dev(value.permute(0, 2, 1, 3).contiguous())
+    vstr = (m * S * d, d, S * d)
+    out = torch.empty(n, lq, m * d, dtype=qdt, device="cuda")
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, dev(ref_pts), lq * L * 2, out, n, m, d, p, lq)
+    _close(out, out_ref.detach(), vdt if vdt == torch.bfloat16 else qdt, msg="fused generic fwd")
+    gv = torch.zeros(vdev.shape, dtype=torch.float32, device="cuda")
+    goa = torch.empty_like(dev(oa))
+    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, dev(ref_pts), lq * L * 2, dev(gout), gv, goa, n, m, d, p, lq)
+    worst = torch.bfloat16 if torch.bfloat16 in (vdt, qdt) else torch.float32
+    _close(gv, v32.grad.permute(0, 2, 1, 3), worst, scale=3, msg="fused generic dvalue")
+    _close(goa, oa32.grad, worst, scale=3, msg="fused generic d(off|logit)")
+
+
+@pytest.mark.parametrize("sdt,ddt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("H,W", [(3, 4), (6, 8), (5, 7), (1, 1)])
+def test_col2im3x3s2_add_is_the_adjoint_of_the_extra_level_conv(ops, sdt, ddt, H, W):
+    """poet_col2im3x3s2_add == d(input) of nn.Conv2d(C, d, 3, stride 2, padding 1) given d(im2col matrix), added into the token
+    rows of a wider stream gradient (the chained extra levels of pose_estimation_transformer.py:327-330)."""
+    N, C = 2, 8
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    rng = np.random.default_rng(3)
+    dcol = torch.from_numpy(rng.standard_normal((N * Ho * Wo, C * 9)).astype(np.float32)).to(sdt)
+    S, off = H * W + 11, 5
+    base = torch.from_numpy(rng.standard_normal((N, S, C)).astype(np.float32)).to(ddt)
+    x = torch.zeros(N, C, H, W, requires_grad=True)
+    cols = torch.nn.functional.unfold(x, 3, padding=1, stride=2)                   # (N, C*9, Ho*Wo), k = c*9 + ky*3 + kx
+    (cols.transpose(1, 2).reshape(N * Ho * Wo, C * 9) * dcol.float()).sum().backward()
+    want = base.float().clone()
+    want[:, off:off + H * W] += x.grad.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    got = dev(base)
+    ops.col2im3x3s2_add(dev(dcol), got, N, C, H, W, Ho, Wo, off, S)
+    _close(got, want, ddt, scale=3, msg="col2im")
+
+
 @pytest.mark.parametrize("vdt,qdt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
 @pytest.mark.parametrize("head_major", [False, True])
 def test_msda_fused(ops, vdt, qdt, head_major):

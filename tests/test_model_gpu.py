@@ -34,7 +34,7 @@ def _real_query_mask(n_boxes, Q):
     return m
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("tiny", 2, False), ("cfg0", 2, False), ("cfg0", 2, True)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("tiny", 2, False), ("cfg0", 2, False), ("cfg0", 2, True), ("tiny5", 2, True)])
 def test_forward_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.float32)
@@ -57,16 +57,15 @@ def test_forward_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
         # padded tokens carry values the decoder never reads (their value rows are masked): compare valid ones
         o = run_oracle(name, batch, pad, backward=False)
         masks = [f.mask for f in o["model"].backbone(o["samples"])[0]]
-        if len(masks) < r["cfg"]["n_levels"]:
-            import torch.nn.functional as F
-            h, w = r["cfg"]["level_hw"][-1]
+        import torch.nn.functional as F
+        for h, w in r["cfg"]["level_hw"][len(masks):]:               # the extra 3x3-s2 level(s): mask interpolated from the image mask
             masks.append(F.interpolate(o["samples"].mask[None].float(), size=(h, w)).to(torch.bool)[0])
         valid = ~torch.cat([m.flatten(1) for m in masks], 1)
         diff = (mem - torch.from_numpy(g["memory"])).abs()
         assert diff[valid].max().item() < TOL_F32
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True)])
 def test_forward_bf16_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.bfloat16)
@@ -80,7 +79,7 @@ def test_forward_bf16_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     assert dt.max().item() < TOL_BF16 and dr.max().item() < TOL_BF16
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True)])
 def test_loss_and_grads_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.float32)
@@ -196,6 +195,31 @@ def test_learned_position_embedding_vs_reference_golden(gpu, golden_dir, precisi
         tr.step(rr["samples"], rr["targets"])
         moved = (rr["model"].backbone[1].row_embed.weight.detach() - w0).abs().max().item()
         assert 0 < moved <= 2e-5 * 1.05 + 1e-4 * 2e-5, moved          # one AdamW step at lr_backbone = 0.1 lr
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_five_levels_three_points_training_graph_equals_eager(gpu, precision):
+    """`--num_feature_levels 5 --enc_n_points 3 --dec_n_points 3` (generic MSDA kernels, two chained extra levels) under the flat
+    parameter arena: the HIP-graph replay equals the eager trainer at frozen parameters, and a real step moves the second extra
+    level's convolution (its gradient exists only through the chained input-projection backward of the level above it)."""
+    import poet_amd
+    runs = {}
+    for mode in ("eager", "graph"):
+        rr = gpu("tiny5", 2, True, precision, dropout=0.0)
+        rr["model"].train()
+        cls = poet_amd.Trainer if mode == "eager" else poet_amd.GraphedTrainer
+        tr = cls(rr["model"], rr["crit"], lr=0.0, weight_decay=1e-4, max_norm=0.1, **({} if mode == "eager" else dict(warm=1)))
+        runs[mode] = [float(tr.step(rr["samples"], rr["targets"])[0]) for _ in range(3)]
+    assert runs["graph"] == pytest.approx(runs["eager"], rel=1e-4, abs=1e-4), runs
+    rr = gpu("tiny5", 2, True, precision, dropout=0.0)
+    rr["model"].train()
+    w3 = rr["model"].input_proj[3][0].weight.detach().clone()
+    w4 = rr["model"].input_proj[4][0].weight.detach().clone()
+    tr = poet_amd.Trainer(rr["model"], rr["crit"], lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+    l0 = float(tr.step(rr["samples"], rr["targets"])[0])
+    assert np.isfinite(l0)
+    assert not torch.equal(rr["model"].input_proj[3][0].weight.detach(), w3)
+    assert not torch.equal(rr["model"].input_proj[4][0].weight.detach(), w4)
 
 
 @pytest.mark.parametrize("qmode,rmode", [("learned", "bbox"), ("learned", "learned")])
