@@ -368,7 +368,8 @@ GRAD_TOL_F32, GRAD_TOL_BF16 = 1e-2, 8e-2
 # sampling_offsets the goldens are not a function of the inputs.  The `*_init` goldens therefore carry, besides the whole-tensor
 # checksums, checksums of the gradient restricted to the channels whose bias component is not an integer (oracle/gen_golden.py):
 # those are held to the plain gradient tolerance, and the kink channels to finiteness + the norm bound below.
-KINK_NORM = 2.0  # a kink channel's one-sided derivative differs from the other side's by at most the two sides' sum
+KINK_NORM = 2.0  # a kink channel's one-sided derivative differs from the other side's by at most the two sides' sum (per ENTRY the kernels
+                 # are held to one of the two one-sided derivatives of the float64 closed form: tests/test_kernels_gpu.py::_kink_error)
 # The conditioned rotation rule of the bf16 policy (test_full_size_forward_backward_vs_reference_golden's docstring): the plain
 # tolerance up to these amplifications of the reference's own 6D -> R map, tolerance x amplification / AMP0 beyond.
 AMP0 = 8.0       # final decoder layer = the model's output (random-init heads only: the `_init` goldens and the seed sweep)
