@@ -621,6 +621,159 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
     }
 }
 
+
+// ---- hybrid gathers: coarse levels from LDS, fine levels through L1 -----------------------------------------------------------
+// The shared-geometry kernels above sit at the per-CU L1's look-up rate (profiles/round3_ycbv_pmc_gather.csv), and HALF of all
+// samples go to the two coarse levels, whose maps are tiny: 15 x 20 + 8 x 10 = 380 pixels at 640 x 480.  Here a workgroup is bound
+// to ONE (image, head quarter) and stages those levels' bf16 value rows of its 4 heads in LDS once -- layout [pixel][4 heads][16 ch]
+// = 128 B per pixel: the 16 lanes of an LDS read group are 4 (query, head) pairs with 4 DIFFERENT heads, a pair's 4 lanes [x corner]
+// [channel half] read 2 x 32 B of two x-adjacent pixels (opposite bank halves), so every ds_read_b128 group covers all 64 banks
+// exactly once -- and walks its share of the image's query rows: the records of levels >= lc carry LDS byte offsets, the gather
+// loop reads them with ds_read_b128, the fine levels keep their global loads.  lc = the finest level from which everything coarser
+// fits HYB_MAP bytes (640 x 480: levels 2-3; LM-O: 1-3; 1280 x 960: level 3).
+constexpr int HYB_WAVES = 8;
+constexpr int HYB_MAP = 50 * 1024;
+struct HybP { int lc, px_lc, chunks; };                       // first staged level, first pixel of it, query chunks per (image, quarter)
+
+template <bool KEEP, bool QH>
+__device__ __forceinline__ void hyb_prepare(const MsdaP& p, const HybP& hp, const ShRaw& raw, float2 rf, int n, int m, int lane, char* wlds, ShGeo& gk) {
+    const int pair = lane >> 2, o = lane & 3;
+    float lg[4], off[8];
+    lg[0] = q_lo<QH>(raw.lg.x); lg[1] = q_hi<QH>(raw.lg.x);
+    lg[2] = q_lo<QH>(raw.lg.y); lg[3] = q_hi<QH>(raw.lg.y);
+    off[0] = q_lo<QH>(raw.off.x); off[1] = q_hi<QH>(raw.off.x);
+    off[2] = q_lo<QH>(raw.off.y); off[3] = q_hi<QH>(raw.off.y);
+    off[4] = q_lo<QH>(raw.off.z); off[5] = q_hi<QH>(raw.off.z);
+    off[6] = q_lo<QH>(raw.off.w); off[7] = q_hi<QH>(raw.off.w);
+    float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    mx = fmaxf(mx, quad_xor1(mx)); mx = fmaxf(mx, quad_xor2(mx));
+    float e[4], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e[i] = __expf(lg[i] - mx); sum += e[i]; }
+    sum += quad_xor1(sum); sum += quad_xor2(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    int Wl = p.W[0], Hl = p.H[0], Sl = p.start[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (o == k) { Wl = p.W[k]; Hl = p.H[k]; Sl = p.start[k]; }
+    const float rx = rf.x * (float)Wl - 0.5f, ry = rf.y * (float)Hl - 0.5f;
+    // levels < lc: byte offsets into the head-major value maps; levels >= lc: byte offsets into the staged maps (128 B per pixel)
+    const bool staged = o >= hp.lc;
+    const uint32_t pix_bytes = staged ? 128u : (uint32_t)p.vs_s * 2u;
+    const uint32_t base = staged ? (uint32_t)(Sl - hp.px_lc) * 128u + (uint32_t)(m & 3) * 32u
+                                 : (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m) * 2) + (uint32_t)Sl * pix_bytes;
+    char* rec = wlds + (o * 4) * 256 + pair * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float aw = e[i] * inv;
+        const float px = off[2 * i] + rx, py = off[2 * i + 1] + ry;
+        const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);
+        const bool vx0 = (unsigned)x0 < (unsigned)Wl, vx1 = (unsigned)x1 < (unsigned)Wl;
+        const bool vy0 = (unsigned)y0 < (unsigned)Hl, vy1 = (unsigned)y1 < (unsigned)Hl;
+        const uint32_t r0 = mad24(clamp0(y0, Hl - 1), Wl, 0u), r1 = mad24(clamp0(y1, Hl - 1), Wl, 0u);
+        const uint32_t c0 = (uint32_t)clamp0(x0, Wl - 1), c1 = (uint32_t)clamp0(x1, Wl - 1);
+        const float wy0 = vy0 ? (1.f - fy) * aw : 0.f, wy1 = vy1 ? fy * aw : 0.f;
+        const float wx0 = vx0 ? 1.f - fx : 0.f, wx1 = vx1 ? fx : 0.f;
+        uint4 a, b;
+        a.x = mad24(r0 + c0, pix_bytes, base); a.y = mad24(r1 + c0, pix_bytes, base);
+        a.z = __float_as_uint(wy0 * wx0);      a.w = __float_as_uint(wy1 * wx0);
+        b.x = mad24(r0 + c1, pix_bytes, base); b.y = mad24(r1 + c1, pix_bytes, base);
+        b.z = __float_as_uint(wy0 * wx1);      b.w = __float_as_uint(wy1 * wx1);
+        *reinterpret_cast<uint4*>(rec + i * 256) = a;
+        *reinterpret_cast<uint4*>(rec + i * 256 + SH_PLANE) = b;
+        if constexpr (KEEP) {
+            gk.aw[i] = aw; gk.fx[i] = fx; gk.fy[i] = fy;
+            gk.valid[i] = (vx0 ? 1u : 0u) | (vx1 ? 2u : 0u) | (vy0 ? 4u : 0u) | (vy1 ? 8u : 0u);
+        }
+    }
+    sh_wave_sync();
+}
+
+// stage the levels >= lc of heads [4 hq, 4 hq + 4) of image n: [pixel][head][16 ch]
+__device__ __forceinline__ void hyb_stage(const MsdaP& p, const HybP& hp, int n, int hq, char* cmap, int tid, int nt) {
+    const int npx = p.S - hp.px_lc;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.value) + (int64_t)n * p.vs_n + (int64_t)hp.px_lc * p.vs_s;
+    for (int i = tid; i < npx * 8; i += nt) {                // item = (pixel, head, channel half), 16 B
+        const int half = i & 1, h = (i >> 1) & 3, px = i >> 3;
+        *reinterpret_cast<uint4*>(cmap + px * 128 + h * 32 + half * 16) =
+            *reinterpret_cast<const uint4*>(vb + (int64_t)(hq * 4 + h) * p.vs_m + (int64_t)px * p.vs_s + half * 8);
+    }
+}
+
+template <bool QH>
+__global__ __launch_bounds__(HYB_WAVES * 64) void msda_fwd_hyb_kernel(const MsdaP p, const HybP hp) {
+    extern __shared__ __attribute__((aligned(16))) char hyb_lds[];    // staged maps | HYB_WAVES x SH_WAVE records
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x % hp.chunks, hq = (blockIdx.x / hp.chunks) & 3, n = blockIdx.x / (hp.chunks * 4);
+    const int map_bytes = (p.S - hp.px_lc) * 128;
+    char* cmap = hyb_lds;
+    char* wlds = hyb_lds + map_bytes + wave * SH_WAVE;
+    hyb_stage(p, hp, n, hq, cmap, threadIdx.x, HYB_WAVES * 64);
+    __syncthreads();
+    // this workgroup's query units (4 consecutive queries each) of image n
+    const int units = (p.Lq + 3) >> 2;
+    const int u_lo = (int)((int64_t)chunk * units / hp.chunks), u_hi = (int)((int64_t)(chunk + 1) * units / hp.chunks);
+    const int pair = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
+    const int qq = pair >> 2, hh = pair & 3, m = hq * 4 + hh;
+    const char* rd = wlds + xc * SH_PLANE + pair * 16;
+    const uint32_t lane_off = (uint32_t)dsub * 16u;
+#pragma unroll 1
+    for (int u = u_lo + wave; u < u_hi; u += HYB_WAVES) {
+        const int qraw = u * 4 + qq;
+        const bool live = qraw < p.Lq;
+        const int q = live ? qraw : p.Lq - 1;
+        const int row = n * p.Lq + q;
+        const float2 rf = *reinterpret_cast<const float2*>(p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * 4 + (lane & 3)) * 2);
+        ShGeo unused;
+        const ShRaw raw = sh_load(p, row, m, lane & 3);
+        hyb_prepare<false, QH>(p, hp, raw, rf, n, m, lane, wlds, unused);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) {
+            uint4 r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(rd + (l * 4 + i) * 256);
+            Raw8<bf16_t> v0[4], v1[4];
+            if (l >= hp.lc) {                                 // (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v0[i].v = *reinterpret_cast<const u32x4_t*>(cmap + r[i].x + lane_off);
+                    v1[i].v = *reinterpret_cast<const u32x4_t*>(cmap + r[i].y + lane_off);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float w0 = __uint_as_float(r[i].z), w1 = __uint_as_float(r[i].w);
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[i].f(ch), acc[ch]);
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
+            }
+        }
+        sh_wave_sync();
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) acc[ch] += quad_xor2(acc[ch]);
+        if (!xc && live) {
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (int64_t)row * 256 + m * 16 + dsub * 8;
+            vec<bf16_t, 8>::st(op, acc);
+        }
+    }
+}
+
+// first level from which everything coarser fits the staged-map budget (0 < lc <= 3), or -1
+static int hyb_first_level(const MsdaP& p) {
+    int lo = 1;
+    { const char* e = getenv("POET_HYB_LC"); if (e && atoi(e) >= 1 && atoi(e) <= 3) lo = atoi(e); }     // experiment: stage fewer levels
+    for (int lc = lo; lc <= 3; ++lc)
+        if ((size_t)(p.S - p.start[lc]) * 128 <= (size_t)HYB_MAP) return lc;
+    return -1;
+}
+
 // packed bf16x2 memory-side atomic add (global_atomic_pk_add_bf16): `p2` = the even channel of a pair (4-byte aligned)
 typedef short gv_short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gv16_add2(bf16_t* p2, float lo, float hi) {
@@ -2011,6 +2164,26 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
         if (!no_shared && P == 4 && p.M == 16 && p.D == 16 && rows < (1ll << 31) && (p.ldq % 8) == 0 && (p.logit_col % 4) == 0 &&
             (p.ref_bs % 2) == 0) {
             // POET_SH_QGROUP=1: one query x 16 heads per wave; default 4 consecutive queries x 4 heads, 4 passes
+            // POET_MSDA_HYBRID=1 (forward, round 4 experiment): coarse levels staged in LDS per (image, head quarter)
+            if constexpr (!BWD) {
+                const char* hy_ = getenv("POET_MSDA_HYBRID");
+                const int lc = (hy_ && atoi(hy_)) ? hyb_first_level(p) : -1;
+                if (lc > 0 && p.grid_queries) {
+                    HybP hp{lc, p.start[lc], 16};
+                    { const char* e = getenv("POET_HYB_CHUNKS"); if (e && atoi(e) > 0) hp.chunks = atoi(e); }
+                    const size_t lds = (size_t)(p.S - hp.px_lc) * 128 + (size_t)HYB_WAVES * SH_WAVE;
+                    static bool attr_set = false;
+                    if (!attr_set) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_hyb_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_hyb_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        attr_set = true;
+                    }
+                    const dim3 hgrid((unsigned)(p.N * 4 * hp.chunks)), hblk(HYB_WAVES * 64);
+                    if (p.q_f16) hipLaunchKernelGGL((msda_fwd_hyb_kernel<true>), hgrid, hblk, lds, st, p, hp);
+                    else hipLaunchKernelGGL((msda_fwd_hyb_kernel<false>), hgrid, hblk, lds, st, p, hp);
+                    return;
+                }
+            }
             const char* qg_ = getenv("POET_SH_QGROUP");
             const int qg = qg_ && atoi(qg_) == 1 ? 1 : 4;          // (2 and 8 measured within 5 % of 4, 16 no better than 1)
             const dim3 grid((unsigned)((rows + SH_WAVES * qg - 1) / (SH_WAVES * qg))), blk(SH_WAVES * 64);

@@ -788,6 +788,13 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     out = torch.empty(n, S, m * d, dtype=torch.bfloat16, device="cuda")
     ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
     e_out = (out.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item()
+    # the opt-in hybrid forward (coarse levels staged in LDS per (image, head quarter), fine levels through L1): the same arithmetic
+    # in the same order -- bit-identical to the default kernel
+    monkeypatch.setenv("POET_MSDA_HYBRID", "1")
+    out_h = torch.empty_like(out)
+    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_h, n, m, d, p, S, grid_queries=True)
+    monkeypatch.delenv("POET_MSDA_HYBRID")
+    assert torch.equal(out_h, out)
     # the opt-in variants that stage bf16 value windows in LDS (one lane per (query, head)), same problem
     monkeypatch.setenv("POET_WIN_GATHER", "1")
     out_w, goa_w = torch.empty_like(out), torch.empty_like(dev(oa))
