@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpoet_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "gemm_dw.hip", "gemm_small.hip", "gemm_pipe.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "gemm_wr.hip", "gemm_dw.hip", "gemm_small.hip", "gemm_pipe.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
 RESOURCES = os.path.join(CSRC, "kernel_resources.txt")      # per-kernel VGPRs / scratch of the last build (git-ignored)

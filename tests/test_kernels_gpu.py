@@ -848,6 +848,32 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     assert torch.equal(rows16.view(n, S, m, d).cpu(), gv16.permute(0, 2, 1, 3).cpu())
 
 
+@pytest.mark.parametrize("N,act,dp,odt", [(1024, 1, 0.1, torch.bfloat16), (768, 0, 0.0, torch.float16), (512, 0, 0.0, torch.bfloat16)])
+@pytest.mark.parametrize("rows", [102080, 5007, 4096 + 16])
+def test_gemm_register_stationary_equals_lds_stationary(ops, monkeypatch, N, act, dp, odt, rows):
+    """gemm_wr.hip (opt-in POET_GEMM_WR=1: the split weights resident in registers, the activation through an LDS-DMA ring) computes
+    the wide split-weight forward products in the accumulation order of gemm_ws.hip: the outputs -- ReLU, the dropout mask, bf16 and
+    fp16 storage, ragged row counts and odd unit counts -- must be bit-identical."""
+    x = _rand(rows, 256, seed=300 + N).to(torch.bfloat16)
+    w = _rand(N, 256, seed=301, scale=1 / 16)
+    b = _rand(N, seed=302)
+    outs = []
+    for wr in ("0", "1"):
+        monkeypatch.setenv("POET_GEMM_WR", wr)
+        out = torch.full((rows + 3, N), 7.0, dtype=odt, device="cuda")          # (3 guard rows: nothing may be written past M)
+        ops.linear_fwd(dev(x), dev(w), dev(b), out[:rows], split=True, act=act, drop_p=dp, seed=99)
+        outs.append(out)
+    monkeypatch.delenv("POET_GEMM_WR")
+    assert torch.equal(outs[0], outs[1])
+    assert bool((outs[1][rows:] == 7.0).all())
+    ref = x.float() @ w.t() + b
+    if act:
+        ref = torch.relu(ref)
+    got = outs[1][:rows].float().cpu()
+    keep = got != 0 if dp > 0 else torch.ones_like(got, dtype=torch.bool)
+    assert ((got * (1 - dp) - ref).abs() * keep).max().item() <= 6e-3 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("rows", [5000 + 7, 700])
 def test_gemm_fp16_output_storage(ops, rows):
     """PoetGemmDesc.c_f16: the 2-byte outputs of a bf16-typed C written as IEEE fp16 (the offsets | logits buffer of the encoder's
