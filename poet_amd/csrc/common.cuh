@@ -125,6 +125,14 @@ template <> struct vec<f16_t, 8> {
     static __device__ __forceinline__ void st(f16_t* p, const float* o) { st8_f16(reinterpret_cast<uint16_t*>(p), o); }
 };
 
+// max(x, 0) as ONE v_max_f32 (through fmaxf hipcc first canonicalises its operand: two instructions per element in epilogues that
+// are issue-bound); a NaN input gives 0 like fmaxf
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // ---- counter-based dropout RNG -------------------------------------------------------------------
 // keep(seed, idx): one lowbias32 hash of (idx>>1 ^ seed-mix) serves the element PAIR (idx & ~1, idx | 1), 16 bits each
 // (p is quantised to 2^-16); regenerated in backward from the same (seed, idx), so no mask is ever stored.  Vectorised

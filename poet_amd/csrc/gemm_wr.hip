@@ -145,7 +145,7 @@ __global__ __launch_bounds__(WR_NT, 2) void gemm_wr_kernel(const WrP p) {
         for (int t = 0; t < 4; ++t) { v[t] = a0[t] + bias8[t]; v[4 + t] = a1[t] + bias8[4 + t]; }
         if (p.act == 1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = relu1(v[e]);
         }
         if (p.drop_thresh) {
             const uint32_t base = (uint32_t)grow * (uint32_t)p.N + (uint32_t)col0;

@@ -262,7 +262,11 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
 #pragma unroll
                     for (int lo = 0; lo < 2; ++lo)
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[lo * 4 + t] = acc[fm][jq * 4 + h * 2 + lo][t] * d.alpha;
+                        for (int t = 0; t < 4; ++t) v[lo * 4 + t] = acc[fm][jq * 4 + h * 2 + lo][t];
+                    if (d.alpha != 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
+                    }
                     {
                         float b[8];
                         vec<float, 8>::ld(sbias + lcol, b);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
                     }
                     if (d.act == 1) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 8; ++e) v[e] = relu1(v[e]);
                     }
                     if constexpr (GATE) {
                         float gt[8];
@@ -499,7 +503,11 @@ __global__ __launch_bounds__(NTH, 2) void gemm_wsk_kernel(const GemmK p) {
 #pragma unroll
                 for (int lo = 0; lo < 2; ++lo)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[lo * 4 + t] = acc[fm][jq * 4 + h * 2 + lo][t] * d.alpha;
+                    for (int t = 0; t < 4; ++t) v[lo * 4 + t] = acc[fm][jq * 4 + h * 2 + lo][t];
+                    if (d.alpha != 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
+                    }
                 {
                     float b[8];
                     vec<float, 8>::ld(sbias + lcol, b);
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_wsk_kernel(const GemmK p) {
                 }
                 if (d.act == 1) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = relu1(v[e]);
                 }
                 if constexpr (GATE) {
                     uint4 gq[NV];
