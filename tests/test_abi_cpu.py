@@ -135,8 +135,9 @@ def test_graft_entry_build_passes():
     __graft_entry__.build()
 
 
-def test_pipe_kernel_m0_only_in_dma(tmp_path):
-    """gemm_pipe.hip sets M0 by hand inside its LDS-DMA inline asm (hipcc accepts no "m0" clobber: reserved register).  That is
+@pytest.mark.parametrize("src", ["gemm_pipe.hip", "gemm_wr.hip"])
+def test_pipe_kernel_m0_only_in_dma(tmp_path, src):
+    """gemm_pipe.hip (and gemm_wr.hip, the opt-in register-stationary kernel) set M0 by hand inside its LDS-DMA inline asm (hipcc accepts no "m0" clobber: reserved register).  That is
     safe only while nothing else in that translation unit uses M0: the compiled ISA may mention m0 only as `s_mov_b32 m0, sN`
     (the asm's own write) -- no movrel / gpr-index, no compiler-generated M0 reads."""
     import shutil
@@ -145,7 +146,7 @@ def test_pipe_kernel_m0_only_in_dma(tmp_path):
         pytest.skip("no hipcc")
     out = str(tmp_path / "pipe.s")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-                           "-S", "--cuda-device-only", os.path.join(ROOT, "poet_amd", "csrc", "gemm_pipe.hip"), "-o", out], stderr=subprocess.DEVNULL)
+                           "-S", "--cuda-device-only", os.path.join(ROOT, "poet_amd", "csrc", src), "-o", out], stderr=subprocess.DEVNULL)
     lines = [l.strip() for l in open(out) if re.search(r"\bm0\b", l) and not l.lstrip().startswith((";", "//"))]
     assert lines, "expected the DMA's M0 writes"
     bad = [l for l in lines if not re.fullmatch(r"s_mov_b32 m0, s\d+", l)]
