@@ -424,6 +424,9 @@ def main():
                                    f"bs={batch} per GPU, dropout {cfg['dropout']}, AdamW + clip 0.1, random init",
                        "global_batch": world * batch, "tokens_per_image": sum(h * w for h, w in cfg["level_hw"]),
                        "parallelism": f"dp{world}", "precision_policy": args.precision,
+                       **({"dp_mode": ("one backward graph + ONE all-reduce of the flat gradient arena" if getattr(trainer, "single_collective", False)
+                                       else "one backward segment + one all-reduce per gradient bucket (comm stream)") +
+                                      f", gradients travel as {os.environ.get('POET_DP_GRAD_DTYPE', 'fp32')}"} if dist.is_initialized() else {}),
                        "launch": "eager" if args.no_graphs else ("hipGraph replay (fwd + matcher + loss graph, bwd + clip + AdamW graph)" if getattr(trainer, "graph_loss", False) else "hipGraph replay (fwd graph, eager loss, bwd+opt graph)"),
                        "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
                        "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4),
