@@ -395,6 +395,13 @@ constexpr int SH_PLANE = 16 * 16 * 16 + 128;     // bytes per x-corner plane of 
 constexpr int SH_WAVE = 2 * SH_PLANE;
 constexpr int SH_WAVES = 4;                       // waves (= query rows) per workgroup
 
+// 16-byte record slot of (pair, level) inside a 256-byte row of records: rotated by two slots per level.  The owner lanes write
+// their records with ds_write_b128, which the LDS services in groups of 8 lanes = 2 pairs x 4 LEVELS: with slot = pair all four
+// levels of a pair land on the same bank quad (measured: SQ_LDS_BANK_CONFLICT = 60 % of SQ_LDS_IDX_ACTIVE in these kernels, all
+// of it record traffic); with the rotation a group covers 8 different quads, and the readers' groups (4 pairs of ONE level) stay
+// conflict-free as before.
+__device__ __forceinline__ int sh_slot(int pair, int level) { return ((pair + 2 * level) & 15) * 16; }
+
 struct ShGeo {                                    // what the owner lane keeps for the backward (its level's 4 points)
     float aw[4], fx[4], fy[4];
     uint32_t valid[4];                            // bit0 vx0, bit1 vx1, bit2 vy0, bit3 vy1
@@ -456,7 +463,7 @@ __device__ __forceinline__ void sh_prepare(const MsdaP& p, const ShRaw& raw, flo
     const float rx = rf.x * (float)Wl - 0.5f, ry = rf.y * (float)Hl - 0.5f;
     const uint32_t pix_bytes = (uint32_t)p.vs_s * 2u;
     const uint32_t base = (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m) * 2) + (uint32_t)Sl * pix_bytes;
-    char* rec = wlds + (o * 4) * 256 + pair * 16;
+    char* rec = wlds + (o * 4) * 256 + sh_slot(pair, o);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float aw = e[i] * inv;
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
     char* wlds = lds + wave * SH_WAVE;
     // gather lanes: [pair][x corner xc][channel half]
     const int pair = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
-    const char* rd = wlds + xc * SH_PLANE + pair * 16;
+    const char* rd0 = wlds + xc * SH_PLANE;
     const uint32_t lane_off = (uint32_t)dsub * 16u;
     // the reference point of (row, level o) serves every pass.  (Requesting the NEXT pass's packed logits / offsets before this
     // pass's gathers was slower, 164 / 218 us against 156 / 200: memory returns in order, and an HBM-latency stream load ahead of
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
+            const char* rd = rd0 + sh_slot(pair, l);
             uint4 r[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(rd + (l * 4 + i) * 256);
@@ -566,8 +574,8 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
     const ShMap<QG> mp(p, unit, lane, rows);
     char* wlds = lds + wave * SH_WAVE;
     const int pair = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1, o = lane & 3;
-    char* slot = wlds + xc * SH_PLANE + pair * 16;
-    const char* own = wlds + (o * 4) * 256 + pair * 16;
+    char* slot0 = wlds + xc * SH_PLANE;
+    const char* own = wlds + (o * 4) * 256 + sh_slot(pair, o);
     const uint32_t lane_off = (uint32_t)dsub * 16u;
     bf16_t* grow = reinterpret_cast<bf16_t*>(p.g1) + (int64_t)mp.row * p.ldg;
     const float2 rf = *reinterpret_cast<const float2*>(p.ref + (int64_t)mp.n * p.ref_bs + ((int64_t)mp.q * 4 + o) * 2);
@@ -581,6 +589,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
         const u32x4_t g = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.grad_out) + (int64_t)mp.row * 256 + m * 16 + dsub * 8);
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
+            char* slot = slot0 + sh_slot(pair, l);
             uint2 r[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint2*>(slot + (l * 4 + i) * 256);
@@ -662,7 +671,7 @@ __device__ __forceinline__ void hyb_prepare(const MsdaP& p, const HybP& hp, cons
     const uint32_t pix_bytes = staged ? 128u : (uint32_t)p.vs_s * 2u;
     const uint32_t base = staged ? (uint32_t)(Sl - hp.px_lc) * 128u + (uint32_t)(m & 3) * 32u
                                  : (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m) * 2) + (uint32_t)Sl * pix_bytes;
-    char* rec = wlds + (o * 4) * 256 + pair * 16;
+    char* rec = wlds + (o * 4) * 256 + sh_slot(pair, o);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float aw = e[i] * inv;
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(HYB_WAVES * 64) void msda_fwd_hyb_kernel(const Msda
     const int u_lo = (int)((int64_t)chunk * units / hp.chunks), u_hi = (int)((int64_t)(chunk + 1) * units / hp.chunks);
     const int pair = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
     const int qq = pair >> 2, hh = pair & 3, m = hq * 4 + hh;
-    const char* rd = wlds + xc * SH_PLANE + pair * 16;
+    const char* rd0 = wlds + xc * SH_PLANE;
     const uint32_t lane_off = (uint32_t)dsub * 16u;
 #pragma unroll 1
     for (int u = u_lo + wave; u < u_hi; u += HYB_WAVES) {
@@ -732,6 +741,7 @@ __global__ __launch_bounds__(HYB_WAVES * 64) void msda_fwd_hyb_kernel(const Msda
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
+            const char* rd = rd0 + sh_slot(pair, l);
             uint4 r[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(rd + (l * 4 + i) * 256);
