@@ -41,6 +41,9 @@ struct DwP {
     float* ws;            // optional workspace [splits][ntiles][128 x 128]: partial tiles leave by plain stores, dw_reduce_kernel merges
 };
 
+// LEAN (rows a multiple of the 64-row stage: every encoder shape of the benchmark): the stage loop without a single predicate --
+// see the block comment in front of the lean loop below.
+template <bool LEAN>
 __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -143,6 +146,94 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
         }
     };
 
+    if constexpr (LEAN) {
+        // The generic loop below issues ~280 instructions per stage and wave around its 32 MFMAs (round-4 disassembly: 118 VALU -- row
+        // clamps and value selects of the ragged-edge handling, 64-bit address arithmetic, LDS addresses recomputed per read -- 45
+        // s_waitcnt, 15 branches), and with two 4-wave workgroups per CU a wave is ONE instruction stream that issues every ~4-5
+        // cycles: the kernel sat on its issue rate, not on memory (matrix pipe 28 % busy).  With rows % 64 == 0 no stage is ragged, so:
+        // loads are SGPR base (advanced per stage) + a hoisted 32-bit lane offset; LDS stores and the 32 transposing reads are a
+        // hoisted lane address + an immediate (the loop is unrolled by two so that the buffer index is a compile-time constant); the
+        // prefetch past the last stage re-reads the last stage (uniform clamp) instead of being predicated.
+        const char* Yb = reinterpret_cast<const char*>(Yp);
+        const char* Xb = reinterpret_cast<const char*>(Xp);
+        const int64_t ystB = (int64_t)DW_RS * p.ldy * 2, xstB = (int64_t)DW_RS * p.ldx * 2;
+        uint32_t yoB[4], xoB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { yoB[i] = (uint32_t)yo[i] * 2u; xoB[i] = (uint32_t)xo[i] * 2u; }
+        auto loadL = [&](int s, uint4 (&y)[4], uint4 (&x)[4]) __attribute__((always_inline)) {
+            const int sc = min(s, nst - 1);                              // (uniform)
+            const char* yb = Yb + sc * ystB;
+            const char* xb = Xb + sc * xstB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                y[i] = *reinterpret_cast<const uint4*>(yb + yoB[i]);
+                x[i] = *reinterpret_cast<const uint4*>(xb + xoB[i]);
+            }
+        };
+        auto storeL = [&](char* buf, int st, const uint4 (&y)[4], const uint4 (&x)[4]) __attribute__((always_inline)) {
+            const bool sum = do_sum && st < s_hi;                         // (uniform; a stage past this workgroup's range is staged but never used)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (sum) {
+                    ys[0] += __uint_as_float(y[i].x << 16); ys[1] += __uint_as_float(y[i].x & 0xffff0000u);
+                    ys[2] += __uint_as_float(y[i].y << 16); ys[3] += __uint_as_float(y[i].y & 0xffff0000u);
+                    ys[4] += __uint_as_float(y[i].z << 16); ys[5] += __uint_as_float(y[i].z & 0xffff0000u);
+                    ys[6] += __uint_as_float(y[i].w << 16); ys[7] += __uint_as_float(y[i].w & 0xffff0000u);
+                }
+                *reinterpret_cast<uint4*>(buf + lo[i]) = make_uint4(y[i].x, y[i].y, y[i].z, y[i].w);
+                *reinterpret_cast<uint4*>(buf + DW_PANEL + lo[i]) = make_uint4(x[i].x, x[i].y, x[i].z, x[i].w);
+            }
+        };
+        // transposing-read lane addresses: [fragment] for the Y panel (this wave's 64 rows of the tile) and the X panel
+        int ty[4], tx[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            ty[f] = trow * DW_ROWB + ((((wm * 4 + f) ^ tswz) << 5) + tcol);
+            tx[f] = trow * DW_ROWB + ((((wn * 4 + f) ^ tswz) << 5) + tcol) + DW_PANEL;
+        }
+        auto computeL = [&](const char* sb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < DW_RS / 32; ++ks) {
+                bf16x8_t fy[4], fx[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    struct { v4s_t lo, hi; } u, v;
+                    u.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + ty[f] + ks * 32 * DW_ROWB));
+                    u.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + ty[f] + (ks * 32 + 4) * DW_ROWB));
+                    v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + tx[f] + ks * 32 * DW_ROWB));
+                    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + tx[f] + (ks * 32 + 4) * DW_ROWB));
+                    fy[f] = __builtin_bit_cast(bf16x8_t, u);
+                    fx[f] = __builtin_bit_cast(bf16x8_t, v);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[jj], acc[i][jj], 0, 0, 0);
+            }
+        };
+        loadL(s_lo, ry[0], rx[0]);
+        storeL(smem, s_lo, ry[0], rx[0]);
+        loadL(s_lo + 1, ry[0], rx[0]);
+        __syncthreads();
+        int s = s_lo;
+#pragma unroll 1
+        for (; s + 1 < s_hi; s += 2) {                                   // stage s in buffer 0, stage s + 1 in the registers
+            storeL(smem + DW_STAGE, s + 1, ry[0], rx[0]);
+            loadL(s + 2, ry[0], rx[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            computeL(smem);
+            __syncthreads();
+            storeL(smem, s + 2, ry[0], rx[0]);                            // (stage s + 2: computed by the next trip, or never read)
+            loadL(s + 3, ry[0], rx[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            computeL(smem + DW_STAGE);
+            __syncthreads();
+        }
+        if (s < s_hi) {                                                  // odd number of stages: the last one sits in buffer 0
+            computeL(smem);
+            __syncthreads();
+        }
+    } else {
     // prologue: stage s_lo -> LDS buffer 0; stage s_lo+1 -> registers
     load(s_lo, ry[0], rx[0]);
     store(smem, s_lo, ry[0], rx[0]);
@@ -159,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
         compute(smem + buf * DW_STAGE);
         __syncthreads();
         buf ^= 1;
+    }
     }
 
     // ---- bias gradient: 16 threads (tid >> 4) hold partial sums of the same 8 columns; fold them through LDS ----
@@ -250,14 +342,18 @@ bool gemm_dw_try(const GemmK& g, hipStream_t st) {
     const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE);
         attr_set = true;
     }
     // partial tiles through the caller's workspace when it is large enough (PoetGemmDesc.workspace), else fp32 atomics
     const int64_t need = (int64_t)p.splits * p.ntiles * DW_T * DW_T * 4;
     static const int no_ws = [] { const char* e = getenv("POET_DW_NO_WORKSPACE"); return e && atoi(e) ? 1 : 0; }();
     p.ws = (!no_ws && d.workspace && d.workspace_bytes >= need && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0) ? reinterpret_cast<float*>(d.workspace) : nullptr;
-    hipLaunchKernelGGL(gemm_dw_kernel, dim3(nblocks), dim3(256), 2 * DW_STAGE, st, p);
+    static const int no_lean = [] { const char* e = getenv("POET_DW_NO_LEAN"); return e && atoi(e) ? 1 : 0; }();      // (A/B aid)
+    if (p.rows % DW_RS == 0 && !no_lean && (int64_t)p.rows * p.ldy * 2 < (1LL << 32) && (int64_t)p.rows * p.ldx * 2 < (1LL << 32))
+        hipLaunchKernelGGL(gemm_dw_kernel<true>, dim3(nblocks), dim3(256), 2 * DW_STAGE, st, p);
+    else hipLaunchKernelGGL(gemm_dw_kernel<false>, dim3(nblocks), dim3(256), 2 * DW_STAGE, st, p);
     if (p.ws) hipLaunchKernelGGL(dw_reduce_kernel, dim3(DW_T * DW_T / 256, p.ntiles), dim3(256), 0, st, p, p.splits);
     return true;
 }
