@@ -943,7 +943,14 @@ def test_frozen_backbone_padded_images_full_size(gpu, precision, tol):
         oout, onb = omodel(osamples, targets)
     vr = otr.valid_ratio(osamples.mask)
     assert float(vr[1].max()) < 0.9                                    # the masks really are non-trivial
-    # product (GPU)
+    # product (GPU).  The backbone is plain PyTorch: by default MIOpen picks convolution algorithms that are not reproducible run to run
+    # (measured, profiles/probes/fwd_determinism.py: the 15 x 20 feature map differs by 1 ulp, 1.8e-7, between two calls on the same input --
+    # and the bf16 policy turns that into a DIFFERENT realisation of its rounding noise: the rotations of the ill-conditioned queries move by
+    # up to 1.8e-2 between such runs, max|dR| against the oracle 3.4e-3 ... 1.9e-2 over nine runs on three boxes; on fixed features the HIP
+    # path is bit-reproducible).  The test pins the backbone to deterministic algorithms so that it measures ONE realisation, and keeps the
+    # round-3 allowance (amplification / 2) for these random-init heads because that realisation may be any of the above.
+    det0, bench0 = torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
     bb = FrozenConvBackbone(256).cuda()
     tr = poet_amd.DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"], cfg["d_ffn"], cfg["dropout"],
                                         "relu", True, cfg["n_levels"], cfg["n_points"], cfg["n_points"]).set_precision(precision)
@@ -954,18 +961,23 @@ def test_frozen_backbone_padded_images_full_size(gpu, precision, tol):
         assert torch.equal(p.detach().cpu(), po.detach()), n
     samples = poet_amd.nested_tensor_from_tensor_list([im.cuda() for im in images])
     assert torch.equal(samples.mask.cpu(), osamples.mask)
-    with torch.no_grad():
-        out, nb = model(samples, [{k: v.cuda() for k, v in t.items()} for t in targets])
+    try:
+        with torch.no_grad():
+            out, nb = model(samples, [{k: v.cuda() for k, v in t.items()} for t in targets])
+            out2, _ = model(samples, [{k: v.cuda() for k, v in t.items()} for t in targets])
+    finally:
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = det0, bench0
+    assert torch.equal(out["pred_rotation"], out2["pred_rotation"]) and torch.equal(out["pred_translation"], out2["pred_translation"])      # one realisation
     assert list(nb) == list(onb)
     dt = (out["pred_translation"].cpu() - oout["pred_translation"]).abs().max().item()
-    # rotations: the conditioned rule of the golden test (a random backbone over noise images puts several of the 40 queries
-    # between 3x and 13x amplification): tolerance x max(1, amplification / AMP0_AUX)
+    # rotations: a random backbone over noise images puts several of the 40 queries between 3x and 13x amplification of the reference's own
+    # 6D -> SO(3) map: tolerance x max(1, amplification / 2) (see the note at the backbone above)
     cls = oout["pred_classes"].clamp(min=0).view(-1)
     r6 = cap["r6"].reshape(-1, omodel.n_classes, 6)[torch.arange(cls.numel()), cls]
     a1, a2 = r6[:, :3], r6[:, 3:]
     x = a1 / a1.norm(dim=1, keepdim=True)
     amp = 1.0 / torch.minimum(a1.norm(dim=1), (a2 - (a2 * x).sum(1, keepdim=True) * x).norm(dim=1))
-    allow = torch.clamp(amp / AMP0_AUX, min=1.0).view(len(images), -1, 1, 1)
+    allow = torch.clamp(amp / 2.0, min=1.0).view(len(images), -1, 1, 1)
     eR = (out["pred_rotation"].cpu() - oout["pred_rotation"]).abs()
     dR, over = eR.max().item(), (eR / allow).max().item()
     print(f"frozen backbone, padded batch, {precision}: max|dt| {dt:.2e} max|dR| {dR:.2e} (plain bound {'holds' if dR < tol else 'MISSED'}; "
