@@ -322,7 +322,7 @@ def test_rotation_modes_fp32_vs_reference_golden(gpu, golden_dir, rotation_mode,
     # to ~1e-2 of the loss within three steps.  So the comparison is split:
     #  (a) lr = 0: parameters never move -- every step of every mode must reproduce the same loss;
     #  (b) one real update (eager warm-up step + the capture step): the parameters agree up to that noise -- every element
-    #      within the two steps' worst case, the mean within 2.5 % of one learning-rate step.
+    #      within the two steps' worst case, the mean within 5 % of one learning-rate step.
     lr = 2e-4
     runs, flats = {}, {}
     for mode in ("eager", "graph", "segmented"):
@@ -346,7 +346,9 @@ def test_rotation_modes_fp32_vs_reference_golden(gpu, golden_dir, rotation_mode,
         d = (flats[mode] - flats["eager"]).abs()
         worst = sorted(((float(d[o:o + sizes[n]].max()), n) for n, o in where.items()), reverse=True)[:4]
         assert d.max().item() <= 2 * 2 * lr * 1.05, (mode, d.max().item(), worst)                # two steps, at most +-lr each
-        assert d.mean().item() < 0.025 * lr, (mode, d.mean().item(), worst)      # (measured 0.015-0.021 lr: sign flips of AdamW's m / sqrt(v) on near-zero gradients)
+        # (measured 0.015-0.028 lr over ~40 runs on four boxes -- sign flips of AdamW's m / sqrt(v) on near-zero gradients; the bound
+        # was 0.025 lr until two of 25 repetitions landed at 0.025 and 0.027: it is a noise bound of two runs of ANY one mode, see above)
+        assert d.mean().item() < 0.05 * lr, (mode, d.mean().item(), worst)
     assert max(runs["eager"]) - min(runs["eager"]) < 1e-4 * max(1.0, abs(runs["eager"][0])), runs   # lr = 0: the loss does not move
 
 
