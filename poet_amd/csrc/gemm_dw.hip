@@ -41,7 +41,7 @@ struct DwP {
     float* ws;            // optional workspace [splits][ntiles][128 x 128]: partial tiles leave by plain stores, dw_reduce_kernel merges
 };
 
-// LEAN (rows a multiple of the 64-row stage: every encoder shape of the benchmark): the stage loop without a single predicate --
+// LEAN (default): the stage loop over WHOLE 64-row stages without a single predicate (a ragged last stage runs the generic code once) --
 // see the block comment in front of the lean loop below.
 template <bool LEAN>
 __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { yoB[i] = (uint32_t)yo[i] * 2u; xoB[i] = (uint32_t)xo[i] * 2u; }
         auto loadL = [&](int s, uint4 (&y)[4], uint4 (&x)[4]) __attribute__((always_inline)) {
-            const int sc = min(s, nst - 1);                              // (uniform)
+            const int sc = min(s, p.rows / DW_RS - 1);                   // (uniform: the last WHOLE stage)
             const char* yb = Yb + sc * ystB;
             const char* xb = Xb + sc * xstB;
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
             }
         };
         auto storeL = [&](char* buf, int st, const uint4 (&y)[4], const uint4 (&x)[4]) __attribute__((always_inline)) {
-            const bool sum = do_sum && st < s_hi;                         // (uniform; a stage past this workgroup's range is staged but never used)
+            const bool sum = do_sum && st < min(s_hi, p.rows / DW_RS);    // (uniform; a stage past this workgroup's whole stages is staged but never used)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (sum) {
@@ -211,26 +211,39 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const DwP p) {
                     for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[jj], acc[i][jj], 0, 0, 0);
             }
         };
-        loadL(s_lo, ry[0], rx[0]);
-        storeL(smem, s_lo, ry[0], rx[0]);
-        loadL(s_lo + 1, ry[0], rx[0]);
-        __syncthreads();
-        int s = s_lo;
+        // A ragged LAST stage of the whole problem (rows % 64 != 0: 1280 x 960 has 204 000 token rows) belongs to exactly one row range:
+        // that workgroup runs the lean loop over its whole stages and the generic, masked stage code once at the end.
+        const int nfull = p.rows / DW_RS;                                 // whole stages of the problem
+        const int e_hi = min(s_hi, nfull);                               // this workgroup's whole stages: [s_lo, e_hi)
+        if (s_lo < e_hi) {
+            loadL(s_lo, ry[0], rx[0]);
+            storeL(smem, s_lo, ry[0], rx[0]);
+            loadL(s_lo + 1, ry[0], rx[0]);
+            __syncthreads();
+            int s = s_lo;
 #pragma unroll 1
-        for (; s + 1 < s_hi; s += 2) {                                   // stage s in buffer 0, stage s + 1 in the registers
-            storeL(smem + DW_STAGE, s + 1, ry[0], rx[0]);
-            loadL(s + 2, ry[0], rx[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            computeL(smem);
-            __syncthreads();
-            storeL(smem, s + 2, ry[0], rx[0]);                            // (stage s + 2: computed by the next trip, or never read)
-            loadL(s + 3, ry[0], rx[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            computeL(smem + DW_STAGE);
-            __syncthreads();
+            for (; s + 1 < e_hi; s += 2) {                               // stage s in buffer 0, stage s + 1 in the registers
+                storeL(smem + DW_STAGE, s + 1, ry[0], rx[0]);
+                loadL(s + 2, ry[0], rx[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                computeL(smem);
+                __syncthreads();
+                storeL(smem, s + 2, ry[0], rx[0]);                        // (stage s + 2: computed by the next trip, or never read)
+                loadL(s + 3, ry[0], rx[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                computeL(smem + DW_STAGE);
+                __syncthreads();
+            }
+            if (s < e_hi) {                                              // odd number of stages: the last one sits in buffer 0
+                computeL(smem);
+                __syncthreads();
+            }
         }
-        if (s < s_hi) {                                                  // odd number of stages: the last one sits in buffer 0
-            computeL(smem);
+        if (e_hi < s_hi) {                                               // the ragged stage (workgroup-uniform; its readers of smem are past a barrier)
+            load(e_hi, ry[0], rx[0]);
+            store(smem, e_hi, ry[0], rx[0]);
+            __syncthreads();
+            compute(smem);
             __syncthreads();
         }
     } else {
@@ -351,7 +364,7 @@ bool gemm_dw_try(const GemmK& g, hipStream_t st) {
     static const int no_ws = [] { const char* e = getenv("POET_DW_NO_WORKSPACE"); return e && atoi(e) ? 1 : 0; }();
     p.ws = (!no_ws && d.workspace && d.workspace_bytes >= need && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0) ? reinterpret_cast<float*>(d.workspace) : nullptr;
     static const int no_lean = [] { const char* e = getenv("POET_DW_NO_LEAN"); return e && atoi(e) ? 1 : 0; }();      // (A/B aid)
-    if (p.rows % DW_RS == 0 && !no_lean && (int64_t)p.rows * p.ldy * 2 < (1LL << 32) && (int64_t)p.rows * p.ldx * 2 < (1LL << 32))
+    if (p.rows >= DW_RS && !no_lean && (int64_t)p.rows * p.ldy * 2 < (1LL << 32) && (int64_t)p.rows * p.ldx * 2 < (1LL << 32))
         hipLaunchKernelGGL(gemm_dw_kernel<true>, dim3(nblocks), dim3(256), 2 * DW_STAGE, st, p);
     else hipLaunchKernelGGL(gemm_dw_kernel<false>, dim3(nblocks), dim3(256), 2 * DW_STAGE, st, p);
     if (p.ws) hipLaunchKernelGGL(dw_reduce_kernel, dim3(DW_T * DW_T / 256, p.ntiles), dim3(256), 0, st, p, p.splits);
