@@ -319,6 +319,36 @@ def cpu_baseline(cfg, max_seconds=40.0):
                      f"{n0} timed steps after 3 warm-up ({1e3 * sec0:.1f} ms/step)"}}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): re-execute this command line as N ranks
+    of ONE node through torch.distributed.run on a free loopback port -- exactly the command the driver uses (one process per GPU,
+    launch_distributed.py:74-92 / main.py:219-231 in the reference).  The ranks inherit stdout: rank 0 still prints the ONE JSON
+    line.  The exit code is the launcher's."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n}: this node shows {have} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def time_steps(trainer, samples, targets, n, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        trainer.step(samples, targets)
+    sync()
+    return 1000.0 * (time.perf_counter() - t0) / n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,8 +366,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("POET_BENCH_SELF_LAUNCH", "0") not in ("", "0")):
+        # (POET_BENCH_SELF_LAUNCH=1 takes the launcher path at --gpus 1 too: with POET_FORCE_COLLECTIVES=1 a one-GPU box then runs
+        # the whole N > 1 code path -- launcher, RCCL group, DP mode trial, exposed-collective timing -- with one rank)
+        return self_launch(args.gpus)                          # plain `python bench.py --gpus N`: become the launcher of N ranks
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus})")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     forced = os.environ.get("POET_FORCE_COLLECTIVES", "0") not in ("", "0")    # 1-rank RCCL group: exercises the N > 1 code path on one GPU
@@ -354,13 +388,6 @@ def main():
     torch.manual_seed(1234)                                      # identical init on every rank (then broadcast anyway)
     poet_amd.manual_seed(1234 + rank)
     feats, targets = synth_batch(cfg, batch, 1234 + rank, device)
-    model, crit = build_model(cfg, feats, args.precision, device)
-    model.train()
-    if args.no_graphs:
-        trainer = poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1)
-    else:
-        trainer = poet_amd.GraphedTrainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=2)
-        args.warmup = max(args.warmup, 4)                       # 2 eager steps + capture + 1 replay before timing
     ih, iw = cfg["image_hw"]
     samples = poet_amd.NestedTensor(None, torch.zeros((batch, ih, iw), dtype=torch.bool, device=device))
 
@@ -369,6 +396,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def make_trainer():
+        torch.manual_seed(1234)
+        model, crit = build_model(cfg, feats, args.precision, device)
+        model.train()
+        if args.no_graphs:
+            return poet_amd.Trainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1)
+        return poet_amd.GraphedTrainer(model, crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=2)
+
+    dp_trial = None
+    if dist.is_initialized() and not args.no_graphs and "POET_DP_SINGLE_COLLECTIVE" not in os.environ:
+        # Data-parallel launch mode chosen by MEASUREMENT on this node, not by a 1-rank trace: both modes are captured (each on
+        # its own model instance, same seed), 3 replayed steps of each are timed over all ranks (max), the faster one runs the
+        # timed region.  "single" = one backward graph + ONE all-reduce of the flat gradient arena behind it; "buckets" = one
+        # backward segment per gradient bucket with its all-reduce on the comm stream under the later segments (main.py:282's
+        # DDP overlap).  POET_DP_SINGLE_COLLECTIVE=0/1 in the environment skips the trial.
+        dp_trial, cands = {}, {}
+        for mode, flag in (("single", "1"), ("buckets", "0")):
+            os.environ["POET_DP_SINGLE_COLLECTIVE"] = flag
+            t = make_trainer()
+            for _ in range(4):                                  # 2 eager steps + capture + 1 replay
+                t.step(samples, targets)
+            ms_mode = torch.tensor([time_steps(t, samples, targets, 3, sync)], dtype=torch.float64, device=device)
+            dist.all_reduce(ms_mode, op=dist.ReduceOp.MAX)
+            dp_trial[mode + "_ms_per_step"] = round(float(ms_mode.item()), 3)
+            cands[mode] = t
+        del os.environ["POET_DP_SINGLE_COLLECTIVE"]
+        best = min(("single", "buckets"), key=lambda m: dp_trial[m + "_ms_per_step"])      # identical on every rank (all-reduced)
+        dp_trial["chosen"] = best
+        trainer = cands.pop(best)
+        cands.clear()
+        torch.cuda.empty_cache()
+    else:
+        trainer = make_trainer()
+    model = trainer.model
+    if not args.no_graphs:
+        args.warmup = max(args.warmup, 4)                       # 2 eager steps + capture + 1 replay before timing
     for _ in range(args.warmup):
         trainer.step(samples, targets)
     sync()
@@ -385,6 +448,18 @@ def main():
     trainer.step(samples, targets)
     t_host = time.perf_counter() - t1
     sync()
+    exposed = None
+    if dist.is_initialized() and not args.no_graphs and getattr(trainer, "segs", None) is not None:
+        # what the gradient all-reduces cost on the critical path: the same replayed step with the collectives left out (the ranks'
+        # parameters drift apart for these 3 steps -- AFTER the timed region, nothing measured depends on them)
+        with_ms = time_steps(trainer, samples, targets, 3, sync)
+        trainer.skip_collectives = True
+        without_ms = time_steps(trainer, samples, targets, 3, sync)
+        trainer.skip_collectives = False
+        tt = torch.tensor([with_ms, without_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        exposed = {"with_collectives_ms": round(float(tt[0]), 3), "without_collectives_ms": round(float(tt[1]), 3),
+                   "allreduce_exposed_ms": round(float(tt[0] - tt[1]), 3)}
     prof, prof_steps = None, 3
     if not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, over 3 EXTRA steps of the same workload right after the
@@ -427,6 +502,7 @@ def main():
                        **({"dp_mode": ("one backward graph + ONE all-reduce of the flat gradient arena" if getattr(trainer, "single_collective", False)
                                        else "one backward segment + one all-reduce per gradient bucket (comm stream)") +
                                       f", gradients travel as {os.environ.get('POET_DP_GRAD_DTYPE', 'fp32')}"} if dist.is_initialized() else {}),
+                       **({"dp_mode_trial": dp_trial} if dp_trial else {}), **(exposed or {}),
                        "launch": "eager" if args.no_graphs else ("hipGraph replay (fwd + matcher + loss graph, bwd + clip + AdamW graph)" if getattr(trainer, "graph_loss", False) else "hipGraph replay (fwd graph, eager loss, bwd+opt graph)"),
                        "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
                        "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4),

@@ -20,7 +20,8 @@ ALIGN = 64   # elements (256 B): every parameter starts on a 16-B-aligned, vecto
 # parameter-name prefixes of the hot path (pose_estimation_transformer.py:85-144 heads / input_proj; the transformer)
 HOT_PREFIXES = ("input_proj.", "transformer.", "translation_head", "rotation_head", "query_embed.", "backbone.1.")
 # ("backbone.1." = the Joiner's position embedding when it is a learned one (position_encoding.py:87-112): trained by the path's
-# own backward (functional.PosEmbedFn); like every "backbone" parameter it steps at lr_backbone, main.py:253-271)
+# own backward (functional.PosEmbedFn).  It steps at the MAIN learning rate: the reference's lr_backbone group is
+# lr_backbone_names = ['backbone.0'] (main.py:39,253-271), which matches the detector body only, never backbone.1.*)
 
 
 _ENC_LAYER = re.compile(r"^transformer\.encoder\.layers\.(\d+)\.")
@@ -118,7 +119,9 @@ class ParamArena:
                 cur, start = b, off
             self.entries.append((n, p, off))
             size = -(-p.numel() // ALIGN) * ALIGN
-            scale += [lr_proj_mult if is_proj(n) else (lr_backbone_mult if n.startswith("backbone.") else 1.0)] * (size // ALIGN)
+            # lr_backbone applies to names matching 'backbone.0' only (main.py:39,253-271); HOT_PREFIXES keeps backbone.0.* out of the arena,
+            # so this branch is for a caller that widens the prefixes -- backbone.1.* (learned position encoding) steps at the main lr
+            scale += [lr_proj_mult if is_proj(n) else (lr_backbone_mult if "backbone.0" in n else 1.0)] * (size // ALIGN)
             off += size
         self.buckets.append((cur, start, off))
         self.n_main = off
@@ -851,7 +854,7 @@ class _Replay(torch.autograd.Function):
         if t.segs is None:
             t.g_bwd.replay()                 # backward + clip + AdamW in one graph (single GPU)
             return None, None
-        reduce = t.reducer is not None and t.reducer.active
+        reduce = t.reducer is not None and t.reducer.active and not getattr(t, "skip_collectives", False)   # (bench.py: exposed-collective timing)
         for g, tags in zip(t.segs, t.seg_tags):
             g.replay()
             if reduce:

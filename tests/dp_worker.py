@@ -61,7 +61,9 @@ def main():
             assert [t for tags in tr.seg_tags for t in tags] == [b[0] for b in tr.arena.buckets]
     assert tr.reducer is not None and tr.reducer.active
     flat = torch.cat([p.detach().float().flatten() for p in r["model"].parameters()]).cpu().numpy()
-    np.savez(out, flat=flat, losses=np.array(losses))
+    # the clip norm the optimiser saw in the last step: |mean over ranks of the gradient| (AdamW is invariant to the gradient's scale,
+    # so a wrong 1 / world fold is invisible in the parameters -- it shows HERE)
+    np.savez(out, flat=flat, losses=np.array(losses), gnorm=float(tr.arena.grad_norm()))
     dist.destroy_process_group()
 
 

@@ -8,11 +8,19 @@ from oracle.formula import CONFIGS, formula_fill, make_inputs
 
 def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False,
                   bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
-                  ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine"):
+                  ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine", replicate=None):
+    """replicate=B: the batch is B copies of image 0 of the (batch, pad) inputs -- features, size and targets alike.  Images of
+    a batch are independent and every loss term is a sum over matched objects divided by the batch's object count, so every
+    per-image output, every loss value and every parameter gradient equals the single-image run's: a golden of the real
+    reference at batch 1 pins a launch of B times the token rows."""
     if not isinstance(precision, str):
         precision = "fp32" if precision == torch.float32 else "bf16"
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
+    if replicate:
+        feats = [f[:1].repeat(replicate, 1, 1, 1).contiguous() for f in feats]
+        sizes = [sizes[0]] * replicate
+        targets = [{k: v.clone() for k, v in targets[0].items()} for _ in range(replicate)]
     fd = feat_dtype or torch.float32
     gfeats = [f.cuda().to(fd) for f in feats]
     bb = SyntheticBackbone(gfeats, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions,

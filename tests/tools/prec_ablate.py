@@ -106,7 +106,7 @@ def main():
     iseed, wseed = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1234, 4321)
     torch.set_num_threads(8)
     cfg = CONFIGS[os.environ.get("CONFIG", "ycbv")]
-    feats, sizes, targets = make_inputs(cfg, seed=iseed, batch=1, pad=False)
+    feats, sizes, targets = make_inputs(cfg, seed=iseed, batch=int(os.environ.get("BATCH", "1")), pad=bool(os.environ.get("PAD")))
     torch.manual_seed(wseed)
     model, _ = poet_ref.build_poet(cfg, feats)
     if os.environ.get("FORMULA"):
