@@ -14,8 +14,11 @@ struct GemmK {
 
 // launches the streaming kernel and returns true when the problem is one it handles; false = use the generic kernel
 bool gemm_ws_try(const GemmK& p, hipStream_t st);
-// register-stationary kernel for the wide (N % 256 == 0, N >= 512) split-weight forward products with K = 256 (gemm_wr.hip)
+#ifdef POET_PROBE_KERNELS
+// register-stationary kernel for the wide (N % 256 == 0, N >= 512) split-weight forward products with K = 256: measured equal to
+// gemm_ws, lives in profiles/probes/kernels/gemm_wr.hip and is compiled only into probe builds (POET_BUILD_PROBES=1)
 bool gemm_wr_try(const GemmK& p, hipStream_t st);
+#endif
 // same contract for the weight-gradient kernel (gemm_dw.hip)
 bool gemm_dw_try(const GemmK& p, hipStream_t st);
 // plain tall-skinny bf16 x bf16 -> fp32 (+=) products with N = 256, K >= 512: the deep-pipeline kernel (gemm_pipe.hip)

@@ -530,11 +530,13 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     }
     POET_CHECK(d.B_lo == nullptr, POET_ERR_UNSUPPORTED,
                "poet_gemm: two-image split weights (B_lo) only in the long-K kernel (N = 256, K >= 512, K %% 64 == 0, M >= 4096)");
-    if (gemm_wr_try(p, st)) {                               // wide split-weight forward products, K = 256: weights in registers (gemm_wr.hip)
+#ifdef POET_PROBE_KERNELS
+    if (gemm_wr_try(p, st)) {                               // (probe build only: profiles/probes/kernels/gemm_wr.hip, POET_GEMM_WR=1)
         g_last_path = POET_GEMM_PATH_STREAM;
         POET_LAUNCH_CHECK();
         return POET_OK;
     }
+#endif
     if (gemm_ws_try(p, st)) {
         g_last_path = POET_GEMM_PATH_STREAM;
         POET_LAUNCH_CHECK();

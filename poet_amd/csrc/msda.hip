@@ -631,158 +631,9 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
 }
 
 
-// ---- hybrid gathers: coarse levels from LDS, fine levels through L1 -----------------------------------------------------------
-// The shared-geometry kernels above sit at the per-CU L1's look-up rate (profiles/round3_ycbv_pmc_gather.csv), and HALF of all
-// samples go to the two coarse levels, whose maps are tiny: 15 x 20 + 8 x 10 = 380 pixels at 640 x 480.  Here a workgroup is bound
-// to ONE (image, head quarter) and stages those levels' bf16 value rows of its 4 heads in LDS once -- layout [pixel][4 heads][16 ch]
-// = 128 B per pixel: the 16 lanes of an LDS read group are 4 (query, head) pairs with 4 DIFFERENT heads, a pair's 4 lanes [x corner]
-// [channel half] read 2 x 32 B of two x-adjacent pixels (opposite bank halves), so every ds_read_b128 group covers all 64 banks
-// exactly once -- and walks its share of the image's query rows: the records of levels >= lc carry LDS byte offsets, the gather
-// loop reads them with ds_read_b128, the fine levels keep their global loads.  lc = the finest level from which everything coarser
-// fits HYB_MAP bytes (640 x 480: levels 2-3; LM-O: 1-3; 1280 x 960: level 3).
-constexpr int HYB_WAVES = 8;
-constexpr int HYB_MAP = 50 * 1024;
-struct HybP { int lc, px_lc, chunks; };                       // first staged level, first pixel of it, query chunks per (image, quarter)
-
-template <bool KEEP, bool QH>
-__device__ __forceinline__ void hyb_prepare(const MsdaP& p, const HybP& hp, const ShRaw& raw, float2 rf, int n, int m, int lane, char* wlds, ShGeo& gk) {
-    const int pair = lane >> 2, o = lane & 3;
-    float lg[4], off[8];
-    lg[0] = q_lo<QH>(raw.lg.x); lg[1] = q_hi<QH>(raw.lg.x);
-    lg[2] = q_lo<QH>(raw.lg.y); lg[3] = q_hi<QH>(raw.lg.y);
-    off[0] = q_lo<QH>(raw.off.x); off[1] = q_hi<QH>(raw.off.x);
-    off[2] = q_lo<QH>(raw.off.y); off[3] = q_hi<QH>(raw.off.y);
-    off[4] = q_lo<QH>(raw.off.z); off[5] = q_hi<QH>(raw.off.z);
-    off[6] = q_lo<QH>(raw.off.w); off[7] = q_hi<QH>(raw.off.w);
-    float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
-    mx = fmaxf(mx, quad_xor1(mx)); mx = fmaxf(mx, quad_xor2(mx));
-    float e[4], sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { e[i] = __expf(lg[i] - mx); sum += e[i]; }
-    sum += quad_xor1(sum); sum += quad_xor2(sum);
-    const float inv = __builtin_amdgcn_rcpf(sum);
-    int Wl = p.W[0], Hl = p.H[0], Sl = p.start[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if (o == k) { Wl = p.W[k]; Hl = p.H[k]; Sl = p.start[k]; }
-    const float rx = rf.x * (float)Wl - 0.5f, ry = rf.y * (float)Hl - 0.5f;
-    // levels < lc: byte offsets into the head-major value maps; levels >= lc: byte offsets into the staged maps (128 B per pixel)
-    const bool staged = o >= hp.lc;
-    const uint32_t pix_bytes = staged ? 128u : (uint32_t)p.vs_s * 2u;
-    const uint32_t base = staged ? (uint32_t)(Sl - hp.px_lc) * 128u + (uint32_t)(m & 3) * 32u
-                                 : (uint32_t)(((int64_t)n * p.vs_n + (int64_t)m * p.vs_m) * 2) + (uint32_t)Sl * pix_bytes;
-    char* rec = wlds + (o * 4) * 256 + sh_slot(pair, o);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float aw = e[i] * inv;
-        const float px = off[2 * i] + rx, py = off[2 * i + 1] + ry;
-        const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
-        const int x0 = (int)x0f, y0 = (int)y0f;
-        const int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);
-        const bool vx0 = (unsigned)x0 < (unsigned)Wl, vx1 = (unsigned)x1 < (unsigned)Wl;
-        const bool vy0 = (unsigned)y0 < (unsigned)Hl, vy1 = (unsigned)y1 < (unsigned)Hl;
-        const uint32_t r0 = mad24(clamp0(y0, Hl - 1), Wl, 0u), r1 = mad24(clamp0(y1, Hl - 1), Wl, 0u);
-        const uint32_t c0 = (uint32_t)clamp0(x0, Wl - 1), c1 = (uint32_t)clamp0(x1, Wl - 1);
-        const float wy0 = vy0 ? (1.f - fy) * aw : 0.f, wy1 = vy1 ? fy * aw : 0.f;
-        const float wx0 = vx0 ? 1.f - fx : 0.f, wx1 = vx1 ? fx : 0.f;
-        uint4 a, b;
-        a.x = mad24(r0 + c0, pix_bytes, base); a.y = mad24(r1 + c0, pix_bytes, base);
-        a.z = __float_as_uint(wy0 * wx0);      a.w = __float_as_uint(wy1 * wx0);
-        b.x = mad24(r0 + c1, pix_bytes, base); b.y = mad24(r1 + c1, pix_bytes, base);
-        b.z = __float_as_uint(wy0 * wx1);      b.w = __float_as_uint(wy1 * wx1);
-        *reinterpret_cast<uint4*>(rec + i * 256) = a;
-        *reinterpret_cast<uint4*>(rec + i * 256 + SH_PLANE) = b;
-        if constexpr (KEEP) {
-            gk.aw[i] = aw; gk.fx[i] = fx; gk.fy[i] = fy;
-            gk.valid[i] = (vx0 ? 1u : 0u) | (vx1 ? 2u : 0u) | (vy0 ? 4u : 0u) | (vy1 ? 8u : 0u);
-        }
-    }
-    sh_wave_sync();
-}
-
-// stage the levels >= lc of heads [4 hq, 4 hq + 4) of image n: [pixel][head][16 ch]
-__device__ __forceinline__ void hyb_stage(const MsdaP& p, const HybP& hp, int n, int hq, char* cmap, int tid, int nt) {
-    const int npx = p.S - hp.px_lc;
-    const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.value) + (int64_t)n * p.vs_n + (int64_t)hp.px_lc * p.vs_s;
-    for (int i = tid; i < npx * 8; i += nt) {                // item = (pixel, head, channel half), 16 B
-        const int half = i & 1, h = (i >> 1) & 3, px = i >> 3;
-        *reinterpret_cast<uint4*>(cmap + px * 128 + h * 32 + half * 16) =
-            *reinterpret_cast<const uint4*>(vb + (int64_t)(hq * 4 + h) * p.vs_m + (int64_t)px * p.vs_s + half * 8);
-    }
-}
-
-template <bool QH>
-__global__ __launch_bounds__(HYB_WAVES * 64) void msda_fwd_hyb_kernel(const MsdaP p, const HybP hp) {
-    extern __shared__ __attribute__((aligned(16))) char hyb_lds[];    // staged maps | HYB_WAVES x SH_WAVE records
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = blockIdx.x % hp.chunks, hq = (blockIdx.x / hp.chunks) & 3, n = blockIdx.x / (hp.chunks * 4);
-    const int map_bytes = (p.S - hp.px_lc) * 128;
-    char* cmap = hyb_lds;
-    char* wlds = hyb_lds + map_bytes + wave * SH_WAVE;
-    hyb_stage(p, hp, n, hq, cmap, threadIdx.x, HYB_WAVES * 64);
-    __syncthreads();
-    // this workgroup's query units (4 consecutive queries each) of image n
-    const int units = (p.Lq + 3) >> 2;
-    const int u_lo = (int)((int64_t)chunk * units / hp.chunks), u_hi = (int)((int64_t)(chunk + 1) * units / hp.chunks);
-    const int pair = lane >> 2, xc = (lane >> 1) & 1, dsub = lane & 1;
-    const int qq = pair >> 2, hh = pair & 3, m = hq * 4 + hh;
-    const char* rd0 = wlds + xc * SH_PLANE;
-    const uint32_t lane_off = (uint32_t)dsub * 16u;
-#pragma unroll 1
-    for (int u = u_lo + wave; u < u_hi; u += HYB_WAVES) {
-        const int qraw = u * 4 + qq;
-        const bool live = qraw < p.Lq;
-        const int q = live ? qraw : p.Lq - 1;
-        const int row = n * p.Lq + q;
-        const float2 rf = *reinterpret_cast<const float2*>(p.ref + (int64_t)n * p.ref_bs + ((int64_t)q * 4 + (lane & 3)) * 2);
-        ShGeo unused;
-        const ShRaw raw = sh_load(p, row, m, lane & 3);
-        hyb_prepare<false, QH>(p, hp, raw, rf, n, m, lane, wlds, unused);
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int l = 0; l < 4; ++l) {
-            const char* rd = rd0 + sh_slot(pair, l);
-            uint4 r[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(rd + (l * 4 + i) * 256);
-            Raw8<bf16_t> v0[4], v1[4];
-            if (l >= hp.lc) {                                 // (wave-uniform)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v0[i].v = *reinterpret_cast<const u32x4_t*>(cmap + r[i].x + lane_off);
-                    v1[i].v = *reinterpret_cast<const u32x4_t*>(cmap + r[i].y + lane_off);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float w0 = __uint_as_float(r[i].z), w1 = __uint_as_float(r[i].w);
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[i].f(ch), acc[ch]);
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
-            }
-        }
-        sh_wave_sync();
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) acc[ch] += quad_xor2(acc[ch]);
-        if (!xc && live) {
-            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (int64_t)row * 256 + m * 16 + dsub * 8;
-            vec<bf16_t, 8>::st(op, acc);
-        }
-    }
-}
-
-// first level from which everything coarser fits the staged-map budget (0 < lc <= 3), or -1
-static int hyb_first_level(const MsdaP& p) {
-    int lo = 1;
-    { const char* e = getenv("POET_HYB_LC"); if (e && atoi(e) >= 1 && atoi(e) <= 3) lo = atoi(e); }     // experiment: stage fewer levels
-    for (int lc = lo; lc <= 3; ++lc)
-        if ((size_t)(p.S - p.start[lc]) * 128 <= (size_t)HYB_MAP) return lc;
-    return -1;
-}
+#ifdef POET_PROBE_KERNELS
+#include "../../profiles/probes/kernels/msda_fwd_hyb.inc"
+#endif
 
 // packed bf16x2 memory-side atomic add (global_atomic_pk_add_bf16): `p2` = the even channel of a pair (4-byte aligned)
 typedef short gv_short2_t __attribute__((ext_vector_type(2)));
@@ -1179,599 +1030,13 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     if constexpr (L > 3) flush_level(p.W[3], p.H[3], p.start[3]);
 }
 
-// ====================================================================================================================
-// Encoder gathers with LDS-STAGED VALUE WINDOWS (grid queries, bf16, D = 16, P = 4): forward and d(offsets | logits).
-// Workgroup = (spatial tile, HPW heads, image), the tiling of the scatter above.  It first copies the bf16 value windows of
-// its heads (tile + halo of every level, 32 B per pixel and head) from the head-major maps into LDS with coalesced 16-B
-// loads -- each value pixel is read from L2/HBM ~2x (halo) per launch instead of ~64x through the per-CU L1 -- and then
-// every thread walks (query, head) items of the tile: ONE lane owns all 16 channels of its item, so the softmax, the
-// sampling geometry and (backward) the three reductions are plain per-lane arithmetic with no cross-lane traffic, and the 4
-// corners of a sample are 8 ds_read_b128.  A sample with an in-image corner outside the window (large learned offset,
-// padded image) takes the global-memory path for that sample, so results never depend on the halo.
-struct GTileP { int TX, TY, HALO, HPW; };
-constexpr int WIN_NT = 512;
+#ifdef POET_PROBE_KERNELS
+#include "../../profiles/probes/kernels/msda_win.inc"
+#endif
 
-struct WinGeo {                    // per-level window of this tile (uniform across the workgroup -> SGPRs)
-    int wx0, wy0, ww, wh, loff;
-};
-
-template <int L>
-__device__ __forceinline__ int win_layout(const MsdaP& p, const GTileP& tp, int tx, int ty, WinGeo (&wg)[L]) {
-    int off = 0;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int W = p.W[l], H = p.H[l];
-        const int ax = max((tx * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((tx + 1) * W, tp.TX) + tp.HALO, W);
-        const int ay = max((ty * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((ty + 1) * H, tp.TY) + tp.HALO, H);
-        wg[l].wx0 = ax; wg[l].wy0 = ay; wg[l].ww = bx - ax; wg[l].wh = by - ay; wg[l].loff = off;
-        off += wg[l].ww * wg[l].wh;
-    }
-    return off;
-}
-
-template <int L>
-__device__ __forceinline__ void win_fill(const MsdaP& p, const WinGeo (&wg)[L], int tot, int hpw, int n, int m0, uint4* win, int tid, int nt) {
-    const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.value) + (int64_t)n * p.vs_n;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int npx2 = wg[l].ww * wg[l].wh * 2, cnt = npx2 * hpw;
-        const float inv_n = 1.f / (float)npx2, inv_w = 1.f / (float)wg[l].ww;
-        for (int i = tid; i < cnt; i += nt) {
-            const int h = idiv_small(i, npx2, inv_n), r = i - h * npx2;
-            const int pix = r >> 1, half = r & 1;
-            const int y = idiv_small(pix, wg[l].ww, inv_w), x = pix - y * wg[l].ww;
-            const bf16_t* src = vb + (int64_t)(m0 + h) * p.vs_m + (int64_t)(p.start[l] + (wg[l].wy0 + y) * p.W[l] + wg[l].wx0 + x) * p.vs_s + half * 8;
-            win[(h * tot + wg[l].loff + pix) * 2 + half] = *reinterpret_cast<const uint4*>(src);
-        }
-    }
-}
-
-// the 4 corners (16 channels each, raw bf16 pairs) of one sample + their masked bilinear weights
-struct Sample {
-    uint4 c[4][2];                 // [corner 00, 01, 10, 11][channel half]
-    float fx, fy;
-    float v00, v01, v10, v11;      // validity (1 inside the image, else 0)
-};
-
-__device__ __forceinline__ void sample_corners(const MsdaP& p, const WinGeo& w, int Wl, int Hl, int startl, const uint4* winh,
-                                               const bf16_t* vhead, float px, float py, Sample& s) {
-    const float x0f = floorf(px), y0f = floorf(py);
-    s.fx = px - x0f; s.fy = py - y0f;
-    const int x0 = (int)x0f, y0 = (int)y0f;                    // v_cvt saturates; every use is an unsigned range test or a clamp
-    const int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);
-    const bool ix0 = (unsigned)x0 < (unsigned)Wl, ix1 = (unsigned)x1 < (unsigned)Wl;
-    const bool iy0 = (unsigned)y0 < (unsigned)Hl, iy1 = (unsigned)y1 < (unsigned)Hl;
-    s.v00 = (ix0 && iy0) ? 1.f : 0.f; s.v01 = (ix1 && iy0) ? 1.f : 0.f;
-    s.v10 = (ix0 && iy1) ? 1.f : 0.f; s.v11 = (ix1 && iy1) ? 1.f : 0.f;
-    const int lx0 = x0 - w.wx0, ly0 = y0 - w.wy0;
-    const int lx1 = (int)((unsigned)lx0 + 1u), ly1 = (int)((unsigned)ly0 + 1u);
-    const bool wx0 = (unsigned)lx0 < (unsigned)w.ww, wx1 = (unsigned)lx1 < (unsigned)w.ww;
-    const bool wy0 = (unsigned)ly0 < (unsigned)w.wh, wy1 = (unsigned)ly1 < (unsigned)w.wh;
-    // windows are clipped to the image, so "in window" implies "in image"; far = in the image but outside the window
-    const bool far = (ix0 && iy0 && !(wx0 && wy0)) || (ix1 && iy0 && !(wx1 && wy0)) || (ix0 && iy1 && !(wx0 && wy1)) || (ix1 && iy1 && !(wx1 && wy1));
-    if (!far) {
-        const int cx0 = clamp0(lx0, w.ww - 1), cx1 = clamp0(lx1, w.ww - 1), cy0 = clamp0(ly0, w.wh - 1), cy1 = clamp0(ly1, w.wh - 1);
-        const int r0 = w.loff + cy0 * w.ww, r1 = w.loff + cy1 * w.ww;
-        const uint4* a00 = winh + (r0 + cx0) * 2; const uint4* a01 = winh + (r0 + cx1) * 2;
-        const uint4* a10 = winh + (r1 + cx0) * 2; const uint4* a11 = winh + (r1 + cx1) * 2;
-        s.c[0][0] = a00[0]; s.c[0][1] = a00[1]; s.c[1][0] = a01[0]; s.c[1][1] = a01[1];
-        s.c[2][0] = a10[0]; s.c[2][1] = a10[1]; s.c[3][0] = a11[0]; s.c[3][1] = a11[1];
-    } else {                                                    // rare: straight from the value map
-        const int gx0 = clamp0(x0, Wl - 1), gx1 = clamp0(x1, Wl - 1), gy0 = clamp0(y0, Hl - 1), gy1 = clamp0(y1, Hl - 1);
-        const bf16_t* b = vhead + (int64_t)startl * p.vs_s;
-        const uint4* a00 = reinterpret_cast<const uint4*>(b + (int64_t)(gy0 * Wl + gx0) * p.vs_s);
-        const uint4* a01 = reinterpret_cast<const uint4*>(b + (int64_t)(gy0 * Wl + gx1) * p.vs_s);
-        const uint4* a10 = reinterpret_cast<const uint4*>(b + (int64_t)(gy1 * Wl + gx0) * p.vs_s);
-        const uint4* a11 = reinterpret_cast<const uint4*>(b + (int64_t)(gy1 * Wl + gx1) * p.vs_s);
-        s.c[0][0] = a00[0]; s.c[0][1] = a00[1]; s.c[1][0] = a01[0]; s.c[1][1] = a01[1];
-        s.c[2][0] = a10[0]; s.c[2][1] = a10[1]; s.c[3][0] = a11[0]; s.c[3][1] = a11[1];
-    }
-}
-
-__device__ __forceinline__ void fma16(float (&acc)[16], float w, const uint4 (&c)[2]) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t u[4] = {c[h].x, c[h].y, c[h].z, c[h].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc[h * 8 + 2 * k] = fmaf(w, __uint_as_float(u[k] << 16), acc[h * 8 + 2 * k]);
-            acc[h * 8 + 2 * k + 1] = fmaf(w, __uint_as_float(u[k] & 0xffff0000u), acc[h * 8 + 2 * k + 1]);
-        }
-    }
-}
-__device__ __forceinline__ float dot16(const float (&g)[16], const uint4 (&c)[2]) {
-    float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t u[4] = {c[h].x, c[h].y, c[h].z, c[h].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            d0 = fmaf(g[h * 8 + 2 * k], __uint_as_float(u[k] << 16), d0);
-            d1 = fmaf(g[h * 8 + 2 * k + 1], __uint_as_float(u[k] & 0xffff0000u), d1);
-        }
-    }
-    return d0 + d1;
-}
-__device__ __forceinline__ void unpack8(const uint4 v, float* o) {
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
-}
-
-template <int L, bool BWD>
-__global__ __launch_bounds__(WIN_NT, 2) void msda_win_kernel(const MsdaP p, const GTileP tp) {
-    extern __shared__ __attribute__((aligned(16))) uint4 winv[];
-    constexpr int P = 4, D = 16, LP = L * P;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m0 = blockIdx.y * tp.HPW, n = blockIdx.z;
-    WinGeo wg[L];
-    const int tot = win_layout<L>(p, tp, tx, ty, wg);
-    win_fill<L>(p, wg, tot, tp.HPW, n, m0, winv, tid, nt);
-    __syncthreads();
-
-    const bf16_t* OA = reinterpret_cast<const bf16_t*>(p.q1);
-    const int hshift = tp.HPW == 1 ? 0 : (tp.HPW == 2 ? 1 : (tp.HPW == 4 ? 2 : 3)), hmask = tp.HPW - 1;
-#pragma unroll 1
-    for (int lq = 0; lq < L; ++lq) {
-        int W = p.W[0], H = p.H[0], st = p.start[0];
-#pragma unroll
-        for (int k = 1; k < L; ++k)
-            if (lq == k) { W = p.W[k]; H = p.H[k]; st = p.start[k]; }
-        const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
-        const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
-        const int qw = qx1 - qx0, nit = qw * (qy1 - qy0) * tp.HPW;
-        const float inv_qw = 1.f / (float)max(qw, 1);
-#pragma unroll 1
-        for (int it = tid; it < nit; it += nt) {
-            const int qi = it >> hshift, h = it & hmask, m = m0 + h;
-            const int iy = idiv_small(qi, qw, inv_qw), q = st + (qy0 + iy) * W + qx0 + (qi - iy * qw);
-            const int64_t row = (int64_t)n * p.Lq + q;
-            const bf16_t* orow = OA + row * p.ldq;
-            const uint4* winh = winv + (size_t)h * tot * 2;
-            const bf16_t* vhead = reinterpret_cast<const bf16_t*>(p.value) + (int64_t)n * p.vs_n + (int64_t)m * p.vs_m;
-            // softmax over the L*P logits of (query, head)
-            float a[16];
-            {
-                const uint4* lp = reinterpret_cast<const uint4*>(orow + p.logit_col + m * LP);
-                unpack8(lp[0], a);
-                if constexpr (LP > 8) unpack8(lp[1], a + 8);
-                float mx = a[0];
-#pragma unroll
-                for (int i = 1; i < LP; ++i) mx = fmaxf(mx, a[i]);
-                float sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < LP; ++i) { a[i] = __expf(a[i] - mx); sum += a[i]; }
-                const float inv = 1.f / sum;
-#pragma unroll
-                for (int i = 0; i < LP; ++i) a[i] *= inv;
-            }
-            float g[16], acc[16], da[BWD ? 16 : 1];
-            if constexpr (BWD) {
-                const uint4* gp = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.grad_out) + row * ((int64_t)p.M * D) + m * D);
-                unpack8(gp[0], g); unpack8(gp[1], g + 8);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            }
-            const float* rp = p.ref + (int64_t)n * p.ref_bs + (int64_t)q * L * 2;
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                float xy[8];
-                unpack8(*reinterpret_cast<const uint4*>(orow + (m * L + l) * 8), xy);
-                const float2 rf = *reinterpret_cast<const float2*>(rp + l * 2);
-                const float rx = rf.x * (float)p.W[l] - 0.5f, ry = rf.y * (float)p.H[l] - 0.5f;
-                float dxy[8];
-#pragma unroll 1                 // rolled on purpose: unrolled, the scheduler hoists the LDS reads of all 16 samples to the front and spills
-                for (int i = 0; i < P; ++i) {
-                    Sample s;
-                    const float ox = i == 0 ? xy[0] : i == 1 ? xy[2] : i == 2 ? xy[4] : xy[6];
-                    const float oy = i == 0 ? xy[1] : i == 1 ? xy[3] : i == 2 ? xy[5] : xy[7];
-                    sample_corners(p, wg[l], p.W[l], p.H[l], p.start[l], winh, vhead, ox + rx, oy + ry, s);
-                    const float aw = i == 0 ? a[l * P] : i == 1 ? a[l * P + 1] : i == 2 ? a[l * P + 2] : a[l * P + 3];
-                    if constexpr (!BWD) {
-                        const float wy0 = (1.f - s.fy) * aw, wy1 = s.fy * aw;
-                        fma16(acc, wy0 * (1.f - s.fx) * s.v00, s.c[0]);
-                        fma16(acc, wy0 * s.fx * s.v01, s.c[1]);
-                        fma16(acc, wy1 * (1.f - s.fx) * s.v10, s.c[2]);
-                        fma16(acc, wy1 * s.fx * s.v11, s.c[3]);
-                    } else {
-                        const float d00 = dot16(g, s.c[0]) * s.v00, d01 = dot16(g, s.c[1]) * s.v01;
-                        const float d10 = dot16(g, s.c[2]) * s.v10, d11 = dot16(g, s.c[3]) * s.v11;
-                        const float T0 = fmaf(s.fy, d10 - d00, d00), T1 = fmaf(s.fy, d11 - d01, d01);      // x0 / x1 columns
-                        const float dai = fmaf(s.fx, T1 - T0, T0), dxi = aw * (T1 - T0), dyi = aw * fmaf(s.fx, (d11 - d01) - (d10 - d00), d10 - d00);
-#pragma unroll
-                        for (int k = 0; k < P; ++k)
-                            if (i == k) { da[l * P + k] = dai; dxy[2 * k] = dxi; dxy[2 * k + 1] = dyi; }
-                    }
-                }
-                if constexpr (BWD) {                      // d/d(offset) = (dpx, dpy): the W, H factors cancel
-                    bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldg + (m * L + l) * 8;
-                    *reinterpret_cast<uint4*>(gp) = make_uint4(pack_bf2(dxy[0], dxy[1]), pack_bf2(dxy[2], dxy[3]), pack_bf2(dxy[4], dxy[5]), pack_bf2(dxy[6], dxy[7]));
-                }
-            }
-            if constexpr (BWD) {                          // softmax backward
-                float dot = 0.f;
-#pragma unroll
-                for (int i = 0; i < LP; ++i) dot = fmaf(a[i], da[i], dot);
-#pragma unroll
-                for (int i = 0; i < LP; ++i) da[i] = a[i] * (da[i] - dot);
-                bf16_t* gp = reinterpret_cast<bf16_t*>(p.g1) + row * p.ldg + p.logit_col + m * LP;
-#pragma unroll
-                for (int i = 0; i < LP; i += 8)
-                    *reinterpret_cast<uint4*>(gp + i) = make_uint4(pack_bf2(da[i], da[i + 1]), pack_bf2(da[i + 2], da[i + 3]), pack_bf2(da[i + 4], da[i + 5]), pack_bf2(da[i + 6], da[i + 7]));
-            } else {
-                bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + row * ((int64_t)p.M * D) + m * D;
-                reinterpret_cast<uint4*>(op)[0] = make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
-                reinterpret_cast<uint4*>(op)[1] = make_uint4(pack_bf2(acc[8], acc[9]), pack_bf2(acc[10], acc[11]), pack_bf2(acc[12], acc[13]), pack_bf2(acc[14], acc[15]));
-            }
-        }
-    }
-}
-
-// ====================================================================================================================
-// d(value) for GRID queries on the MATRIX cores: the scatter as a sparse-as-dense product (bf16 storage, D = 16, P = 4).
-// Same workgroup = (spatial tile, head, image) with int32 fixed-point LDS windows as msda_bwd_dv_tiled_kernel above, but
-//   * ONE LANE OWNS ONE QUERY: its softmax, its 16 sample points and their corner weights are plain per-lane arithmetic on
-//     registers it loaded itself (10 x 16-byte loads) -- no DPP softmax, no per-point lanes, no broadcast chain; the sample
-//     geometry costs ~40 instructions per point for 64 queries at once instead of ~150 per 4 queries;
-//   * a wave works on an 8 x 8 block of queries = four 4 x 4 SUB-BLOCKS of 16 queries.  For one (level, point) the 16 samples
-//     of a sub-block fall into a few adjacent pixels, so the sub-block's contribution is a small dense product
-//         dV[8 x 8 pixel tile, 16 channels] = Wt[64 pixels, 16 queries] x G[16 queries, 16 channels]
-//     with Wt = bilinear corner weight x attention weight (4 nonzeros per column, written as fp16 by the owning lanes into a
-//     2 KB LDS tile, origin = the sub-block's first sample - margin) and G = the queries' grad_out rows (bf16 x 2^k: exact in
-//     fp16).  It runs as up to four v_mfma_f32_16x16x16_f16 (only the 2-row pixel strips some sample touches), and the 16 x 16
-//     fp32 result tiles are added into the int32 window: one v_cvt + one ds_add_u32 per (pixel, channel) of the strip instead
-//     of 2.5 half-rate VALU + one ds_add per (corner, channel) of every sample;
-//   * samples that do not fit their sub-block's tile (coarse-level queries sampling a fine level: 2 .. 8 px apart; learned
-//     offsets that scatter) or that leave the window take a per-lane path: the lane adds its 16 channels itself (LDS atomics
-//     inside the window, global atomics for in-image pixels outside it), so the result never depends on tile or halo.
-constexpr int MF_NW = 8, MF_NT = MF_NW * 64;
-constexpr int MF_TPX = 64;                                   // W tile of a sub-block: 8 rows x 8 pixels
-constexpr int MF_WT_BYTES = MF_TPX * 16 * 2;                 // [pixel][16 queries] fp16
-constexpr int MF_PAD = 8;                                    // pad pixels in front of / behind the windows (a strip may start 7 px left of a row)
-constexpr int MF_HDR = 80;                                   // ints in front of the pad (uniform tables, see the kernel)
-
-typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-typedef short mf_v4s_t __attribute__((ext_vector_type(4)));
-typedef uint32_t mf_u32x16_t __attribute__((ext_vector_type(16)));
-typedef float mf_f32x16_t __attribute__((ext_vector_type(16)));
-typedef float mf_f32x8_t __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) mf_v4s_t mf_lds_v4s_t;
-
-__device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
-__device__ __forceinline__ float qs_lo(uint32_t v, int f16) { return f16 ? h_lo(v) : bf_lo(v); }      // offsets | logits: bf16 or fp16 storage
-__device__ __forceinline__ float qs_hi(uint32_t v, int f16) { return f16 ? h_hi(v) : bf_hi(v); }
-
-template <typename TQ, int L>
-__global__ __launch_bounds__(MF_NT) void msda_bwd_dv_mfma_kernel(const MsdaP p, const TileP tp) {
-    static_assert(sizeof(TQ) == 2, "bf16 storage only");
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    constexpr int P = 4, D = 16, LP = L * P;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m = blockIdx.y, n = blockIdx.z;
-    // header (ints): [0] next block, [1] number of blocks, [4 .. 4 + MF_NW) reduction scratch,
-    // [16 + 8 l ..) level l: W, H, start, window x0, y0, width, height, first pixel; [48 + 8 l ..) its query rectangle: x0, y0, w, h,
-    // 8-blocks per row, first block.  (Uniform values read back through LDS + v_readfirstlane where they are used: kept live in
-    // SGPRs across the block loop, the ~60 of them push the kernel into scratch memory.)
-    int* hdr = smem;
-    int* win = smem + MF_HDR;                                // pixel x of the allocation = win[16 x .. 16 x + 16)
-    auto U = [&](int i) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(hdr[i]); };
-    int win_px;
-    {
-        int lo = MF_PAD, cb = 0;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int W = p.W[l], H = p.H[l];
-            const int ax = max((tx * W) / tp.TX - tp.HALO, 0), bx = min(cdiv_i((tx + 1) * W, tp.TX) + tp.HALO, W);
-            const int ay = max((ty * H) / tp.TY - tp.HALO, 0), by = min(cdiv_i((ty + 1) * H, tp.TY) + tp.HALO, H);
-            const int qx0 = max(cdiv_i(2 * W * tx - tp.TX, 2 * tp.TX), 0), qx1 = min(max(cdiv_i(2 * W * (tx + 1) - tp.TX, 2 * tp.TX), 0), W);
-            const int qy0 = max(cdiv_i(2 * H * ty - tp.TY, 2 * tp.TY), 0), qy1 = min(max(cdiv_i(2 * H * (ty + 1) - tp.TY, 2 * tp.TY), 0), H);
-            const int qw = qx1 - qx0, qh = qy1 - qy0, nbx = max((qw + 7) >> 3, 1);
-            if (tid == 0) {
-                int* t = hdr + 16 + 8 * l;
-                t[0] = W; t[1] = H; t[2] = p.start[l]; t[3] = ax; t[4] = ay; t[5] = bx - ax; t[6] = by - ay; t[7] = lo;
-                int* r = hdr + 48 + 8 * l;
-                r[0] = qx0; r[1] = qy0; r[2] = qw; r[3] = qh; r[4] = nbx; r[5] = cb;
-            }
-            lo += (bx - ax) * (by - ay);
-            cb += (qw > 0 && qh > 0) ? nbx * ((qh + 7) >> 3) : 0;
-        }
-        if (tid == 0) { hdr[0] = 0; hdr[1] = cb; hdr[2] = lo; }
-        win_px = lo + MF_PAD;
-    }
-    char* const wt = reinterpret_cast<char*>(win + win_px * D) + wid * MF_WT_BYTES;     // this wave's W tile (all zero between uses)
-    {
-        int4* w4 = reinterpret_cast<int4*>(win);
-        const int n4 = win_px * (D / 4) + MF_NW * (MF_WT_BYTES / 16);
-        for (int i = tid; i < n4; i += MF_NT) w4[i] = make_int4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    const int row0 = n * p.Lq;
-    const uint32_t g_row = (uint32_t)(p.M * D) * 2u, q_row = (uint32_t)p.ldq * 2u;
-
-    // pass 1: max |grad_out| over this tile's queries -> power-of-two scale (lanes = [query slot][channel], coalesced 32-byte pieces)
-    float gm = (tp.skip & 1) ? 4.f : 0.f;
-    {
-        const int c = tid & 15, slot = tid >> 4;
-        constexpr int NSLOT = MF_NT / 16;
-        const uint32_t g_lane = (uint32_t)(m * D + c) * 2u;
-#pragma unroll 1
-        for (int lq = 0; lq < ((tp.skip & 1) ? 0 : L); ++lq) {
-            const int W = U(16 + 8 * lq), qw = U(48 + 8 * lq + 2), nq = qw * U(48 + 8 * lq + 3);
-            const float inv_qw = 1.f / (float)max(qw, 1);
-            const int qbase = row0 + U(16 + 8 * lq + 2) + U(48 + 8 * lq + 1) * W + U(48 + 8 * lq);
-            auto g_of = [&](int i) __attribute__((always_inline)) {
-                const int iy = idiv_small(i, qw, inv_qw);
-                return fabsf(bf2f(ldg32<TQ>(p.grad_out, (uint32_t)(qbase + iy * W + (i - iy * qw)) * g_row + g_lane)));
-            };
-            int i = slot;
-            for (; i + 3 * NSLOT < nq; i += 4 * NSLOT) {
-                const float g0 = g_of(i), g1 = g_of(i + NSLOT), g2 = g_of(i + 2 * NSLOT), g3 = g_of(i + 3 * NSLOT);
-                gm = fmaxf(fmaxf(gm, fmaxf(g0, g1)), fmaxf(g2, g3));
-            }
-            for (; i < nq; i += NSLOT) gm = fmaxf(gm, g_of(i));
-        }
-    }
-    gm = wave_max(gm);
-    if (lane == 0) reinterpret_cast<float*>(hdr)[4 + wid] = gm;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < MF_NW; ++w) gm = fmaxf(gm, reinterpret_cast<float*>(hdr)[4 + w]);
-    if (!(gm > 0.f) || !(gm < 3.0e38f)) return;               // nothing to scatter (uniform across the workgroup)
-    int ex;
-    (void)frexpf(gm, &ex);                                    // gm in [2^(ex-1), 2^ex)
-    // window fixed point: w g 2^(18-ex) per contribution, as in the tiled kernel.  Split: G' = g 2^(15-ex) (|G'| < 2^15: fp16), W' = 8 w
-    const float gscale = ldexpf(1.f, 15 - ex), inv = ldexpf(1.f, ex - 18);
-    const int nblk = (tp.skip & 2) ? 0 : U(1);
-
-    const int sbl = lane >> 4, j16 = lane & 15;               // sub-block of the lane, its query inside it
-    const int jx = (j16 & 3) + ((sbl & 1) << 2), jy = (j16 >> 2) + ((sbl >> 1) << 2);      // position in the 8 x 8 block
-    float* gvb = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m;
-    bf16_t* gvb16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m;       // (gv_bf16)
-    // read addresses of the MFMA operands in the wave's tile: A = Wt rows (pixel = lane & 15 of the strip, 4 queries of k-group lane >> 4)
-    const int a_rd = (lane & 15) * 32 + (lane >> 4) * 8;
-    // transposing read of the staged grad_out rows [query][channel]: source lane r of 16-lane block b points at row 4 b + (r >> 2), piece r & 3
-    const int g_rd = ((lane >> 4) * 4 + (j16 >> 2)) * 32 + (j16 & 3) * 8;
-
-#pragma unroll 1
-    for (;;) {
-        int blk = 0;
-        if (lane == 0) blk = atomicAdd(&hdr[0], 1);
-        blk = __builtin_amdgcn_readfirstlane(blk);
-        if (blk >= nblk) break;
-        int lq = 0;                                            // the LAST non-empty level whose first block is <= blk
-#pragma unroll
-        for (int l = 1; l < L; ++l) if (blk >= U(48 + 8 * l + 5) && U(48 + 8 * l + 2) > 0 && U(48 + 8 * l + 3) > 0) lq = l;
-        const int* rq = hdr + 48 + 8 * lq;
-        const int rx0 = __builtin_amdgcn_readfirstlane(rq[0]), ry0 = __builtin_amdgcn_readfirstlane(rq[1]), rw = __builtin_amdgcn_readfirstlane(rq[2]),
-                  rh = __builtin_amdgcn_readfirstlane(rq[3]), nbx = __builtin_amdgcn_readfirstlane(rq[4]), bl = blk - __builtin_amdgcn_readfirstlane(rq[5]);
-        const int Wq = U(16 + 8 * lq), startq = U(16 + 8 * lq + 2);
-        const int by = bl / nbx, bx = bl - by * nbx;
-        const int qxl = bx * 8 + jx, qyl = by * 8 + jy;       // inside the tile's rectangle of level lq
-        const bool active = qxl < rw && qyl < rh && (!(tp.skip & 64) || sbl == ((tp.skip >> 8) & 3));     // (skip bit 64: debugging aid, one sub-block only)
-        const int q = startq + (ry0 + (active ? qyl : 0)) * Wq + rx0 + (active ? qxl : 0);
-        const uint32_t row = (uint32_t)(row0 + q);
-
-        // ---- this lane's operands: 16 bytes of offsets and 8 of logits per level, 32 of grad_out, the reference points ----
-        // (LLVM vectors, not C arrays: the level loop below is ROLLED -- unrolled, the kernel is 50 KB of code -- and indexes them with
-        // the wave-uniform level number, which the backend turns into v_movrels; a C array would go to scratch memory)
-        mf_u32x16_t ofv;
-        mf_f32x16_t a;
-        mf_f32x8_t rfv;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const uint4 o = ldg32<uint4>(p.q1, row * q_row + (uint32_t)((m * LP + l * P) * 2) * 2u);
-            const uint2 g = ldg32<uint2>(p.q1, row * q_row + (uint32_t)(p.logit_col + m * LP + l * P) * 2u);
-            const float2 r = ldg32<float2>(p.ref, (uint32_t)(n * p.ref_bs + (q * L + l) * 2) * 4u);
-            ofv[4 * l] = o.x; ofv[4 * l + 1] = o.y; ofv[4 * l + 2] = o.z; ofv[4 * l + 3] = o.w;
-            a[4 * l] = qs_lo(g.x, p.q_f16); a[4 * l + 1] = qs_hi(g.x, p.q_f16); a[4 * l + 2] = qs_lo(g.y, p.q_f16); a[4 * l + 3] = qs_hi(g.y, p.q_f16);
-            rfv[2 * l] = r.x; rfv[2 * l + 1] = r.y;
-        }
-        const uint4 gv0 = ldg32<uint4>(p.grad_out, row * g_row + (uint32_t)(m * D) * 2u);
-        const uint4 gv1 = ldg32<uint4>(p.grad_out, row * g_row + (uint32_t)(m * D + 8) * 2u);
-
-        // grad_out row -> fp16 x 2^(15-ex) (exact: 8 significant bits), staged [query][channel] in the (all-zero) W tile, read back
-        // TRANSPOSED as the four sub-blocks' MFMA B operands (B[k = query][n = channel]: 4 consecutive queries of one channel per lane)
-        const float gs_ = active ? gscale : 0.f;
-        f16x2_t gh[8];
-        {
-            const uint32_t gw[8] = {gv0.x, gv0.y, gv0.z, gv0.w, gv1.x, gv1.y, gv1.z, gv1.w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) gh[i] = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz(bf_lo(gw[i]) * gs_, bf_hi(gw[i]) * gs_));
-            uint4* st = reinterpret_cast<uint4*>(wt + lane * 32);
-            st[0] = make_uint4(__builtin_bit_cast(uint32_t, gh[0]), __builtin_bit_cast(uint32_t, gh[1]), __builtin_bit_cast(uint32_t, gh[2]), __builtin_bit_cast(uint32_t, gh[3]));
-            st[1] = make_uint4(__builtin_bit_cast(uint32_t, gh[4]), __builtin_bit_cast(uint32_t, gh[5]), __builtin_bit_cast(uint32_t, gh[6]), __builtin_bit_cast(uint32_t, gh[7]));
-        }
-        asm volatile("" ::: "memory");
-        // (scalars, not an array: selecting Bf[s] by the run-time sub-block index would pin an array in scratch memory)
-        const uint2 B0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 0 * 512 + g_rd)));
-        const uint2 B1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 1 * 512 + g_rd)));
-        const uint2 B2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 2 * 512 + g_rd)));
-        const uint2 B3 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mf_lds_v4s_t*)(wt + 3 * 512 + g_rd)));
-        asm volatile("" ::: "memory");
-        {
-            uint4* st = reinterpret_cast<uint4*>(wt + lane * 32);
-            st[0] = make_uint4(0, 0, 0, 0);
-            st[1] = make_uint4(0, 0, 0, 0);
-        }
-
-        // softmax over the (query, head)'s L*P logits, x 8 (the W' scale), 0 for lanes without a query
-        {
-            float mx = a[0];
-#pragma unroll
-            for (int i = 1; i < LP; ++i) mx = fmaxf(mx, a[i]);
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < LP; ++i) { a[i] = __expf(a[i] - mx); s += a[i]; }
-            const float r = active ? 8.f * __builtin_amdgcn_rcpf(s) : 0.f;
-#pragma unroll
-            for (int i = 0; i < LP; ++i) a[i] *= r;
-        }
-
-#pragma unroll 1
-        for (int l = 0; l < L; ++l) {
-            const int Wl = U(16 + 8 * l), Hl = U(16 + 8 * l + 1), startl = U(16 + 8 * l + 2);
-            const float WlF = (float)Wl, HlF = (float)Hl;
-            const int lwx0 = U(16 + 8 * l + 3), lwy0 = U(16 + 8 * l + 4), lww = U(16 + 8 * l + 5), lwh = U(16 + 8 * l + 6), lo = U(16 + 8 * l + 7);
-            // queries of a coarser level sit 2 .. 8 px apart at this one: a 4 x 4 sub-block then spans >= 7 px, no margin to give
-            const int margin = (l >= lq) ? 2 : 0;
-            // per-lane part of a result strip's window address: strip rows 2 t + (lane >> 5), pixel ((lane >> 4) & 1) * 4 + r, channel lane & 15
-            const int lc = (((lane >> 5) * lww + ((lane >> 4) & 1) * 4) << 6) + (lane & 15) * 4;
-            const float bxf = fmaf(rfv[2 * l], WlF, -0.5f), byf = fmaf(rfv[2 * l + 1], HlF, -0.5f);
-#pragma unroll 1
-            for (int pt = 0; pt < P; ++pt) {
-                const float aj = a[4 * l + pt];
-                const uint32_t ofw = ofv[4 * l + pt];
-                const float px = bxf + qs_lo(ofw, p.q_f16), py = byf + qs_hi(ofw, p.q_f16);
-                const float x0f = floorf(px), y0f = floorf(py), fx = px - x0f, fy = py - y0f;
-                const int x0 = (int)x0f, y0 = (int)y0f;         // v_cvt saturates; every use below is an unsigned range test
-                const int lx0 = x0 - lwx0, ly0 = y0 - lwy0;
-                const bool wxi0 = (unsigned)lx0 < (unsigned)lww, wxi1 = (unsigned)(lx0 + 1) < (unsigned)lww;
-                const bool wyi0 = (unsigned)ly0 < (unsigned)lwh, wyi1 = (unsigned)(ly0 + 1) < (unsigned)lwh;
-                const bool ixi0 = (unsigned)x0 < (unsigned)Wl, ixi1 = (unsigned)(x0 + 1) < (unsigned)Wl;
-                const bool iyi0 = (unsigned)y0 < (unsigned)Hl, iyi1 = (unsigned)(y0 + 1) < (unsigned)Hl;
-                // a corner inside the image but outside the window (the windows are clipped to the image: in-window implies in-image)
-                const bool far = (((ixi0 && !wxi0) || (ixi1 && !wxi1)) && (iyi0 || iyi1)) || (((iyi0 && !wyi0) || (iyi1 && !wyi1)) && (ixi0 || ixi1));
-                const bool anyw = (wxi0 || wxi1) && (wyi0 || wyi1);
-                const float wx_0 = wxi0 ? 1.f - fx : 0.f, wx_1 = wxi1 ? fx : 0.f;
-                const float wy_0 = wyi0 ? (1.f - fy) * aj : 0.f, wy_1 = wyi1 ? fy * aj : 0.f;
-                // tile coordinates relative to the sub-block's first sample (its lane 0, broadcast within the 16-lane DPP row)
-                // (the broadcasts are made opaque: folded into the subtraction as v_subrev_u32_dpp the difference came out NEGATED on
-                // gfx950 / ROCm 7.2 -- found with the W-tile dump of profiles/probes/dv_mfma_dbg2.py)
-                int fx0 = row_bcast<0>(lx0), fy0 = row_bcast<0>(ly0);
-                asm volatile("" : "+v"(fx0), "+v"(fy0));
-                const int tcx = lx0 - fx0 + margin, tcy = ly0 - fy0 + margin;
-                const bool fit = active && !far && (unsigned)tcx <= 6u && (unsigned)tcy <= 6u && !(tp.skip & 8);      // (skip bit 8: debugging aid, every sample on the per-lane path)
-                const bool slow = active && !fit && (far || anyw);
-                const int wofs = ((tcy * 8 + tcx) * 16 + j16) * 2;
-                const _Float16 h00 = (_Float16)(wy_0 * wx_0), h01 = (_Float16)(wy_0 * wx_1), h10 = (_Float16)(wy_1 * wx_0), h11 = (_Float16)(wy_1 * wx_1);
-                // 2-row strips (of 16 tile pixels) some fitting sample touches, per sub-block: bits 16 s .. 16 s + 15 of the ballots
-                const unsigned long long bt0 = __ballot(fit && tcy <= 1), bt1 = __ballot(fit && tcy >= 1 && tcy <= 3),
-                                         bt2 = __ballot(fit && tcy >= 3 && tcy <= 5), bt3 = __ballot(fit && tcy >= 5);
-                if (bt0 | bt1 | bt2 | bt3) {
-                    // window pixel of the tile origin, per sub-block (uniform): origin = first sample - margin
-                    const int org = lo + (fy0 - margin) * lww + fx0 - margin;
-                    const int orow = fy0 - margin;
-#pragma unroll 1
-                    for (int s = 0; s < 4; ++s) {
-                        const unsigned m0 = (unsigned)(bt0 >> (16 * s)) & 0xffffu, m1 = (unsigned)(bt1 >> (16 * s)) & 0xffffu,
-                                       m2 = (unsigned)(bt2 >> (16 * s)) & 0xffffu, m3 = (unsigned)(bt3 >> (16 * s)) & 0xffffu;
-                        if (!(m0 | m1 | m2 | m3)) continue;
-                        const bool mine = fit && sbl == s;
-                        if (tp.skip & 32) {          // (debug: the two lanes of a dword write in separate instructions)
-                            if (mine && !(lane & 1)) { _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs); wp[0] = h00; wp[16] = h01; wp[128] = h10; wp[144] = h11; }
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (mine && (lane & 1)) { _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs); wp[0] = h00; wp[16] = h01; wp[128] = h10; wp[144] = h11; }
-                        } else
-                        if (mine) {
-                            _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs);
-                            wp[0] = h00; wp[16] = h01; wp[128] = h10; wp[144] = h11;
-                        }
-                        if (tp.skip & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if ((tp.skip & 128) && blockIdx.x == 0 && m == 0 && n == 0) {       // (debug: dump the W tile of (l, pt, s) = (0, 0, skip >> 8))
-                            if (l == 0 && pt == 0 && s == ((tp.skip >> 8) & 3) && blk == 0) {
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                for (int i = lane; i < 1024; i += 64) p.grad_value[i] = (float)reinterpret_cast<const _Float16*>(wt)[i];
-                                p.grad_value[1024 + lane] = (float)(fit ? 1 : 0) + 2.f * (float)tcx + 32.f * (float)tcy + 1024.f * (mine ? 1.f : 0.f);
-                            }
-                        }
-                        asm volatile("" ::: "memory");
-                        const uint32_t bsx = s == 0 ? B0.x : s == 1 ? B1.x : s == 2 ? B2.x : B3.x, bsy = s == 0 ? B0.y : s == 1 ? B1.y : s == 2 ? B2.y : B3.y;
-                        const f16x4_t Bs = __builtin_bit_cast(f16x4_t, make_uint2(bsx, bsy));
-                        const int sorg = __builtin_amdgcn_readlane(org, s * 16), srow = __builtin_amdgcn_readlane(orow, s * 16);
-                        const unsigned ms[4] = {m0, m1, m2, m3};
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if (!ms[t]) continue;
-                            const f16x4_t A = *reinterpret_cast<const f16x4_t*>(wt + t * 512 + a_rd);
-                            const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x16f16(A, Bs, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                            const int rr = srow + 2 * t + (lane >> 5);
-                            if ((unsigned)rr < (unsigned)lwh) {
-                                int* ap = reinterpret_cast<int*>(reinterpret_cast<char*>(win) + (((sorg + 2 * t * lww) << 6) + lc));
-                                // (compiler-visible conversions: the hazard recogniser does not look inside inline assembly, and a v_cvt_rpi
-                                // placed right behind the MFMA would read its result registers before the matrix pipe has written them)
-                                atomicAdd(ap, __float2int_rn(d[0]));
-                                atomicAdd(ap + 16, __float2int_rn(d[1]));
-                                atomicAdd(ap + 32, __float2int_rn(d[2]));
-                                atomicAdd(ap + 48, __float2int_rn(d[3]));
-                            }
-                        }
-                        asm volatile("" ::: "memory");
-                        if (mine) {
-                            _Float16* wp = reinterpret_cast<_Float16*>(wt + wofs);
-                            wp[0] = (_Float16)0.f; wp[16] = (_Float16)0.f; wp[128] = (_Float16)0.f; wp[144] = (_Float16)0.f;
-                        }
-                    }
-                }
-                if (__ballot(slow)) {
-                    if (slow) {
-                        // the lane adds its sample itself: 16 channels x the corners that lie in the image
-                        const int wb = lo + ly0 * lww + lx0, gp0 = startl + y0 * Wl + x0;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const bool inw = ((k & 1) ? wxi1 : wxi0) && ((k >> 1) ? wyi1 : wyi0);
-                            const bool inimg = ((k & 1) ? ixi1 : ixi0) && ((k >> 1) ? iyi1 : iyi0);
-                            const float wk = ((k >> 1) ? fy : 1.f - fy) * ((k & 1) ? fx : 1.f - fx) * aj;
-                            if (inw) {
-                                int* ap = win + (wb + (k & 1) + (k >> 1) * lww) * D;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) {
-                                    atomicAdd(ap + 2 * i, cvt_rpi(wk * (float)gh[i][0]));
-                                    atomicAdd(ap + 2 * i + 1, cvt_rpi(wk * (float)gh[i][1]));
-                                }
-                            } else if (inimg) {
-                                const int64_t pe = (int64_t)(gp0 + (k & 1) + (k >> 1) * Wl) * p.gs_s;
-                                const float wi = wk * inv;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) {
-                                    if (p.gv_bf16) gv16_add2(gvb16 + pe + 2 * i, wi * (float)gh[i][0], wi * (float)gh[i][1]);
-                                    else { atomicAdd(gvb + pe + 2 * i, wi * (float)gh[i][0]); atomicAdd(gvb + pe + 2 * i + 1, wi * (float)gh[i][1]); }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (tp.skip & 4) return;
-    // flush (as in the tiled kernel): one coalesced pass per level, packed bf16x2 or fp32 memory-side atomics for the nonzero words
-#pragma unroll 1
-    for (int l = 0; l < L; ++l) {
-        const int W = U(16 + 8 * l), start = U(16 + 8 * l + 2), ax = U(16 + 8 * l + 3), ay = U(16 + 8 * l + 4), wpf = U(16 + 8 * l + 5),
-                  lofff = U(16 + 8 * l + 7);
-        const int cnt = wpf * U(16 + 8 * l + 6) * D;
-        const float inv_wp = 1.f / (float)wpf;
-        if (p.gv_bf16) {
-            bf16_t* gl16 = reinterpret_cast<bf16_t*>(p.grad_value) + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + (int64_t)start * p.gs_s;
-            const int2* w2 = reinterpret_cast<const int2*>(win + lofff * D);
-            for (int i = tid; i < (cnt >> 1); i += MF_NT) {
-                const int2 v = w2[i];
-                if (v.x | v.y) {
-                    const int cc = (i & 7) * 2, pix = i >> 3;
-                    const int py = idiv_small(pix, wpf, inv_wp);
-                    const int xx = ax + pix - py * wpf, yy = ay + py;
-                    gv16_add2(gl16 + (int64_t)(yy * W + xx) * p.gs_s + cc, (float)v.x * inv, (float)v.y * inv);
-                }
-            }
-        } else {
-            float* gl = p.grad_value + (int64_t)n * p.gs_n + (int64_t)m * p.gs_m + (int64_t)start * p.gs_s;
-            for (int i = tid; i < cnt; i += MF_NT) {
-                const int v = win[lofff * D + i];
-                if (v != 0) {
-                    const int cc = i & 15, pix = i >> 4;
-                    const int py = idiv_small(pix, wpf, inv_wp);
-                    const int xx = ax + pix - py * wpf, yy = ay + py;
-                    atomicAdd(gl + (int64_t)(yy * W + xx) * p.gs_s + cc, (float)v * inv);
-                }
-            }
-        }
-    }
-}
+#ifdef POET_PROBE_KERNELS
+#include "../../profiles/probes/kernels/msda_dv_mfma.inc"
+#endif
 
 // host: pick the tile grid / halo so the windows fit the LDS budget; returns window PIXELS of the largest tile (0 = no plan).
 // px_budget: pixels that fit; extra_px: pixels reserved behind the windows.
@@ -1824,6 +1089,7 @@ static size_t plan_tiles_px(const MsdaP& p, int L, TileP& tp, size_t px_budget, 
 }
 static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
     if (p.D != 16) return 0;
+#ifdef POET_PROBE_KERNELS                                        // (probe builds only: re-read per launch by profiles/probes/dv_tiles_bench.py)
     if (const char* e = getenv("POET_DV_TILES")) {               // experiment: "TX,TY,HALO" (rejected when it does not fit)
         int tx = 0, ty = 0, halo = 0;
         if (sscanf(e, "%d,%d,%d", &tx, &ty, &halo) == 3 && tx > 0 && ty > 0 && halo >= 0) {
@@ -1842,44 +1108,10 @@ static size_t plan_tiles(const MsdaP& p, int L, TileP& tp) {
             if (worst + 9 <= (size_t)(POET_DV_LDS_BYTES / 64)) { tp.TX = tx; tp.TY = ty; tp.HALO = halo; tp.skip = 0; return (worst + 9) * 64; }
         }
     }
+#endif
     // 150 KB of int32 windows (one 1024-thread workgroup per CU) + 1 pad pixel + 8 dummy pixels (see the kernel)
     static const int halos[3] = {5, 4, 2};
     return plan_tiles_px(p, L, tp, POET_DV_LDS_BYTES / (16 * 4), 9, halos, 3) * 16 * 4;
-}
-
-template <typename TV, typename TQ, int L, bool BWD>
-static bool launch_win(const MsdaP& p, int P, hipStream_t st) {
-    if constexpr (sizeof(TV) != 2 || sizeof(TQ) != 2) return false;
-    else {
-    if (P != 4 || p.D != 16 || L * P % 8 != 0 || !p.grid_queries || p.Lq != p.S || p.vs_s != 16 || p.q_f16) return false;
-    // OPT-IN (POET_WIN_GATHER=1).  Measured at 640x480, bs 16, M = 16: forward 267 us / backward 359 us
-    // at the best configuration against 250 / 330 us for the L1-served gathers below -- per-lane random 32-B LDS reads
-    // conflict 3-4 ways and a lane's offset / logit / output rows are 1.5 KB apart in HBM.
-    { const char* e = getenv("POET_WIN_GATHER"); if (!(e && atoi(e))) return false; }
-    int hpw = 1, nthreads = 256;
-    { const char* e = getenv("POET_WIN_HPW"); if (e && atoi(e) > 0) hpw = atoi(e); }
-    { const char* e = getenv("POET_WIN_NT"); if (e && (atoi(e) == 256 || atoi(e) == 512)) nthreads = atoi(e); }
-    if (hpw != 1 && hpw != 2 && hpw != 4 && hpw != 8) return false;
-    while (hpw > 1 && p.M % hpw) hpw >>= 1;
-    TileP tp{};
-    GTileP gp{};
-    // <= 78 KB of bf16 windows (32 B per pixel and head) per workgroup: two (three at ~52 KB) workgroups per CU.  Halo 5 px:
-    // the reference's initial offsets reach 4 px (L-inf) and the right / lower bilinear corner one more; at halo 4, 1 % of
-    // noisy samples -- half of all (wave, sample) steps -- would take the global-memory path
-    int halo_hi = 5;
-    { const char* e = getenv("POET_WIN_HALO"); if (e && atoi(e) >= 2 && atoi(e) <= 12) halo_hi = atoi(e); }
-    int halos[16], n_halos = 0;
-    for (int h = halo_hi; h >= min(halo_hi, 4); --h) halos[n_halos++] = h;
-    const size_t px = plan_tiles_px(p, L, tp, (size_t)(78 * 1024) / (32 * hpw), 0, halos, n_halos);
-    if (!px) return false;
-    gp.TX = tp.TX; gp.TY = tp.TY; gp.HALO = tp.HALO; gp.HPW = hpw;
-    const size_t lds = px * 32 * hpw;
-    auto kern = msda_win_kernel<L, BWD>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(gp.TX * gp.TY, p.M / hpw, p.N), dim3(nthreads), lds, st, p, gp);
-    return true;
-    }
 }
 
 template <typename TQ, int L>
@@ -1893,8 +1125,12 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
         ((int64_t)(p.N - 1) * p.ref_bs + (int64_t)p.Lq * L * 2) * 4 >= (1ll << 32) || (p.ref_bs & 1)) return false;
     TileP tp{};
     const size_t lds = plan_tiles(p, L, tp);
-    { const char* e = getenv("POET_NO_TILED_SCATTER"); if (e && atoi(e)) return false; }
+    static const int no_tiled = [] { const char* e = getenv("POET_NO_TILED_SCATTER"); return e && atoi(e) ? 1 : 0; }();     // (A/B aid, read once)
+    if (no_tiled) return false;
+    tp.skip = 0;
+#ifdef POET_PROBE_KERNELS                                        // timing-breakdown aid of the probe scripts (re-read per launch there)
     { const char* e = getenv("POET_DV_SKIP"); tp.skip = e ? atoi(e) : 0; }
+#endif
     if (!lds) return false;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1908,39 +1144,9 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
     }
 }
 
-// The matrix-core scatter (opt-in while it is being measured: POET_DV_MFMA=1).  Windows + pads + a 2 KB tile per wave must fit.
-template <typename TQ, int L>
-static bool launch_dv_mfma(const MsdaP& p, int P, hipStream_t st) {
-    if constexpr (sizeof(TQ) != 2) return false;
-    else {
-    { const char* e = getenv("POET_DV_MFMA"); if (!(e && atoi(e))) return false; }
-    if (P != 4 || p.D != 16) return false;
-    const int64_t rows = (int64_t)p.N * p.Lq;
-    if (rows * p.M * p.D * 2 >= (1ll << 32) || rows * p.ldq * 2 >= (1ll << 32) || (p.ldq & 7) || (p.logit_col & 3) ||
-        ((int64_t)(p.N - 1) * p.ref_bs + (int64_t)p.Lq * L * 2) * 4 >= (1ll << 32) || (p.ref_bs & 1)) return false;
-    TileP tp{};
-    static const int halos[3] = {5, 4, 2};
-    const size_t budget = (size_t)POET_DV_LDS_BYTES - MF_HDR * 4 - (size_t)MF_NW * MF_WT_BYTES;
-    size_t px = 0;
-    if (const char* e = getenv("POET_DV_TILES")) {               // experiment: "TX,TY,HALO" (ignored when it does not fit)
-        int tx = 0, ty = 0, halo = 0;
-        if (sscanf(e, "%d,%d,%d", &tx, &ty, &halo) == 3 && tx > 0 && ty > 0 && halo >= 0) {
-            const size_t w = tile_footprint(p, L, tx, ty, halo, nullptr);
-            if (w + 2 * MF_PAD <= budget / 64) { tp.TX = tx; tp.TY = ty; tp.HALO = halo; px = w + 2 * MF_PAD; }
-        }
-    }
-    if (!px) px = plan_tiles_px(p, L, tp, budget / 64, 2 * MF_PAD, halos, 3);
-    if (!px) return false;
-    { const char* e = getenv("POET_DV_SKIP"); tp.skip = e ? atoi(e) : 0; }
-    const size_t lds = MF_HDR * 4 + px * 64 + (size_t)MF_NW * MF_WT_BYTES;
-    auto kern = msda_bwd_dv_mfma_kernel<TQ, L>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(tp.TX * tp.TY, p.M, p.N), dim3(MF_NT), lds, st, p, tp);
-    return true;
-    }
-}
-
+#ifdef POET_PROBE_KERNELS
+#include "../../profiles/probes/kernels/msda_probe_launch.inc"
+#endif
 
 // ---- generic kernels: any n_levels <= MAXL, any n_points (L x P <= 64) -------------------------------------------------------
 // `--num_feature_levels`, `--enc_n_points`, `--dec_n_points` are free parameters of the reference (main.py:71,100-101); the
@@ -2153,7 +1359,9 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
     dim3 gridv(cdiv(p.total * 8, 256)), gridf(cdiv(p.total * 2, 256));
     bool dv_done = !(p.parts & 2);
     if constexpr (BWD && FUSED) {
+#ifdef POET_PROBE_KERNELS
         if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_mfma<TQ, L>(p, P, st);
+#endif
         if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
     }
     if (p.q_f16 && BWD && !dv_done) { g_f16_refused = true; return; }
@@ -2163,17 +1371,19 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
         else hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 1, FUSED>), gridv, block, 0, st, p);
     }
     if (BWD && !(p.parts & 1)) return;
+#ifdef POET_PROBE_KERNELS
     if constexpr (FUSED) {
         if (launch_win<TV, TQ, L, BWD>(p, P, st)) return;
     }
+#endif
     if constexpr (FUSED && L == 4 && sizeof(TV) == 2 && sizeof(TQ) == 2) {
         // the encoder's shape: shared-geometry gathers (POET_MSDA_NO_SHARED=1: the general kernels below)
-        const char* ns_ = getenv("POET_MSDA_NO_SHARED");
-        const bool no_shared = ns_ && atoi(ns_);
+        static const bool no_shared = [] { const char* e = getenv("POET_MSDA_NO_SHARED"); return e && atoi(e); }();       // (A/B aids, read once)
         const int64_t rows = (int64_t)p.N * p.Lq;
         if (!no_shared && P == 4 && p.M == 16 && p.D == 16 && rows < (1ll << 31) && (p.ldq % 8) == 0 && (p.logit_col % 4) == 0 &&
             (p.ref_bs % 2) == 0) {
             // POET_SH_QGROUP=1: one query x 16 heads per wave; default 4 consecutive queries x 4 heads, 4 passes
+#ifdef POET_PROBE_KERNELS
             // POET_MSDA_HYBRID=1 (forward, round 4 experiment): coarse levels staged in LDS per (image, head quarter)
             if constexpr (!BWD) {
                 const char* hy_ = getenv("POET_MSDA_HYBRID");
@@ -2194,11 +1404,15 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
                     return;
                 }
             }
-            const char* qg_ = getenv("POET_SH_QGROUP");
-            const int qg = qg_ && atoi(qg_) == 1 ? 1 : 4;          // (2 and 8 measured within 5 % of 4, 16 no better than 1)
+#endif
+            // 4 consecutive queries x 4 heads per wave, 4 passes (1, 2, 8 and 16 queries per group measured no better: DESIGN section 9)
+            int qg = 4;
+            size_t dyn = 0;
+#ifdef POET_PROBE_KERNELS
+            { const char* e = getenv("POET_SH_QGROUP"); if (e && atoi(e) == 1) qg = 1; }
+            { const char* e = getenv("POET_SH_PADLDS"); if (e) dyn = (size_t)atoi(e); }     // experiment: extra LDS per workgroup (lowers the occupancy)
+#endif
             const dim3 grid((unsigned)((rows + SH_WAVES * qg - 1) / (SH_WAVES * qg))), blk(SH_WAVES * 64);
-            const char* pad_ = getenv("POET_SH_PADLDS");          // experiment: extra LDS per workgroup (lowers the occupancy)
-            const size_t dyn = pad_ ? (size_t)atoi(pad_) : 0;
 #define POET_SH_LAUNCH(Q, H) do { if (BWD) hipLaunchKernelGGL((msda_bwd_shared_kernel<Q, H>), grid, blk, dyn, st, p); \
                                   else hipLaunchKernelGGL((msda_fwd_shared_kernel<Q, H>), grid, blk, dyn, st, p); } while (0)
             if (p.q_f16) { if (qg == 1) POET_SH_LAUNCH(1, true); else POET_SH_LAUNCH(4, true); }

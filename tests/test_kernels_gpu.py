@@ -1,6 +1,7 @@
 """Kernel-level parity: every C-ABI kernel vs the CPU oracle / an fp32 torch statement of the
 same arithmetic, on seeded inputs.  -m gpu only."""
 import contextlib
+import os
 import math
 
 import numpy as np
@@ -9,6 +10,9 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+# kernels that were built, measured and lost are not in the product library; a probe build (POET_BUILD_PROBES=1) carries them
+PROBES_BUILT = os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "poet_amd", "csrc", ".probes_on"))
 
 from oracle import poet_ref, msda_explicit  # noqa: E402  (checker only)
 
@@ -788,32 +792,36 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
     out = torch.empty(n, S, m * d, dtype=torch.bfloat16, device="cuda")
     ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
     e_out = (out.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item()
-    # the opt-in hybrid forward (coarse levels staged in LDS per (image, head quarter), fine levels through L1): the same arithmetic
-    # in the same order -- bit-identical to the default kernel
-    monkeypatch.setenv("POET_MSDA_HYBRID", "1")
-    out_h = torch.empty_like(out)
-    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_h, n, m, d, p, S, grid_queries=True)
-    monkeypatch.delenv("POET_MSDA_HYBRID")
-    assert torch.equal(out_h, out)
-    # the opt-in variants that stage bf16 value windows in LDS (one lane per (query, head)), same problem
-    monkeypatch.setenv("POET_WIN_GATHER", "1")
-    out_w, goa_w = torch.empty_like(out), torch.empty_like(dev(oa))
-    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_w, n, m, d, p, S, grid_queries=True)
-    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), torch.zeros(n, m, S, d, device="cuda"), goa_w,
-                       n, m, d, p, S, grid_queries=True, parts=1)
-    monkeypatch.delenv("POET_WIN_GATHER")
-    assert (out_w.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item() < 6e-3
-    dqw = goa_w.double().cpu()
-    assert ((dqw[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs() * (~kink)).max().item() / doa_ref[..., : 2 * mlp].abs().max().item() < 8e-3
-    assert (dqw[..., 2 * mlp:] - doa_ref[..., 2 * mlp:]).abs().max().item() / doa_ref[..., 2 * mlp:].abs().max().item() < 8e-3
+    if PROBES_BUILT:          # measured losers, compiled only into probe builds of the library (POET_BUILD_PROBES=1, profiles/probes/kernels/)
+        # the opt-in hybrid forward (coarse levels staged in LDS per (image, head quarter), fine levels through L1): the same arithmetic
+        # in the same order -- bit-identical to the default kernel
+        monkeypatch.setenv("POET_MSDA_HYBRID", "1")
+        out_h = torch.empty_like(out)
+        ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_h, n, m, d, p, S, grid_queries=True)
+        monkeypatch.delenv("POET_MSDA_HYBRID")
+        assert torch.equal(out_h, out)
+        # the opt-in variants that stage bf16 value windows in LDS (one lane per (query, head)), same problem
+        monkeypatch.setenv("POET_WIN_GATHER", "1")
+        out_w, goa_w = torch.empty_like(out), torch.empty_like(dev(oa))
+        ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_w, n, m, d, p, S, grid_queries=True)
+        ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), torch.zeros(n, m, S, d, device="cuda"), goa_w,
+                           n, m, d, p, S, grid_queries=True, parts=1)
+        monkeypatch.delenv("POET_WIN_GATHER")
+        assert (out_w.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item() < 6e-3
+        dqw = goa_w.double().cpu()
+        assert ((dqw[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs() * (~kink)).max().item() / doa_ref[..., : 2 * mlp].abs().max().item() < 8e-3
+        assert (dqw[..., 2 * mlp:] - doa_ref[..., 2 * mlp:]).abs().max().item() / doa_ref[..., 2 * mlp:].abs().max().item() < 8e-3
     # the general gather kernels (every lane of a (query, head) computes the sample geometry itself), same problem: the default
-    # at this shape are the shared-geometry kernels (one lane per level prepares the points, LDS records)
-    monkeypatch.setenv("POET_MSDA_NO_SHARED", "1")
-    out_g, goa_g = torch.empty_like(out), torch.empty_like(dev(oa))
-    ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out_g, n, m, d, p, S, grid_queries=True)
-    ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), torch.zeros(n, m, S, d, device="cuda"), goa_g,
+    # at this shape are the shared-geometry kernels (one lane per level prepares the points, LDS records), which want 16-byte
+    # aligned offset | logit rows -- rows pitched at 3 M L P + 4 elements take the general kernels, as any odd layout does
+    ldq_g = 3 * mlp + 4
+    oa_g = torch.zeros(n, S, ldq_g, dtype=torch.bfloat16, device="cuda")
+    oa_g[..., : 3 * mlp] = dev(oa)
+    out_g, goa_p = torch.empty_like(out), torch.zeros_like(oa_g)
+    ops.msda_fused_fwd(vdev, vstr, geom, oa_g, ldq_g, 2 * mlp, ref, S * L * 2, out_g, n, m, d, p, S, grid_queries=True)
+    ops.msda_fused_bwd(vdev, vstr, geom, oa_g, ldq_g, 2 * mlp, ref, S * L * 2, dev(gout), torch.zeros(n, m, S, d, device="cuda"), goa_p,
                        n, m, d, p, S, grid_queries=True, parts=1)
-    monkeypatch.delenv("POET_MSDA_NO_SHARED")
+    goa_g = goa_p[..., : 3 * mlp]
     assert (out_g.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item() < 6e-3
     dqg = goa_g.double().cpu()
     assert ((dqg[..., : 2 * mlp] - doa_ref[..., : 2 * mlp]).abs() * (~kink)).max().item() / doa_ref[..., : 2 * mlp].abs().max().item() < 8e-3
@@ -850,6 +858,7 @@ def test_msda_encoder_kernels_vs_explicit_full_geometry(ops, case, monkeypatch):
 
 @pytest.mark.parametrize("N,act,dp,odt", [(1024, 1, 0.1, torch.bfloat16), (768, 0, 0.0, torch.float16), (512, 0, 0.0, torch.bfloat16)])
 @pytest.mark.parametrize("rows", [102080, 5007, 4096 + 16])
+@pytest.mark.skipif(not PROBES_BUILT, reason="gemm_wr.hip lives under profiles/probes/kernels/: probe builds only (POET_BUILD_PROBES=1)")
 def test_gemm_register_stationary_equals_lds_stationary(ops, monkeypatch, N, act, dp, odt, rows):
     """gemm_wr.hip (opt-in POET_GEMM_WR=1: the split weights resident in registers, the activation through an LDS-DMA ring) computes
     the wide split-weight forward products in the accumulation order of gemm_ws.hip: the outputs -- ReLU, the dropout mask, bf16 and
