@@ -28,6 +28,11 @@ CONFIGS = {
     "tiny5": dict(d_model=64, nheads=4, enc_layers=2, dec_layers=2, d_ffn=128, n_levels=5, n_points=3,
                   num_queries=6, n_classes=5, dropout=0.1, strides=[8, 16, 32], num_channels=[32, 48, 40],
                   image_hw=(96, 128), level_hw=[(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)], batch=2),
+    # `--num_queries 100` (main.py:98; nn.MultiheadAttention has no limit, deformable_transformer.py:253): the two-wave self-attention
+    # kernels (64 < Q <= 128) and the host matcher beyond the device matcher's 64 x 64
+    "tiny100": dict(d_model=64, nheads=4, enc_layers=2, dec_layers=2, d_ffn=128, n_levels=3, n_points=4,
+                    num_queries=100, n_classes=5, dropout=0.1, strides=[8, 16], num_channels=[32, 48],
+                    image_hw=(96, 128), level_hw=[(12, 16), (6, 8), (3, 4)], batch=2),
     # BASELINE.json configs[1]/[2]: YCB-V
     "ycbv": dict(d_model=256, nheads=16, enc_layers=5, dec_layers=5, d_ffn=1024, n_levels=4, n_points=4,
                  num_queries=20, n_classes=21, dropout=0.1, strides=[8, 16, 32], num_channels=[256, 256, 256],

@@ -362,6 +362,9 @@ def main():
         _run_model("hires", 1, False, False, default_init=True)
         _run_model("lmo", 3, True, False)
         return
+    if "--queries" in sys.argv:               # --num_queries 100 (main.py:98): more object queries than one wave holds
+        _run_model("tiny100", 2, True, True)
+        return
     if "--levels" in sys.argv:                # 5 feature levels (two chained extra levels) x 3 sampling points
         _run_model("tiny5", 2, True, True)
         return
@@ -387,6 +390,7 @@ def main():
     _run_model("tiny", 2, True, True, query_embedding_mode="learned", ref_points_mode="learned")
     _run_model("tiny", 2, True, True, position_embedding="learned")
     _run_model("tiny5", 2, True, True)
+    _run_model("tiny100", 2, True, True)
     _run_inference("tiny")
     _run_inference("cfg0")
     _run_matcher()

@@ -1,7 +1,8 @@
-// Small-Q multi-head self-attention core (decoder self-attention over <= 64 object queries;
+// Small-Q multi-head self-attention core (decoder self-attention over <= 128 object queries: `--num_queries`, main.py:98;
 // reference: nn.MultiheadAttention at models/deformable_transformer.py:253,277-278, called with
 // q = k = tgt + query_pos, v = tgt, NO key-padding mask: dummy queries attend and are attended).
-// One wave per (image, head): Q x Q scores live in LDS, one lane per query row, fp32 throughout.
+// One workgroup per (image, head) -- one wave up to 64 queries (every BASELINE.json configuration), two waves up to 128: Q x Q
+// scores live in LDS, one lane per query row, fp32 throughout.
 // The in/out projections are poet_gemm calls; this kernel is only softmax(q k^T / sqrt(hd)) v with
 // dropout on the probabilities (same counter RNG in forward and backward, nothing stored).
 #include "common.cuh"
@@ -19,8 +20,8 @@ struct MhaP {
     const uint32_t* seed_dev;
 };
 
-template <int HD>
-__global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
+template <int HD, int NT>
+__global__ __launch_bounds__(NT) void mha_fwd_kernel(const MhaP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Q = p.Q;
     constexpr int PH = HD;            // rows are read by all lanes at once (broadcast): no padding, 16-byte LDS reads
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
     const int n = blockIdx.x / p.M, m = blockIdx.x % p.M;
     const int lane = threadIdx.x;
     const int64_t rbase = (int64_t)n * Q;
-    for (int i = lane; i < Q * HD; i += 64) {
+    for (int i = lane; i < Q * HD; i += NT) {
         const int r = i / HD, c = i % HD;
         sk[r * PH + c] = p.k[(rbase + r) * p.ld + m * HD + c];
         sv[r * PH + c] = p.v[(rbase + r) * p.ld + m * HD + c];
@@ -72,32 +73,43 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const MhaP p) {
     for (int c = 0; c < HD; ++c) p.out[(rbase + lane) * p.ld_out + m * HD + c] = acc[c];
 }
 
-template <int HD>
-__global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
+// OVERLAY (two waves, Q > 64): the row-phase operands (k, v) and the column-phase operands (scaled q, d(out)) SHARE their LDS --
+// 2 Q hd + 2 Q (Q + 1) floats = 148 KB at Q = 128, hd = 16 instead of 165 KB; a lane reads its own q / d(out) row from memory
+template <int HD, int NT, bool OVERLAY>
+__global__ __launch_bounds__(NT) void mha_bwd_kernel(const MhaP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Q = p.Q, PQ = Q + 1;
     constexpr int PH = HD;            // rows are read by all lanes at once (broadcast): no padding, 16-byte LDS reads
     float* sq = smem;                 // scaled q
-    float* sk = sq + Q * PH;
+    float* sk = OVERLAY ? smem : sq + Q * PH;
     float* sv = sk + Q * PH;
-    float* sdo = sv + Q * PH;
+    float* sdo = OVERLAY ? sv : sv + Q * PH;
     float* spd = sdo + Q * PH;        // dropped probabilities  [Q][Q+1]
     float* sds = spd + Q * PQ;        // dS                      [Q][Q+1]
     const int n = blockIdx.x / p.M, m = blockIdx.x % p.M;
     const int lane = threadIdx.x;
     const int64_t rbase = (int64_t)n * Q;
-    for (int i = lane; i < Q * HD; i += 64) {
+    for (int i = lane; i < Q * HD; i += NT) {
         const int r = i / HD, c = i % HD;
-        sq[r * PH + c] = p.q[(rbase + r) * p.ld + m * HD + c] * p.scale;
+        if constexpr (!OVERLAY) {
+            sq[r * PH + c] = p.q[(rbase + r) * p.ld + m * HD + c] * p.scale;
+            sdo[r * PH + c] = p.dout[(rbase + r) * p.ld_out + m * HD + c];
+        }
         sk[r * PH + c] = p.k[(rbase + r) * p.ld + m * HD + c];
         sv[r * PH + c] = p.v[(rbase + r) * p.ld + m * HD + c];
-        sdo[r * PH + c] = p.dout[(rbase + r) * p.ld_out + m * HD + c];
     }
     __syncthreads();
     if (lane < Q) {
         float qr[HD], dor[HD];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) { qr[c] = sq[lane * PH + c]; dor[c] = sdo[lane * PH + c]; }
+        for (int c = 0; c < HD; ++c) {
+            if constexpr (OVERLAY) {
+                qr[c] = p.q[(rbase + lane) * p.ld + m * HD + c] * p.scale;
+                dor[c] = p.dout[(rbase + lane) * p.ld_out + m * HD + c];
+            } else {
+                qr[c] = sq[lane * PH + c]; dor[c] = sdo[lane * PH + c];
+            }
+        }
         float mx = -3.0e38f;
     #pragma unroll 4
     for (int j = 0; j < Q; ++j) {
@@ -149,6 +161,14 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
         for (int c = 0; c < HD; ++c) p.dq[(rbase + lane) * p.ld_d + m * HD + c] = dqr[c] * p.scale;
     }
     __syncthreads();
+    if constexpr (OVERLAY) {          // every reader of k / v is past the barrier: their LDS now takes scaled q / d(out)
+        for (int i = lane; i < Q * HD; i += NT) {
+            const int r = i / HD, c = i % HD;
+            sq[r * PH + c] = p.q[(rbase + r) * p.ld + m * HD + c] * p.scale;
+            sdo[r * PH + c] = p.dout[(rbase + r) * p.ld_out + m * HD + c];
+        }
+        __syncthreads();
+    }
     if (lane < Q) {
         float dkr[HD], dvr[HD];
 #pragma unroll
@@ -170,8 +190,14 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const MhaP p) {
     }
 }
 
+constexpr size_t MHA_LDS_MAX = 160 * 1024;
+// dynamic LDS beyond the 64 KiB default needs the function attribute (set per kernel whenever a launch asks for more)
+static void mha_lds_attr(const void* fn, size_t lds) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MHA_LDS_MAX);
+}
+
 static int mha_common(MhaP& p, int N, int Q, int M, int hd, float drop_p, uint32_t seed, const uint32_t* seed_dev) {
-    POET_CHECK(N > 0 && M > 0 && Q > 0 && Q <= 64, POET_ERR_UNSUPPORTED, "mha: Q=%d must be in 1..64", Q);
+    POET_CHECK(N > 0 && M > 0 && Q > 0 && Q <= 128, POET_ERR_UNSUPPORTED, "mha: Q=%d must be in 1..128", Q);
     POET_CHECK(hd == 16 || hd == 32 || hd == 64, POET_ERR_UNSUPPORTED, "mha: head dim %d not in {16,32,64}", hd);
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "mha: drop_p");
     p.N = N; p.Q = Q; p.M = M;
@@ -195,12 +221,14 @@ extern "C" int poet_mha_fwd(const float* q, const float* k, const float* v, int6
     POET_CHECK(q && k && v && out, POET_ERR_ARG, "mha_fwd: null pointer");
     p.q = q; p.k = k; p.v = v; p.out = out; p.ld = ld; p.ld_out = ld_out;
     const size_t lds = sizeof(float) * (2 * Q * hd + Q * (Q + 1));
-    POET_CHECK(lds <= 64 * 1024, POET_ERR_UNSUPPORTED, "mha_fwd: LDS %zu > 64 KiB", lds);
-    dim3 grid(N * M), block(64);
+    POET_CHECK(lds <= MHA_LDS_MAX, POET_ERR_UNSUPPORTED, "mha_fwd: Q=%d at head dim %d needs %zu bytes of LDS (> 160 KiB)", Q, hd, lds);
+    dim3 grid(N * M);
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 16) hipLaunchKernelGGL(mha_fwd_kernel<16>, grid, block, lds, st, p);
-    else if (hd == 32) hipLaunchKernelGGL(mha_fwd_kernel<32>, grid, block, lds, st, p);
-    else hipLaunchKernelGGL(mha_fwd_kernel<64>, grid, block, lds, st, p);
+#define POET_MHA_FWD(HD, NT) do { mha_lds_attr(reinterpret_cast<const void*>(mha_fwd_kernel<HD, NT>), lds);        \
+                                  hipLaunchKernelGGL((mha_fwd_kernel<HD, NT>), grid, dim3(NT), lds, st, p); } while (0)
+    if (Q <= 64) { if (hd == 16) POET_MHA_FWD(16, 64); else if (hd == 32) POET_MHA_FWD(32, 64); else POET_MHA_FWD(64, 64); }
+    else { if (hd == 16) POET_MHA_FWD(16, 128); else if (hd == 32) POET_MHA_FWD(32, 128); else POET_MHA_FWD(64, 128); }
+#undef POET_MHA_FWD
     POET_LAUNCH_CHECK();
     return POET_OK;
 }
@@ -213,13 +241,16 @@ extern "C" int poet_mha_bwd(const float* q, const float* k, const float* v, int6
     if (rc) return rc;
     POET_CHECK(q && k && v && dout && dq && dk && dv, POET_ERR_ARG, "mha_bwd: null pointer");
     p.q = q; p.k = k; p.v = v; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv; p.ld = ld; p.ld_out = ld_out; p.ld_d = ld_d;
-    const size_t lds = sizeof(float) * (4 * Q * hd + 2 * Q * (Q + 1));
-    POET_CHECK(lds <= 64 * 1024, POET_ERR_UNSUPPORTED, "mha_bwd: LDS %zu > 64 KiB", lds);
-    dim3 grid(N * M), block(64);
+    const bool two = Q > 64;                                            // two waves: k / v and q / d(out) share their LDS (OVERLAY)
+    const size_t lds = sizeof(float) * ((two ? 2 : 4) * Q * hd + 2 * Q * (Q + 1));
+    POET_CHECK(lds <= MHA_LDS_MAX, POET_ERR_UNSUPPORTED, "mha_bwd: Q=%d at head dim %d needs %zu bytes of LDS (> 160 KiB)", Q, hd, lds);
+    dim3 grid(N * M);
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 16) hipLaunchKernelGGL(mha_bwd_kernel<16>, grid, block, lds, st, p);
-    else if (hd == 32) hipLaunchKernelGGL(mha_bwd_kernel<32>, grid, block, lds, st, p);
-    else hipLaunchKernelGGL(mha_bwd_kernel<64>, grid, block, lds, st, p);
+#define POET_MHA_BWD(HD, NT, OV) do { mha_lds_attr(reinterpret_cast<const void*>(mha_bwd_kernel<HD, NT, OV>), lds);   \
+                                      hipLaunchKernelGGL((mha_bwd_kernel<HD, NT, OV>), grid, dim3(NT), lds, st, p); } while (0)
+    if (!two) { if (hd == 16) POET_MHA_BWD(16, 64, false); else if (hd == 32) POET_MHA_BWD(32, 64, false); else POET_MHA_BWD(64, 64, false); }
+    else { if (hd == 16) POET_MHA_BWD(16, 128, true); else if (hd == 32) POET_MHA_BWD(32, 128, true); else POET_MHA_BWD(64, 128, true); }
+#undef POET_MHA_BWD
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -698,7 +698,8 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
 // flushes each window once with coalesced global atomics; a sample whose corner falls outside the window (large
 // learned offset, padded image) goes straight to a global atomic, so the result never depends on the halo.
 // Global atomics drop from (16 points x 4 corners x D) per (query, head) to ~(window pixels x D) per workgroup (~20x).
-struct TileP { int TX, TY, HALO, skip; };     // skip: timing-breakdown aid (POET_DV_SKIP bits: 1 max pass, 2 accumulate, 4 flush)
+struct TileP { int TX, TY, HALO, skip, order; };     // skip: timing-breakdown aid (POET_DV_SKIP bits: 1 max pass, 2 accumulate, 4 flush)
+                                                      // order: 1 = the 16 heads of one (tile, image) run together on ONE XCD (below)
 // 512 threads: twice the waves on the same LDS windows (the accumulate loop is VALU/LDS-issue bound at 2 waves/SIMD)
 constexpr int TILED_NT = 1024;
 
@@ -773,7 +774,28 @@ __global__ __launch_bounds__(TILED_NT) void msda_bwd_dv_tiled_kernel(const MsdaP
     __shared__ float s_red[TILED_NT / 64];
     constexpr int P = 4, D = 16, LP = L * P, NSLOT = TILED_NT / D;
     const int tid = threadIdx.x;
-    const int tx = blockIdx.x % tp.TX, ty = blockIdx.x / tp.TX, m = blockIdx.y, n = blockIdx.z;
+    // Work item -> (head, tile, image).  The operand rows are shared between heads: head m reads 32 B (grad_out), 64 B (offsets) and
+    // 32 B (logits) of rows whose 64-byte sectors it shares with head m ^ 1, and the 16 heads together read every byte of the
+    // rows exactly once.  A (tiles, M, N) grid dealt round-robin over the XCDs puts heads m and m + 1 of one (tile, image) on
+    // DIFFERENT XCDs (private L2s): every shared sector is fetched twice (counters, round 4: 1.84x / 1.87x the algorithmic bytes
+    // at LM-O / 1280x960).  order = 1: head fastest, and each XCD takes a CONTIGUOUS range of work items, so the 16 heads of a
+    // (tile, image) are resident on one XCD at the same time and share the rows through its L2.
+    int tx, ty, m, n;
+    {
+        const int txy = tp.TX * tp.TY;
+        if (tp.order) {
+            const int w = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+            m = w % p.M;
+            const int t = (w / p.M) % txy;
+            n = w / (p.M * txy);
+            tx = t % tp.TX; ty = t / tp.TX;
+        } else {
+            const int t = blockIdx.x % txy;
+            m = (blockIdx.x / txy) % p.M;
+            n = blockIdx.x / (txy * p.M);
+            tx = t % tp.TX; ty = t / tp.TX;
+        }
+    }
     int wx0[L], wy0[L], ww[L], wh[L], wp[L], loff[L + 1];    // loff in pixels; wp = LDS row pitch of the window
     loff[0] = 1;                                             // one pad pixel in front (see `arow` below)
 #pragma unroll
@@ -1138,8 +1160,10 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_dv_tiled_kernel<TQ, L, true>), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048);
         attr_set = true;
     }
-    if (p.q_f16) hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, true>), dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
-    else hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, false>), dim3(tp.TX * tp.TY, p.M, p.N), dim3(TILED_NT), lds, st, p, tp);
+    static const int order = [] { const char* e = getenv("POET_DV_ORDER"); return e ? atoi(e) : 1; }();         // (A/B aid, read once: 0 = the (tiles, M, N) grid order)
+    tp.order = order;
+    if (p.q_f16) hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, true>), dim3(tp.TX * tp.TY * p.M * p.N), dim3(TILED_NT), lds, st, p, tp);
+    else hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, false>), dim3(tp.TX * tp.TY * p.M * p.N), dim3(TILED_NT), lds, st, p, tp);
     return true;
     }
 }

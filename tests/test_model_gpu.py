@@ -34,7 +34,7 @@ def _real_query_mask(n_boxes, Q):
     return m
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("tiny", 2, False), ("cfg0", 2, False), ("cfg0", 2, True), ("tiny5", 2, True)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("tiny", 2, False), ("cfg0", 2, False), ("cfg0", 2, True), ("tiny5", 2, True), ("tiny100", 2, True)])
 def test_forward_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.float32)
@@ -65,7 +65,7 @@ def test_forward_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
         assert diff[valid].max().item() < TOL_F32
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True), ("tiny100", 2, True)])
 def test_forward_bf16_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.bfloat16)
@@ -79,7 +79,7 @@ def test_forward_bf16_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     assert dt.max().item() < TOL_BF16 and dr.max().item() < TOL_BF16
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True), ("tiny100", 2, True)])
 def test_loss_and_grads_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.float32)
@@ -364,7 +364,14 @@ FULL_SIZE = [("ycbv", 1, False, False), ("ycbv", 1, False, True),          # BAS
 # its softmax attentions: over the eight full-size goldens x {plain, arena} the worst entry measured is 6.4e-2 (LM-O bs 3,
 # decoder.layers.1.self_attn.in_proj_weight; 5.3e-2 at YCB-V); as relative L2 over ALL gradients the bf16 policy sits 4.8-5.8 %
 # from the fp32 policy (test_arena_paths_match_plain_model_at_full_size).
-GRAD_TOL_F32, GRAD_TOL_BF16 = 1e-2, 8e-2
+GRAD_TOL_F32, GRAD_TOL_BF16 = 2e-3, 8e-2        # fp32: worst measured over all full-size goldens 3.5e-4 (round 5; was 1e-2)
+# Round 5: the bf16 bound per golden = worst checksum entry measured on that golden (plain and arena pass; round-5 runs on three
+# boxes agree to the digit: the two passes are deterministic up to the decoder's bf16 atomics) x 1.3, not one flat 8e-2.  The worst
+# entry is every time the NORM of a small decoder tensor (self_attn.in_proj of layers 0 / 1, a norm1 weight): gradients that are sums
+# over a few dozen queries of terms that cancel, fed by the memory's bf16 rounding noise; the encoder tensors (sums over 6380+ token
+# rows) sit at 1.0-1.7e-2.  Other tests keep GRAD_TOL_BF16 as the ceiling.
+GRAD_TOL_BF16_AT = {("ycbv", 1, False): 4.8e-2, ("ycbv", 1, True): 7.7e-2, ("lmo", 1, False): 2.5e-2, ("lmo", 2, False): 6.4e-2,
+                    ("lmo", 1, True): 2.5e-2, ("lmo", 3, False): 3.0e-2, ("hires", 1, False): 3.0e-2, ("hires", 1, True): 5.9e-2}
 # d(sampling offset) is a ONE-SIDED derivative wherever a sampling point sits exactly on a pixel centre (bilinear
 # interpolation has a kink there).  With the reference's default init every offset is bias only, and the biases of the
 # axis / diagonal heads are exact integers (k * (1,0), k * (1,1), ...), so at init=True which side the reference itself takes
@@ -385,7 +392,8 @@ AMP0_AUX = 4.0   # auxiliary decoder layers: never more than tol / 4 = 2.5e-3 on
 # AMP0_AUX rule applies to it.  The reference's own random init (`_init` goldens, amplification up to 200x) keeps the rule on its
 # auxiliary layers and AMP0 on its final layer.
 PLAIN_ALL_LAYERS = ("ycbv", "lmo", "hires")
-PLAIN_EXCEPT = {("lmo", 2): 1.02e-2}     # (name, batch) -> measured all-layer max |dR| of the bf16 policy
+PLAIN_EXCEPT = {("lmo", 2): 1.16e-2}     # (name, batch) -> worst all-layer max |dR| of the bf16 policy measured so far (rounds 4-5: 1.02e-2 .. 1.16e-2,
+                                         # one query of an auxiliary layer; DESIGN section 2 and profiles/round5_prec_nsite_lmo_b2.txt)
 
 
 def _rotation_amplification(name, batch, pad, init):
@@ -427,10 +435,21 @@ def _grad_errors(g, grad_of, gtol, init):
             e = float(np.abs(checksum(gr[~kink]) - ref_nk).max()) / max(1e-3, abs(ref_nk[0]))
             assert torch.isfinite(gr).all() and float(gr[kink].norm()) <= KINK_NORM * max(abs(ref[0]), 1e-3) + float(gr[~kink].norm()), n
         else:
-            e = float(np.abs(checksum(gr) - ref).max()) / max(1e-3, abs(ref[0]))      # fraction of the tensor's gradient norm
+            got = checksum(gr)
+            e = float(np.abs(got - ref).max()) / max(1e-3, abs(ref[0]))      # fraction of the tensor's gradient norm
+            NORM_ERRS.append((abs(got[0] - ref[0]) / max(1e-3, abs(ref[0])), n))   # the L2 norm alone: a systematic scale error shows here
         errs.append((e / gtol, e, n))
     errs.sort(reverse=True)
     return errs
+
+
+NORM_ERRS = []       # (relative error of a tensor's gradient NORM, name) of the last _grad_errors calls; drained by _norm_worst()
+
+
+def _norm_worst():
+    w = max(NORM_ERRS, default=(0.0, ""))
+    NORM_ERRS.clear()
+    return w
 
 
 @pytest.mark.parametrize("name,batch,pad,init", FULL_SIZE)
@@ -455,7 +474,8 @@ def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, b
         layer of the `_init` goldens only.
     The printed line says for each run what the plain bound would have given."""
     g = np.load(os.path.join(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz"))
-    passes = [(torch.float32, TOL_F32, GRAD_TOL_F32, False), (torch.bfloat16, TOL_BF16, GRAD_TOL_BF16, False), (torch.bfloat16, TOL_BF16, GRAD_TOL_BF16, True)]
+    gtol16 = GRAD_TOL_BF16_AT[(name, batch, init)]
+    passes = [(torch.float32, TOL_F32, GRAD_TOL_F32, False), (torch.bfloat16, TOL_BF16, gtol16, False), (torch.bfloat16, TOL_BF16, gtol16, True)]
     amp = None
     for dtype, tol, gtol, arena in passes:
         r = gpu(name, batch, pad, dtype, default_init=init)
@@ -501,6 +521,8 @@ def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, b
         grad_of = lambda n: gof(params[n])
         grad_of.param = lambda n: params[n]
         errs = _grad_errors(g, grad_of, gtol, init)
+        nw = _norm_worst()
+        print(f"{name} b{batch} init={init} {dtype}{' arena' if arena else ''}: worst gradient-NORM error {nw[0]:.2e} ({nw[1]})")
         print(f"{name} b{batch} init={init} {dtype}{' arena' if arena else ''}: max|dt| {dt:.2e}; max|dR| final layer {dR[-1].max():.2e} all layers {dR.max():.2e} "
               f"(rms {dR.pow(2).mean().sqrt():.2e}){rule}; max loss err {lerr:.2e}; worst grad checksums {[(n, round(e, 4)) for _, e, n in errs[:3]]}")
         assert dt < tol, (dtype, dt)
@@ -538,6 +560,8 @@ def test_benched_batch_sizes_vs_reference_golden_by_replication(gpu, golden_dir,
         spread = max((trans - trans[:, :1]).abs().max().item(), (rot - rot[:, :1]).abs().max().item())
         lerr = float(np.abs(lv - g["loss_values"]).max())
         errs = _grad_errors(g, grad_of, gtol, False)
+        nw = _norm_worst()
+        print(f"{name} x{B} {tag}: worst gradient-NORM error {nw[0]:.2e} ({nw[1]})")
         print(f"{name} x{B} {tag}: max|dt| {dt.max():.2e}; max|dR| final layer {dR[-1].max():.2e} all layers {dR.max():.2e}; spread over the copies "
               f"{spread:.2e}; max loss err {lerr:.2e}; worst grad checksums {[(n, round(e, 4)) for _, e, n in errs[:3]]}")
         assert dt.max().item() < tol and dR.max().item() < tol, (tag, dt.max().item(), dR.max().item())
@@ -545,8 +569,9 @@ def test_benched_batch_sizes_vs_reference_golden_by_replication(gpu, golden_dir,
         assert errs[0][0] <= 1.0, (tag, errs[:8])
 
     gof = lambda p: getattr(p, "_grad_view", None) if getattr(p, "_grad_view", None) is not None else p.grad
-    for dtype, tol, gtol, ltol, arena in [(torch.float32, TOL_F32, GRAD_TOL_F32, 2e-4, False), (torch.bfloat16, TOL_BF16, GRAD_TOL_BF16, 2e-2, False),
-                                          (torch.bfloat16, TOL_BF16, GRAD_TOL_BF16, 2e-2, True)]:
+    gtol16 = GRAD_TOL_BF16_AT[(name, 1, False)]                 # the bs-1 golden's own bound: B copies average the same realisation
+    for dtype, tol, gtol, ltol, arena in [(torch.float32, TOL_F32, GRAD_TOL_F32, 2e-4, False), (torch.bfloat16, TOL_BF16, gtol16, 2e-2, False),
+                                          (torch.bfloat16, TOL_BF16, gtol16, 2e-2, True)]:
         r = gpu(name, 1, False, dtype, replicate=B)
         model, crit = r["model"], r["crit"]
         model.eval()                                            # dropout off, as in the golden run
@@ -584,7 +609,7 @@ def test_benched_batch_sizes_vs_reference_golden_by_replication(gpu, golden_dir,
     params = dict(r["model"].named_parameters())
     grad_of = lambda n: gof(params[n])
     grad_of.param = lambda n: params[n]
-    check("bf16 graph replay", tr.s_trans.detach().float().cpu(), tr.s_rot.detach().float().cpu(), lv, grad_of, TOL_BF16, GRAD_TOL_BF16, 2e-2)
+    check("bf16 graph replay", tr.s_trans.detach().float().cpu(), tr.s_rot.detach().float().cpu(), lv, grad_of, TOL_BF16, gtol16, 2e-2)
 
 
 def test_arena_trainer_matches_oracle_step(gpu):
