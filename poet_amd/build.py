@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpoet_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "gemm_dw.hip", "gemm_small.hip", "gemm_pipe.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_ws.hip", "gemm_dw.hip", "gemm_dwr.hip", "gemm_small.hip", "gemm_pipe.hip", "msda.hip", "norm.hip", "attn.hip", "misc.hip"]
 # Kernels that were built, measured and LOST live under profiles/probes/kernels/ and are NOT in the product
 # library.  POET_BUILD_PROBES=1 compiles them in (-DPOET_PROBE_KERNELS: gemm_wr.hip + the msda_*.inc fragments msda.hip includes)
 # so that their A/B scripts under profiles/probes/ still run; each stays behind its own opt-in environment switch.

@@ -10,6 +10,7 @@ struct GemmK {
     int a_vec, b_vec, c_vec;
     uint32_t drop_thresh;
     float drop_scale;
+    int stagger;          // gemm_ws: initial delay (x 1024 cycles) of the upper half of a workgroup's waves (phase offset between the waves of a SIMD)
 };
 
 // launches the streaming kernel and returns true when the problem is one it handles; false = use the generic kernel
@@ -19,7 +20,9 @@ bool gemm_ws_try(const GemmK& p, hipStream_t st);
 // gemm_ws, lives in profiles/probes/kernels/gemm_wr.hip and is compiled only into probe builds (POET_BUILD_PROBES=1)
 bool gemm_wr_try(const GemmK& p, hipStream_t st);
 #endif
-// same contract for the weight-gradient kernel (gemm_dw.hip)
+// same contract for the weight-gradient kernels: the DMA-ring form (gemm_dwr.hip: 256 x 128 tiles, wide shapes) is asked first, then
+// the register-staged one (gemm_dw.hip)
+bool gemm_dwr_try(const GemmK& p, hipStream_t st);
 bool gemm_dw_try(const GemmK& p, hipStream_t st);
 // plain tall-skinny bf16 x bf16 -> fp32 (+=) products with N = 256, K >= 512: the deep-pipeline kernel (gemm_pipe.hip)
 bool gemm_pipe_try(const GemmK& p, hipStream_t st);

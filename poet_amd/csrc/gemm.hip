@@ -496,6 +496,7 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     const int BKB = d.b_split ? (tcs == 0 ? split_bkb() : 128) : (tcs == 0 ? 128 : (tcs == 3 ? 1024 : 256));
     const int BK = BKB / (d.compute == POET_BF16 ? 2 : 4);
     p.kchunk = cdiv(cdiv(d.K, d.splitk), BK) * BK;
+    { static const int stg = [] { const char* e = getenv("POET_WS_STAGGER"); return e ? atoi(e) : 0; }(); p.stagger = stg; }
     p.a_vec = vec_ok(d.A, d.lda, d.strideA);
     p.b_vec = vec_ok(d.B, d.ldb, d.strideB);
     p.c_vec = vec_ok(d.C, d.ldc, d.strideC) && (!d.add_src || vec_ok(d.add_src, d.ld_add, 0)) && (!d.gate_ref || vec_ok(d.gate_ref, d.ldc, 0)) &&
@@ -505,7 +506,7 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-    if (gemm_dw_try(p, st)) {                               // streaming dW (gemm_dw.hip); fuses the bias gradient of the dW form
+    if (gemm_dwr_try(p, st) || gemm_dw_try(p, st)) {        // streaming dW (gemm_dwr.hip: DMA ring, wide shapes; gemm_dw.hip); both fuse the bias gradient of the dW form
         g_last_path = POET_GEMM_PATH_DW;
         POET_LAUNCH_CHECK();
         return POET_OK;

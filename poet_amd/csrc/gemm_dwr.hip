@@ -1,0 +1,309 @@
+// Weight-gradient GEMM, DMA-ring form, for gfx950:  dW[n1, n2] += sum_r dY[r, n1] * X[r, n2]  (+ db[n1] += sum_r dY[r, n1]),
+// r over ~1e5 token rows -- the backward of every encoder nn.Linear (reference: autograd of the Linear layers in
+// models/deformable_transformer.py:193-208 and of MSDeformAttn's projections).  Same product as gemm_dw.hip, organised the way
+// the counters of round 4 asked for:
+//
+//  * one persistent 768-thread workgroup per CU owns a 256 (n1) x 128 (n2) tile of dW and one contiguous range of 64-row stages
+//    (1024 x 256: 8 tiles x 32 row ranges): a quarter less panel traffic out of the L2s than 128 x 128 tiles (627 instead of
+//    836 MB at 1024 x 256) at HALF the partial-tile bytes of a 256 x 256 tile;
+//  * the two operand panels of a stage (64 x 256 of dY, 64 x 128 of X: 48 KB) reach LDS by DMA (global_load_lds_dwordx4: no
+//    VGPRs, no ds_write, no staging instructions in the compute waves' stream) into a THREE-stage ring, two stages = 96 KB in
+//    flight per CU, issued by 4 loader waves that do nothing else; counted s_waitcnt vmcnt(N) + one raw s_barrier per stage
+//    (the skeleton of gemm_pipe.hip);
+//  * the LDS images are plain row-major copies of memory (the reduction index r is the slow dimension of BOTH operands) with the
+//    32-byte pieces of a row XOR-swizzled by the row index -- applied to the per-lane SOURCE address of the DMA -- and the 8
+//    compute waves (4 x 2, 64 x 64 of the tile each) take their MFMA fragments out with ds_read_b64_tr_b16, the CDNA4 transposing
+//    LDS read, exactly as gemm_dw.hip does;
+//  * the bias gradient (column sums of dY) comes off the matrix pipe: the n2-tile-0 workgroups multiply the dY fragments they
+//    already hold with a fragment of ones (4 extra MFMAs per 16 in four of their eight waves);
+//  * partial tiles (and the bias partials) leave by plain stores into the caller's workspace and ONE reduction kernel adds the
+//    row ranges into the gradient in a fixed order: no atomics at all, deterministic.
+#include "gemm.cuh"
+
+#include <stdlib.h>
+
+namespace poet {
+
+namespace {
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+
+constexpr int R_TY = 256, R_TX = 128;            // tile: n1 x n2
+constexpr int R_RS = 64;                         // rows per stage
+constexpr int R_NST = 3;                         // ring depth (R_NST - 1 stages in flight)
+constexpr int R_YROWB = R_TY * 2, R_XROWB = R_TX * 2;
+constexpr int R_YPANEL = R_RS * R_YROWB;         // 32 KB
+constexpr int R_XPANEL = R_RS * R_XROWB;         // 16 KB
+constexpr int R_STAGE = R_YPANEL + R_XPANEL;     // 48 KB
+constexpr int R_NCW = 8, R_NLW = 4, R_NT = (R_NCW + R_NLW) * 64;
+constexpr int R_YQ = R_YPANEL / 1024 / R_NLW;    // DMA instructions per loader wave and stage: 8 (dY) + 4 (X)
+constexpr int R_XQ = R_XPANEL / 1024 / R_NLW;
+constexpr int R_TILE_F = R_TY * R_TX;            // floats per partial tile
+
+struct DwrP {
+    const bf16_t* Y;
+    const bf16_t* X;
+    float* C;
+    float* ysum;
+    float* ws;
+    float* wsb;           // bias-gradient partials [splits][n1] behind the partial tiles (nullptr: no bias gradient)
+    int64_t ldy, ldx, ldc;
+    int rows, n1, n2, ntiles, tiles_n2, splits;
+};
+
+// piece swizzle of a row (gemm_dw.hip's): 32-byte pieces XORed with (row & 3) | bit 3 of the row << 2
+__device__ __forceinline__ int r_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__device__ __forceinline__ void r_dma16(uint32_t voff, const void* base, uint32_t lds) {
+    // (M0 is written behind the compiler's back -- hipcc rejects "m0" on a clobber list; nothing else in this translation unit uses M0:
+    // tests/test_abi_cpu.py::test_pipe_kernel_m0_only_in_dma greps the ISA)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
+}
+template <int N> __device__ __forceinline__ void r_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(R_NT, 3) void gemm_dwr_kernel(const DwrP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+    // ---- work assignment: (tile, row range); the tiles of a range share an XCD (workgroup b -> XCD b % 8) ----
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % p.ntiles, split = (j / p.ntiles) * 8 + xcd;
+    if (split >= p.splits) return;
+    const int n1_0 = (tile / p.tiles_n2) * R_TY, n2_0 = (tile % p.tiles_n2) * R_TX;
+    const int nst = (p.rows + R_RS - 1) / R_RS;
+    const int s_lo = (int)((int64_t)split * nst / p.splits), s_hi = (int)((int64_t)(split + 1) * nst / p.splits);
+    const int S = s_hi - s_lo;
+    if (S <= 0) return;
+    // a ragged LAST stage of the whole problem: its rows past p.rows are clamped re-reads that the compute waves zero in LDS
+    const int ragged = (s_hi == nst && (p.rows % R_RS) != 0) ? (p.rows - (nst - 1) * R_RS) : 0;      // valid rows of that stage, 0 = none
+
+    if (wave >= R_NCW) {
+        // ====== loader waves: the two panels of every stage by LDS-DMA, R_NST - 1 stages ahead ======
+        constexpr int PD = R_NST - 1, NPL = R_YQ + R_XQ, LW = NPL * (PD - 1);
+        const int lw = wave - R_NCW;
+        const int ldyB = (int)p.ldy * 2, ldxB = (int)p.ldx * 2;
+        // instruction q of this wave covers 1 KB of a panel image: dY 2 rows x 512 B, X 4 rows x 256 B; lane -> (row, 16-byte chunk)
+        // of the IMAGE, whose content is the source chunk with its 32-byte piece un-swizzled
+        int y_row[R_YQ], y_col[R_YQ], x_row[R_XQ], x_col[R_XQ];
+#pragma unroll
+        for (int q = 0; q < R_YQ; ++q) {
+            const int pos = ((lw * R_YQ + q) * 64 + lane) * 16, row = pos / R_YROWB, c = (pos % R_YROWB) >> 4, pc = c >> 1;
+            y_row[q] = row;
+            y_col[q] = ((((pc & 8) | ((pc ^ r_swz(row)) & 7)) << 1) | (c & 1)) * 16;
+        }
+#pragma unroll
+        for (int q = 0; q < R_XQ; ++q) {
+            const int pos = ((lw * R_XQ + q) * 64 + lane) * 16, row = pos / R_XROWB, c = (pos % R_XROWB) >> 4, pc = c >> 1;
+            x_row[q] = row;
+            x_col[q] = ((((pc ^ r_swz(row)) & 7) << 1) | (c & 1)) * 16;
+        }
+        const char* Yb = reinterpret_cast<const char*>(p.Y + n1_0);
+        const char* Xb = reinterpret_cast<const char*>(p.X + n2_0);
+        int l_s = s_lo, l_slot = 0;
+        auto issue = [&]() {
+            const int r0 = l_s * R_RS;
+            const int rv = min(R_RS, p.rows - r0);                      // (uniform) valid rows of this stage
+            const char* yb = Yb + (int64_t)r0 * ldyB;
+            const char* xb = Xb + (int64_t)r0 * ldxB;
+            const uint32_t slot = lds0 + l_slot * R_STAGE;
+#pragma unroll
+            for (int q = 0; q < R_YQ; ++q)
+                r_dma16((uint32_t)(min(y_row[q], rv - 1) * ldyB + y_col[q]), yb, slot + (lw * R_YQ + q) * 1024);
+#pragma unroll
+            for (int q = 0; q < R_XQ; ++q)
+                r_dma16((uint32_t)(min(x_row[q], rv - 1) * ldxB + x_col[q]), xb, slot + R_YPANEL + (lw * R_XQ + q) * 1024);
+            ++l_s;
+            l_slot = (l_slot + 1 == R_NST) ? 0 : l_slot + 1;
+        };
+#pragma unroll 1
+        for (int i = 0; i < min(PD, S); ++i) issue();
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            // stage s has landed (this wave's share) when at most the loads issued after it are outstanding
+            if (min(S, s + PD) - (s + 1) < PD - 1) r_wait_vm<0>(); else r_wait_vm<LW>();
+            __builtin_amdgcn_s_barrier();                               // every share of stage s landed; the slot of stage s - 1 is free
+            if (ragged && s == S - 1) __builtin_amdgcn_s_barrier();     // (the compute waves zero the clamped rows in between)
+            if (l_s < s_hi) issue();
+        }
+        return;
+    }
+
+    // =========================== compute waves: 64 x 64 of the tile each (4 x 2) ===========================
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_sum = p.wsb != nullptr && n2_0 == 0 && wn == 0;      // wave-uniform
+    f32x4_t accs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+    {
+        const uint4 o = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        ones = __builtin_bit_cast(bf16x8_t, o);
+    }
+
+    // per-lane constants of the transposing read: source lane r of a 16-lane block points at row 8 b + (r >> 2) (+ 4 for the
+    // second half), 8-byte chunk r & 3 of the fragment's 32-byte piece
+    const int r16 = lane & 15, b4 = lane >> 4;
+    const int trow = 8 * b4 + (r16 >> 2), tswz = (r16 >> 2) | ((b4 & 1) << 2), tcol = (r16 & 3) * 8;
+    int ty[4], tx[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int py = wm * 4 + f, px = wn * 4 + f;
+        ty[f] = trow * R_YROWB + (((py & 8) | ((py ^ tswz) & 7)) << 5) + tcol;
+        tx[f] = R_YPANEL + trow * R_XROWB + (((px ^ tswz) & 7) << 5) + tcol;
+    }
+
+    int slot = 0;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        __builtin_amdgcn_s_barrier();                                   // stage s has landed
+        asm volatile("" ::: "memory");
+        char* sb = smem + slot * R_STAGE;
+        slot = (slot + 1 == R_NST) ? 0 : slot + 1;
+        if (ragged && s == S - 1) {                                     // zero the rows past the end of the problem (uniform branch)
+            const int ct = tid;                                         // 512 compute threads
+            for (int i = ct; i < (R_RS - ragged) * (R_YROWB / 16); i += R_NCW * 64)
+                *reinterpret_cast<uint4*>(sb + ragged * R_YROWB + i * 16) = make_uint4(0, 0, 0, 0);
+            for (int i = ct; i < (R_RS - ragged) * (R_XROWB / 16); i += R_NCW * 64)
+                *reinterpret_cast<uint4*>(sb + R_YPANEL + ragged * R_XROWB + i * 16) = make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the zeros are in LDS
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int ks = 0; ks < R_RS / 32; ++ks) {
+            bf16x8_t fy[4], fx[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                struct { v4s_t lo, hi; } u, v;
+                u.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + ty[f] + ks * 32 * R_YROWB));
+                u.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + ty[f] + (ks * 32 + 4) * R_YROWB));
+                v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + tx[f] + ks * 32 * R_XROWB));
+                v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + tx[f] + (ks * 32 + 4) * R_XROWB));
+                fy[f] = __builtin_bit_cast(bf16x8_t, u);
+                fx[f] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[jj], acc[i][jj], 0, 0, 0);
+            if (do_sum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], ones, accs[i], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- bias gradient: every column of accs[i] is the row sum; lanes r16 == 0 hold rows 4 b4 + t of fragment i.  Partials go to
+    // the workspace like the tiles (128 row ranges adding into 256 addresses with memory-side atomics cost 16 us at 256 x 256) ----
+    if (do_sum && r16 == 0) {
+        float* bp = p.wsb + (int64_t)split * p.n1 + n1_0 + wm * 64 + b4 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(bp + i * 16) = accs[i];
+    }
+    // ---- partial tile: plain, fully coalesced stores of the register image (wave, fragment, t, lane) ----
+    float* wp = p.ws + ((int64_t)split * p.ntiles + tile) * R_TILE_F + wave * 4096 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wp[((i * 4 + jj) * 4 + t) * 64] = acc[i][jj][t];
+}
+
+// dW[tile] += sum over row ranges of the partial tiles (single owner per element: a plain read-modify-write, fixed order)
+__global__ __launch_bounds__(256) void dwr_reduce_kernel(const DwrP p) {
+    const int tile = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;               // e: index inside the 256 x 128 register image
+    const float* wp = p.ws + (int64_t)tile * R_TILE_F + e;
+    const int64_t stride = (int64_t)p.ntiles * R_TILE_F;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < p.splits; k += 4) {
+        s0 += wp[(int64_t)k * stride]; s1 += wp[(int64_t)(k + 1) * stride];
+        s2 += wp[(int64_t)(k + 2) * stride]; s3 += wp[(int64_t)(k + 3) * stride];
+    }
+    for (; k < p.splits; ++k) s0 += wp[(int64_t)k * stride];
+    const int lane = e & 63, t = (e >> 6) & 3, fr = (e >> 8) & 15, wid = e >> 12;
+    const int i = fr >> 2, jj = fr & 3, wm = wid >> 1, wn = wid & 1, r16 = lane & 15, b4 = lane >> 4;
+    const int n1_0 = (tile / p.tiles_n2) * R_TY, n2_0 = (tile % p.tiles_n2) * R_TX;
+    float* c = p.C + (int64_t)(n1_0 + wm * 64 + i * 16 + b4 * 4 + t) * p.ldc + n2_0 + wn * 64 + jj * 16 + r16;
+    *c += (s0 + s1) + (s2 + s3);
+    if (p.wsb && blockIdx.x < 8 && n2_0 == 0) {                         // db[n1_0 .. n1_0 + 256) += sum over row ranges (fixed order):
+        // 8 blocks x 32 entries, 8 lanes per entry take every 8th row range (independent loads), folded with three DPP steps
+        const int ent = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+        const float* bp = p.wsb + n1_0 + ent;
+        float b0 = 0.f, b1 = 0.f;
+        int q = part;
+        for (; q + 8 < p.splits; q += 16) { b0 += bp[(int64_t)q * p.n1]; b1 += bp[(int64_t)(q + 8) * p.n1]; }
+        if (q < p.splits) b0 += bp[(int64_t)q * p.n1];
+        float b = b0 + b1;
+        b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4);
+        if (part == 0) p.ysum[n1_0 + ent] += b;
+    }
+}
+
+int dwr_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+}  // namespace
+
+bool gemm_dwr_try(const GemmK& g, hipStream_t st) {
+    const PoetGemmDesc& d = g.d;
+    // which shapes take the ring (POET_DW_RING: 0 = none, 1 = all eligible, default = the ones it measured faster on: see gemm_dwr_shapes)
+    static const int mode = [] { const char* e = getenv("POET_DW_RING"); return e ? atoi(e) : 2; }();
+    if (mode == 0) return false;
+    // the dW form of poet_gemm: A = dY stored [K = rows][M = n1], B = X stored [K = rows][N = n2], fp32 accumulate into C
+    if (!d.a_kmajor || !d.b_kmajor || !(d.atomic || d.splitk > 1) || d.batch != 1 || d.A2) return false;
+    if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || d.c_dtype != POET_F32 || d.compute != POET_BF16) return false;
+    if (d.M % R_TY != 0 || d.N % R_TX != 0 || d.K < 8192 || d.alpha != 1.f) return false;
+    if (!g.a_vec || !g.b_vec) return false;
+    if ((int64_t)R_RS * d.lda * 2 >= (1LL << 31) || (int64_t)R_RS * d.ldb * 2 >= (1LL << 31)) return false;   // 32-bit lane offsets inside a stage
+    if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B)) & 15) return false;
+    if ((d.lda & 7) || (d.ldb & 7)) return false;
+    DwrP p;
+    p.Y = reinterpret_cast<const bf16_t*>(d.A);
+    p.X = reinterpret_cast<const bf16_t*>(d.B);
+    p.C = reinterpret_cast<float*>(d.C);
+    p.ysum = const_cast<float*>(d.bias);
+    p.ldy = d.lda; p.ldx = d.ldb; p.ldc = d.ldc;
+    p.rows = d.K; p.n1 = d.M; p.n2 = d.N;
+    p.tiles_n2 = d.N / R_TX;
+    p.ntiles = (d.M / R_TY) * p.tiles_n2;
+    if (mode == 2 && p.ntiles < 6) return false;                         // 256 x 256 (2 tiles, 128 row ranges of 12 stages): the register-staged kernel
+    const int cus = dwr_cus();
+    int per = cus / 8 / p.ntiles;                                      // row ranges per XCD: one workgroup per CU
+    if (per < 1) per = 1;
+    p.splits = per * 8;
+    const int nst = (p.rows + R_RS - 1) / R_RS;
+    if (p.splits > nst) p.splits = nst;
+    const int64_t tile_bytes = (int64_t)p.splits * p.ntiles * R_TILE_F * 4;
+    const int64_t need = tile_bytes + (p.ysum ? (int64_t)p.splits * p.n1 * 4 : 0);
+    if (!d.workspace || d.workspace_bytes < need || (reinterpret_cast<uintptr_t>(d.workspace) & 15)) return false;
+    p.ws = reinterpret_cast<float*>(d.workspace);
+    p.wsb = p.ysum ? p.ws + tile_bytes / 4 : nullptr;
+    const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dwr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R_NST * R_STAGE);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_dwr_kernel, dim3(nblocks), dim3(R_NT), R_NST * R_STAGE, st, p);
+    hipLaunchKernelGGL(dwr_reduce_kernel, dim3(R_TILE_F / 256, p.ntiles), dim3(256), 0, st, p);
+    return true;
+}
+
+}  // namespace poet

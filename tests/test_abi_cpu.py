@@ -135,9 +135,9 @@ def test_graft_entry_build_passes():
     __graft_entry__.build()
 
 
-@pytest.mark.parametrize("src", ["gemm_pipe.hip"])
+@pytest.mark.parametrize("src", ["gemm_pipe.hip", "gemm_dwr.hip"])
 def test_pipe_kernel_m0_only_in_dma(tmp_path, src):
-    """gemm_pipe.hip sets M0 by hand inside its LDS-DMA inline asm (hipcc accepts no "m0" clobber: reserved register).  That is
+    """gemm_pipe.hip (and gemm_dwr.hip, the DMA-ring weight-gradient kernel) sets M0 by hand inside its LDS-DMA inline asm (hipcc accepts no "m0" clobber: reserved register).  That is
     safe only while nothing else in that translation unit uses M0: the compiled ISA may mention m0 only as `s_mov_b32 m0, sN`
     (the asm's own write) -- no movrel / gpr-index, no compiler-generated M0 reads."""
     import shutil
