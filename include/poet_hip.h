@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define POET_ABI_VERSION 3
+#define POET_ABI_VERSION 4
 #define POET_SQNORM_SCRATCH 1024
 
 #define POET_F32 0
@@ -129,6 +129,15 @@ typedef struct PoetGemmDesc {
                               same layout and ldb as B, which then holds hi) -- the two images the optimiser kernel maintains
                               (poet_adamw p_bf16 / p_bf16_lo); the long-K kernel multiplies every activation fragment with both
                               in one pass over A */
+    /* ABI version 4: per-segment column sums of A out of the weight-gradient form's own pass over A (a_kmajor = b_kmajor = 1, atomic):
+       seg_sums[s][m] += sum of A[r][m] over the rows r with seg_start[s] <= r % seg_period < seg_start[s + 1], s < seg_n <= 8.
+       The encoder's d(offsets | logits) rows feed both the bias gradients and d(level_embed) through the sums over the rows of one
+       feature LEVEL (deformable_transformer.py:139-141: pos + level_embed[l]); rows of an image are its levels back to back, so
+       seg_period = tokens per image, seg_start = the level starts.  NULL = off.  With seg_sums the plain `bias` sum is not formed. */
+    float* seg_sums;
+    int64_t ld_seg;        /* row stride of seg_sums (elements) */
+    int32_t seg_n, seg_period;
+    int32_t seg_start[10]; /* seg_n + 1 entries used */
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
 /* Which kernel family the calling thread's last successful poet_gemm launched (profiling aid: lets a caller attribute a

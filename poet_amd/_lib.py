@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpoet_hip.so")
-ABI_VERSION = 3                                # POET_ABI_VERSION of include/poet_hip.h this binding was written against
+ABI_VERSION = 4                                # POET_ABI_VERSION of include/poet_hip.h this binding was written against
 
 F32, BF16 = 0, 1
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("out_mode", C.c_int32), ("hm_M", C.c_int32), ("hm_S", C.c_int32), ("hm_D", C.c_int32),
         ("seed_dev", vp), ("b_split", C.c_int32), ("c_f16", C.c_int32), ("workspace", vp), ("workspace_bytes", i64),
         ("B_lo", vp),
+        ("seg_sums", vp), ("ld_seg", i64), ("seg_n", C.c_int32), ("seg_period", C.c_int32), ("seg_start", C.c_int32 * 10),
     ]
 
 

@@ -26,6 +26,9 @@ def next_seed() -> int:
     return (_seed_state["base"] + _seed_state["count"] * 0x9E3779B1) & 0xFFFFFFFF
 
 
+_ENV_SEG_FUSE = __import__("os").environ.get("POET_NO_SEG_FUSE", "0") in ("", "0")      # (A/B aid, read at import)
+
+
 def empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -153,13 +156,19 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
                        grid_queries=grid_queries, ld_grad=ldg, gv_strides=None if gvs == vstrides_of(V) else gvs)
     plain = seg_sums is None
     pr = _pair(so_w, dOA)
+    seg_done = False
     if pr is not None and pr[2].data_ptr() == g_so_w.data_ptr():      # (the gradient sink is the arena: stacked dW + db)
-        ops.linear_dw(dOA, q2d, pr[2], rows=rows, ldy=ldg, db=pr[3] if plain else None)
+        # the per-level column sums ride in the weight-gradient kernel's own pass over d(offsets | logits) (PoetGemmDesc.seg_sums):
+        # no 157 MB column-sum launch per layer
+        seg_done = seg_sums is not None and seg_sums.stride(0) == ldq and Lq >= 64 and _ENV_SEG_FUSE
+        ops.linear_dw(dOA, q2d, pr[2], rows=rows, ldy=ldg, db=pr[3] if plain else None,
+                      seg=(seg_sums, geom.c_segs, Lq) if seg_done else None)
     else:
         ops.linear_dw(dOA, q2d, g_so_w, rows=rows, ldy=ldg, db=g_so_b if plain else None)
         ops.linear_dw(dOA[:, 2 * mlp:], q2d, g_aw_w, rows=rows, ldy=ldg, db=g_aw_b if plain else None)
     if seg_sums is not None:      # per-level column sums (encoder): feeds both the biases and level_embed
-        ops.colsum(dOA, ldg, seg_sums, N, Lq, ldq, geom.c_segs, geom.L)
+        if not seg_done:
+            ops.colsum(dOA, ldg, seg_sums, N, Lq, ldq, geom.c_segs, geom.L)
         ops.colsum(seg_sums, ldq, g_so_b, 1, geom.L, 2 * mlp)
         ops.colsum(seg_sums[:, 2 * mlp:], ldq, g_aw_b, 1, geom.L, mlp)
     if dq is not None:

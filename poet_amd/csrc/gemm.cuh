@@ -10,7 +10,6 @@ struct GemmK {
     int a_vec, b_vec, c_vec;
     uint32_t drop_thresh;
     float drop_scale;
-    int stagger;          // gemm_ws: initial delay (x 1024 cycles) of the upper half of a workgroup's waves (phase offset between the waves of a SIMD)
 };
 
 // launches the streaming kernel and returns true when the problem is one it handles; false = use the generic kernel

@@ -479,6 +479,12 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         POET_CHECK((!d.bias || dw_form) && !d.act && !d.gate_ref && !d.add_src && d.drop_p == 0.f && !d.row_mask, POET_ERR_ARG,
                    "poet_gemm: atomic/split-K allows no epilogue");
     }
+    if (d.seg_sums) {                                      // per-segment column sums of A out of the weight-gradient pass (ABI v4)
+        POET_CHECK(dw_form && d.batch == 1 && !ysum, POET_ERR_ARG, "poet_gemm: seg_sums belongs to the weight-gradient form (a_kmajor, b_kmajor, atomic), batch 1, bias NULL");
+        POET_CHECK(d.seg_n >= 1 && d.seg_n <= 8 && d.seg_period >= 64 && d.K % d.seg_period == 0 && d.ld_seg >= d.M && d.seg_start[0] == 0 &&
+                   d.seg_start[d.seg_n] == d.seg_period, POET_ERR_ARG, "poet_gemm: seg_sums: 1..8 segments covering a period >= 64 that divides the row count");
+        for (int i = 0; i < d.seg_n; ++i) POET_CHECK(d.seg_start[i] <= d.seg_start[i + 1], POET_ERR_ARG, "poet_gemm: seg_start must ascend");
+    }
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.c_f16)
         POET_CHECK(d.c_dtype == POET_BF16 && !d.add_src && !d.gate_ref && !atomic, POET_ERR_ARG,
@@ -496,7 +502,6 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     const int BKB = d.b_split ? (tcs == 0 ? split_bkb() : 128) : (tcs == 0 ? 128 : (tcs == 3 ? 1024 : 256));
     const int BK = BKB / (d.compute == POET_BF16 ? 2 : 4);
     p.kchunk = cdiv(cdiv(d.K, d.splitk), BK) * BK;
-    { static const int stg = [] { const char* e = getenv("POET_WS_STAGGER"); return e ? atoi(e) : 0; }(); p.stagger = stg; }
     p.a_vec = vec_ok(d.A, d.lda, d.strideA);
     p.b_vec = vec_ok(d.B, d.ldb, d.strideB);
     p.c_vec = vec_ok(d.C, d.ldc, d.strideC) && (!d.add_src || vec_ok(d.add_src, d.ld_add, 0)) && (!d.gate_ref || vec_ok(d.gate_ref, d.ldc, 0)) &&
@@ -506,6 +511,19 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+    if (d.seg_sums && gemm_dwr_try(p, st)) {                // the DMA-ring dW forms the per-segment sums in its own pass over A
+        g_last_path = POET_GEMM_PATH_DW;
+        POET_LAUNCH_CHECK();
+        return POET_OK;
+    }
+    if (d.seg_sums) {                                       // every other kernel: a column-sum launch of its own over A, then the plain product
+        POET_CHECK(d.ld_seg == d.M, POET_ERR_UNSUPPORTED, "poet_gemm: seg_sums with ld_seg != M needs the DMA-ring weight-gradient kernel");
+        int64_t segs[10];
+        for (int i = 0; i <= d.seg_n; ++i) segs[i] = d.seg_start[i];
+        const int rc = poet_colsum(d.A, d.lda, d.seg_sums, d.K / d.seg_period, d.seg_period, d.M, segs, d.seg_n, d.a_dtype, stream);
+        if (rc) return rc;
+        d.seg_sums = nullptr;
+    }
     if (gemm_dwr_try(p, st) || gemm_dw_try(p, st)) {        // streaming dW (gemm_dwr.hip: DMA ring, wide shapes; gemm_dw.hip); both fuse the bias gradient of the dW form
         g_last_path = POET_GEMM_PATH_DW;
         POET_LAUNCH_CHECK();

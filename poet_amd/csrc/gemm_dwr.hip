@@ -47,7 +47,12 @@ struct DwrP {
     float* C;
     float* ysum;
     float* ws;
-    float* wsb;           // bias-gradient partials [splits][n1] behind the partial tiles (nullptr: no bias gradient)
+    float* wsb;           // bias-gradient partials [splits][nsum][n1] behind the partial tiles (nullptr: no column sums)
+    // per-segment column sums of dY (PoetGemmDesc.seg_sums): nsum = seg_n > 0 ? seg_n : 1 sums per column
+    float* seg_out;
+    int64_t ld_seg;
+    int seg_n, seg_period;
+    int seg_start[9];
     int64_t ldy, ldx, ldc;
     int rows, n1, n2, ntiles, tiles_n2, splits;
 };
@@ -138,10 +143,12 @@ __global__ __launch_bounds__(R_NT, 3) void gemm_dwr_kernel(const DwrP p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const bool do_sum = p.wsb != nullptr && n2_0 == 0 && wn == 0;      // wave-uniform
-    f32x4_t accs[4];
+    // column sums of dY (bias gradient / per-segment sums): in the n2-tile-0 workgroups, the two waves that hold the same dY fragments
+    // (wn = 0, 1) take two of the four fragments each, so every SIMD carries the same 2 extra MFMAs per 16
+    const bool do_sum = p.wsb != nullptr && n2_0 == 0;                 // workgroup-uniform
+    f32x4_t accs[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i) accs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     bf16x8_t ones;
     {
         const uint4 o = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
@@ -160,7 +167,88 @@ __global__ __launch_bounds__(R_NT, 3) void gemm_dwr_kernel(const DwrP p) {
         tx[f] = R_YPANEL + trow * R_XROWB + (((px ^ tswz) & 7) << 5) + tcol;
     }
 
+    // segment-indicator fragments of a stage's two 32-row blocks (pos = position of the stage's first row inside its period, uniform)
+    bf16x8_t indk[R_RS / 32] = {ones, ones};
+    // the segment table in SGPRs for the whole kernel: read through `p` inside the loop it is re-fetched from the kernel-argument
+    // segment every stage (s_load + s_waitcnt lgkmcnt(0): ~15 % on the tile-column-0 workgroups)
+    int sst[8], s_per = p.seg_period, s_n = p.seg_n;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { sst[t] = (t >= 1 && t < p.seg_n) ? p.seg_start[t] : 0x7fffffff; asm volatile("" : "+s"(sst[t])); }
+    asm volatile("" : "+s"(s_per), "+s"(s_n));
+    // scalar cursor: the segment `cur` the stage's first row lies in and the position `nxt` where it ends.  A stage that ends before
+    // `nxt` (almost all of them: levels are hundreds of rows) has both fragments = ones in column `cur`; only a stage that straddles a
+    // segment or image boundary takes the block-by-block / row-by-row forms below.  (The first version re-derived the segment of every
+    // 32-row block with a 14-compare chain per block: 15 us of 58 on the tile-column-0 workgroups.)
+    int cur = 0, nxt = 0x7fffffff;
+    auto locate = [&](int pos) __attribute__((always_inline)) {
+        int c = 0, n = s_per;
+#pragma unroll
+        for (int t = 1; t < 8; ++t) {
+            c += (pos >= sst[t]) ? 1 : 0;
+            n = (sst[t] > pos && sst[t] < n) ? sst[t] : n;
+        }
+        cur = __builtin_amdgcn_readfirstlane(c);
+        nxt = __builtin_amdgcn_readfirstlane(n);
+    };
+    auto make_ind = [&](int pos0) __attribute__((always_inline)) {
+        if (!(do_sum && s_n > 0)) return;
+        if (__builtin_amdgcn_readfirstlane(pos0 + R_RS - 1 < nxt ? 1 : 0)) {
+            const uint32_t w1 = (cur == r16) ? 0x3f803f80u : 0u;
+            const uint4 o = make_uint4(w1, w1, w1, w1);
+#pragma unroll
+            for (int ks = 0; ks < R_RS / 32; ++ks) indk[ks] = __builtin_bit_cast(bf16x8_t, o);
+            return;
+        }
+        {
+#pragma unroll
+            for (int ks = 0; ks < R_RS / 32; ++ks) {
+                bf16x8_t ind;
+                {
+                    // column n of the B fragment = indicator "row k belongs to segment n": the product then IS the per-segment column sum.
+                    // Almost every 32-row block lies inside ONE segment (levels are hundreds of rows): decided on the scalar unit, the
+                    // fragment is then all-ones in the column of that segment.  A block that straddles a segment or image boundary
+                    // takes the per-row form: this lane holds k = 8 b4 .. 8 b4 + 7 of the block for column n = r16.
+                    const int qa = __builtin_amdgcn_readfirstlane(pos0) + ks * 32;       // (uniform, and SAID so: a branch hipcc takes for divergent runs both sides under exec masks) position of the block's first row inside its period
+                    int sa = 0, sb = 0;
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) {
+                        sa += (qa >= sst[t]) ? 1 : 0;
+                        sb += (qa + 31 >= sst[t]) ? 1 : 0;
+                    }
+                    if (__builtin_amdgcn_readfirstlane((qa + 31 < s_per && sa == sb) ? 1 : 0)) {
+                        const uint32_t w1 = (sa == r16) ? 0x3f803f80u : 0u;
+                        const uint4 o = make_uint4(w1, w1, w1, w1);
+                        ind = __builtin_bit_cast(bf16x8_t, o);
+                    } else {
+                        int q0 = qa + 8 * b4;
+                        if (q0 >= s_per) q0 -= s_per;
+                        uint32_t w[4];
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            uint32_t pk = 0u;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                int q = q0 + e2 * 2 + h;
+                                if (q >= s_per) q -= s_per;
+                                int sgm = 0;
+#pragma unroll
+                                for (int t = 1; t < 8; ++t) sgm += (q >= sst[t]) ? 1 : 0;
+                                pk |= (sgm == r16 ? 0x3f80u : 0u) << (16 * h);
+                            }
+                            w[e2] = pk;
+                        }
+                        const uint4 o = make_uint4(w[0], w[1], w[2], w[3]);
+                        ind = __builtin_bit_cast(bf16x8_t, o);
+                    }
+                }
+                indk[ks] = ind;
+            }
+        }
+    };
     int slot = 0;
+    int pos0 = p.seg_n > 0 ? (int)(((int64_t)s_lo * R_RS) % p.seg_period) : 0;      // position of the stage's first row inside its period (uniform)
+    if (do_sum && s_n > 0) locate(pos0);
+    make_ind(pos0);
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
         __builtin_amdgcn_s_barrier();                                   // stage s has landed
@@ -195,19 +283,34 @@ __global__ __launch_bounds__(R_NT, 3) void gemm_dwr_kernel(const DwrP p) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[jj], acc[i][jj], 0, 0, 0);
             if (do_sum) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], ones, accs[i], 0, 0, 0);
+                const bf16x8_t ind = indk[ks];
+                if (wn == 0) {
+                    accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[0], ind, accs[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[1], ind, accs[1], 0, 0, 0);
+                } else {
+                    accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2], ind, accs[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[3], ind, accs[1], 0, 0, 0);
+                }
             }
         }
         asm volatile("" ::: "memory");
+        pos0 += R_RS;
+        if (do_sum && s_n > 0) {
+            const bool wrap = pos0 >= s_per;
+            if (wrap) pos0 -= s_per;
+            if (wrap || pos0 >= nxt) locate(pos0);
+        }
+        make_ind(pos0);                 // the NEXT stage's fragments, formed behind this stage's MFMAs (issued, still executing)
     }
 
     // ---- bias gradient: every column of accs[i] is the row sum; lanes r16 == 0 hold rows 4 b4 + t of fragment i.  Partials go to
     // the workspace like the tiles (128 row ranges adding into 256 addresses with memory-side atomics cost 16 us at 256 x 256) ----
-    if (do_sum && r16 == 0) {
-        float* bp = p.wsb + (int64_t)split * p.n1 + n1_0 + wm * 64 + b4 * 4;
+    // (per-segment sums: column r16 < seg_n of accs[i] is segment r16's sum)
+    const int nsum = p.seg_n > 0 ? p.seg_n : 1;
+    if (do_sum && r16 < nsum) {
+        float* bp = p.wsb + ((int64_t)split * nsum + r16) * p.n1 + n1_0 + wm * 64 + wn * 32 + b4 * 4;       // fragments 2 wn, 2 wn + 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(bp + i * 16) = accs[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4_t*>(bp + i * 16) = accs[i];
     }
     // ---- partial tile: plain, fully coalesced stores of the register image (wave, fragment, t, lane) ----
     float* wp = p.ws + ((int64_t)split * p.ntiles + tile) * R_TILE_F + wave * 4096 + lane;
@@ -236,17 +339,22 @@ __global__ __launch_bounds__(256) void dwr_reduce_kernel(const DwrP p) {
     const int n1_0 = (tile / p.tiles_n2) * R_TY, n2_0 = (tile % p.tiles_n2) * R_TX;
     float* c = p.C + (int64_t)(n1_0 + wm * 64 + i * 16 + b4 * 4 + t) * p.ldc + n2_0 + wn * 64 + jj * 16 + r16;
     *c += (s0 + s1) + (s2 + s3);
-    if (p.wsb && blockIdx.x < 8 && n2_0 == 0) {                         // db[n1_0 .. n1_0 + 256) += sum over row ranges (fixed order):
-        // 8 blocks x 32 entries, 8 lanes per entry take every 8th row range (independent loads), folded with three DPP steps
-        const int ent = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
-        const float* bp = p.wsb + n1_0 + ent;
+    const int nsum = p.seg_n > 0 ? p.seg_n : 1;
+    if (p.wsb && (int)blockIdx.x < 8 * nsum && n2_0 == 0) {             // column sums of dY over the row ranges (fixed order):
+        // per segment 8 blocks x 32 entries, 8 lanes per entry take every 8th row range (independent loads), folded with three shuffle steps
+        const int sg = blockIdx.x >> 3, ent = (blockIdx.x & 7) * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+        const float* bp = p.wsb + (int64_t)sg * p.n1 + n1_0 + ent;
+        const int64_t st = (int64_t)nsum * p.n1;
         float b0 = 0.f, b1 = 0.f;
         int q = part;
-        for (; q + 8 < p.splits; q += 16) { b0 += bp[(int64_t)q * p.n1]; b1 += bp[(int64_t)(q + 8) * p.n1]; }
-        if (q < p.splits) b0 += bp[(int64_t)q * p.n1];
+        for (; q + 8 < p.splits; q += 16) { b0 += bp[(int64_t)q * st]; b1 += bp[(int64_t)(q + 8) * st]; }
+        if (q < p.splits) b0 += bp[(int64_t)q * st];
         float b = b0 + b1;
         b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4);
-        if (part == 0) p.ysum[n1_0 + ent] += b;
+        if (part == 0) {
+            if (p.seg_n > 0) p.seg_out[(int64_t)sg * p.ld_seg + n1_0 + ent] += b;
+            else p.ysum[n1_0 + ent] += b;
+        }
     }
 }
 
@@ -290,11 +398,15 @@ bool gemm_dwr_try(const GemmK& g, hipStream_t st) {
     p.splits = per * 8;
     const int nst = (p.rows + R_RS - 1) / R_RS;
     if (p.splits > nst) p.splits = nst;
+    p.seg_out = d.seg_sums; p.ld_seg = d.ld_seg; p.seg_n = d.seg_sums ? d.seg_n : 0; p.seg_period = d.seg_sums ? d.seg_period : 1;
+    for (int i = 0; i < 9; ++i) p.seg_start[i] = d.seg_sums ? d.seg_start[i] : 0;
+    const int nsum = p.seg_n > 0 ? p.seg_n : 1;
+    const bool sums = p.ysum != nullptr || p.seg_n > 0;
     const int64_t tile_bytes = (int64_t)p.splits * p.ntiles * R_TILE_F * 4;
-    const int64_t need = tile_bytes + (p.ysum ? (int64_t)p.splits * p.n1 * 4 : 0);
+    const int64_t need = tile_bytes + (sums ? (int64_t)p.splits * nsum * p.n1 * 4 : 0);
     if (!d.workspace || d.workspace_bytes < need || (reinterpret_cast<uintptr_t>(d.workspace) & 15)) return false;
     p.ws = reinterpret_cast<float*>(d.workspace);
-    p.wsb = p.ysum ? p.ws + tile_bytes / 4 : nullptr;
+    p.wsb = sums ? p.ws + tile_bytes / 4 : nullptr;
     const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
     static bool attr_set = false;
     if (!attr_set) {

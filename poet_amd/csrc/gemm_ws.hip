@@ -319,10 +319,6 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
 
     int u = u_lo;
     const int u_full = min(u_hi, d.M >> 4);                             // units below u_full are wholly inside [0, M)
-    if (p.stagger > 0 && (wid & (NWV / 2))) {
-#pragma unroll 1
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     for (; u + FM <= u_full; u += FM) iteration(u, std::false_type{});
     if (u < u_hi) iteration(u, std::true_type{});
 }

@@ -1420,3 +1420,37 @@ def test_groupnorm_whole_row_kernels(ops, xdt, ydt, HW, monkeypatch):
     _close(dx, xr.grad.permute(0, 2, 1), xdt, msg="gn rows dx")
     _close(dg, g32.grad, ydt, scale=math.sqrt(N * HW), msg="gn rows dgamma")
     _close(db, b32.grad, ydt, scale=math.sqrt(N * HW), msg="gn rows dbeta")
+
+
+@pytest.mark.parametrize("n_img,shapes,n_out,k_in", [(16, [(60, 80), (30, 40), (15, 20), (8, 10)], 768, 256),      # the encoder's d(offsets | logits) at 640x480, bs 16
+                                                      (3, [(60, 80), (30, 40), (15, 20), (8, 10)], 768, 256),       # row ranges that straddle images and levels
+                                                      (8, [(30, 40), (15, 20), (8, 10), (4, 5)], 1024, 256),        # LM-O levels (the smallest has 20 rows: many segments inside one 64-row stage)
+                                                      (2, [(120, 160), (60, 80), (30, 40), (15, 20)], 256, 256),    # a shape the DMA ring declines: separate column-sum launch
+                                                      (1, [(60, 80), (30, 40), (15, 20), (8, 10)], 768, 256),       # 6380 rows (bs 1): below the ring's row count
+                                                      (1, [(12, 16), (6, 8), (3, 4)], 192, 64)])                    # 264 rows: the small-GEMM path
+def test_gemm_dw_segment_sums(ops, n_img, shapes, n_out, k_in):
+    """PoetGemmDesc.seg_sums (ABI v4): per-LEVEL column sums of dY out of the weight-gradient kernel's own pass over dY (the DMA-ring
+    kernel multiplies its dY fragments with a level-indicator fragment: deformable_transformer.py:139-141 makes d(level_embed) the sum
+    over a level's rows) == the column-sum kernel; the weight gradient itself is unchanged."""
+    geom = ops.LevelGeom(shapes)
+    S, L = geom.S, len(shapes)
+    rows = n_img * S
+    # dY is a column block of a wider buffer (the encoder writes d(offsets | logits) next to d(value) rows: row stride 3 M L P + d)
+    wide = _rand(rows, n_out + 256, seed=610).to(torch.bfloat16)
+    dy = wide[:, :n_out]
+    x = _rand(rows, k_in, seed=611).to(torch.bfloat16)
+    dyd, xd = dev(wide)[:, :n_out], dev(x)
+    ldy = n_out + 256
+    dw_a, dw_b = torch.zeros(n_out, k_in, device="cuda"), torch.zeros(n_out, k_in, device="cuda")
+    seg_a = torch.full((L, n_out), 0.5, device="cuda")                          # (accumulates: starts from a non-zero value)
+    seg_b = torch.full((L, n_out), 0.5, device="cuda")
+    ops.linear_dw(dyd, xd, dw_a, rows=rows, ldy=ldy, seg=(seg_a, geom.c_segs, S))
+    ops.linear_dw(dyd, xd, dw_b, rows=rows, ldy=ldy)
+    ops.colsum(dyd, ldy, seg_b, n_img, S, n_out, geom.c_segs, L)
+    torch.cuda.synchronize()
+    assert torch.equal(dw_a, dw_b)
+    starts = [int(v) for v in geom.c_segs]
+    ref = torch.stack([dy.float().view(n_img, S, n_out)[:, starts[l]:starts[l + 1]].double().sum((0, 1)) for l in range(L)]) + 0.5
+    scale = ref.abs().max().item()
+    assert (seg_a.double().cpu() - ref).abs().max().item() < 2e-5 * scale + 1e-3
+    assert (seg_a - seg_b).abs().max().item() < 2e-5 * scale + 1e-3
