@@ -24,6 +24,8 @@
  *       every nn.Linear / 1x1 nn.Conv2d on the path (deformable_transformer.py:182,185,258,261,
  *       the 4 Linears of MSDeformAttn, nn.MultiheadAttention's in/out projections :253,
  *       pose_estimation_transformer.py:106-122,684-688) and their backward contractions.
+ *   poet_linear_bwd
+ *       dW, db and dX of the encoder's 256-wide-output Linears in one pass (deformable_transformer.py:193-197,202-203, backward).
  *   poet_ln_fwd / poet_ln_bwd
  *       `x = norm(x + dropout(y))`  (deformable_transformer.py:202-203,195-196,279-287,271-272).
  *   poet_mha_fwd / poet_mha_bwd
@@ -140,6 +142,16 @@ typedef struct PoetGemmDesc {
     int32_t seg_start[10]; /* seg_n + 1 entries used */
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
+/* Backward of y = x W^T + b for a Linear with a 256-wide OUTPUT, all three results in one pass over dy and x (ABI v4, gemm_dwr.hip):
+ *   dw[256][n2] += dy^T x,   db[256] += column sums of dy (db may be NULL),   dx[rows][n2] = (dy w) [x (x > 0 ? gate_scale : 0) if gate].
+ * Reference: autograd of nn.Linear at models/deformable_transformer.py:193-197 (FFN linear2; gate = 1: x is the hidden activation after
+ * ReLU + dropout, its zeros ARE the gate of :196 / :194) and :202-203 (MSDeformAttn.output_proj; gate = 0).  dy bf16 [rows][256] (row
+ * stride ldy), x bf16 [rows][n2], w bf16 [256][n2] (the weight as stored, [out][in]), dw fp32 (accumulated), dx bf16 (written).
+ * rows >= 8192, n2 a multiple of 128, 16-byte aligned operands; `workspace` (caller-owned, like PoetGemmDesc.workspace) takes the
+ * partial tiles.  POET_ERR_UNSUPPORTED outside that range: issue the two poet_gemm calls instead. */
+int poet_linear_bwd(const void* dy, int64_t ldy, const void* x, int64_t ldx, const void* w, int64_t ldw, float* dw, int64_t lddw,
+                    float* db, void* dx, int64_t lddx, int gate, float gate_scale, int64_t rows, int n2, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 /* Which kernel family the calling thread's last successful poet_gemm launched (profiling aid: lets a caller attribute a
  * launch time to the kernel symbol a rocprofv3 trace shows). */
 /* dw[i][n_out, k_in] += dy[i][rows, n_out]^T x[i][rows, k_in] and (db != NULL, db[i] != NULL) db[i][n_out] += column sums of

@@ -38,6 +38,7 @@ _PROTOS = {
     "poet_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "poet_gemm_dw_list": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, vp], i32),
     "poet_gemm_last_path": ([], i32),
+    "poet_linear_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, f32, i64, i32, vp, i64, vp], i32),
     "poet_msda_fwd": ([vp, pi64, pi64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_msda_bwd": ([vp, pi64, pi64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_msda_fused_fwd": ([vp, i64, i64, i64, pi64, pi64, vp, i64, i32, vp, i64, vp,

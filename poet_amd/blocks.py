@@ -224,9 +224,15 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
     separate = p > 0 or z.dtype != dy.dtype or ops.defer_small_dw.active is not None
     dxo = torch.empty_like(z) if separate else dz
     ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dxo if separate else None, ggamma, gbeta, rows, d, p, seed)
-    ops.linear_dw(dxo, x_in, gW, rows=rows, db=gb)
     dx_in = empty((rows, W.shape[1]), x_in.dtype, x_in)
-    ops.linear_dx(dxo, Wb(W, dxo), dx_in, rows=rows, gate_ref=gate_ref, gate_scale=gate_scale)
+    Wop = Wb(W, dxo)
+    if (gate_ref is None or gate_ref is x_in) and ops.linear_bwd_ok(dxo, x_in, Wop, gW, rows):
+        # weight, bias and input gradient of the 256-wide-output Linear in ONE pass over dxo and x_in (poet_linear_bwd): the hidden
+        # activation of the FFN is read once instead of twice (as the dW operand and as the ReLU / dropout gate)
+        ops.linear_bwd(dxo, x_in, Wop, gW, gb, dx_in, rows=rows, gate=gate_ref is not None, gate_scale=gate_scale)
+        return dz, dx_in
+    ops.linear_dw(dxo, x_in, gW, rows=rows, db=gb)
+    ops.linear_dx(dxo, Wop, dx_in, rows=rows, gate_ref=gate_ref, gate_scale=gate_scale)
     return dz, dx_in
 
 

@@ -53,6 +53,12 @@ struct DwrP {
     int64_t ld_seg;
     int seg_n, seg_period;
     int seg_start[9];
+    // fused input gradient (gemm_dwx_kernel): dX[rows][n2] = (dY W) (x gate), W bf16 [256][n2]
+    const bf16_t* Wt;
+    bf16_t* dx;
+    int64_t ldw, lddx;
+    int gate;
+    float gate_scale;
     int64_t ldy, ldx, ldc;
     int rows, n1, n2, ntiles, tiles_n2, splits;
 };
@@ -322,6 +328,235 @@ __global__ __launch_bounds__(R_NT, 3) void gemm_dwr_kernel(const DwrP p) {
             for (int t = 0; t < 4; ++t) wp[((i * 4 + jj) * 4 + t) * 64] = acc[i][jj][t];
 }
 
+// ---- the same weight gradient WITH the Linear's input gradient in the same pass --------------------------------------------------
+// Backward of y = x W^T + b for the encoder's Linears with a 256-wide output (FFN linear2: deformable_transformer.py:193-197, and
+// MSDeformAttn's output_proj :202-203): autograd runs  dW += dY^T X,  db += colsum(dY)  and  dX = dY W (x ReLU / dropout gate of the
+// hidden activation)  as two products that BOTH stream dY (rows x 256) and, for the gated form, X (rows x n2: 209 MB for the FFN's
+// hidden activation -- once as the dW operand, once as the gate).  Here the workgroup that owns the 256 x 128 tile of dW and a row
+// range holds, per 32-row stage, exactly the operands of the matching dX block as well: the dY panel (32 x 256 = the whole reduction
+// of dX) and the X panel (32 x 128 = the gate of its 128 output columns).  It keeps its 256 x 128 slab of W in LDS for its whole life
+// (64 KB, columns permuted so that a lane of the transposed product owns 8 CONSECUTIVE output columns: 16-byte stores, 64 contiguous
+// bytes per row and instruction) and writes the dX block straight from registers: the hidden activation is read ONCE, the separate
+// input-gradient launch (130 us at 102 080 x 1024) disappears, and the matrix pipe of this memory-bound kernel goes from 40 % to 80 %.
+constexpr int X_RS = 32;                          // rows per stage
+constexpr int X_NST = 4;                          // ring depth: 3 stages = 72 KB in flight
+constexpr int X_YPANEL = X_RS * R_YROWB;          // 16 KB
+constexpr int X_XPANEL = X_RS * R_XROWB;          // 8 KB
+constexpr int X_STAGE = X_YPANEL + X_XPANEL;      // 24 KB
+constexpr int X_WSLAB = R_TY * R_XROWB;           // 64 KB: W[o][128 columns of the slab]
+constexpr int X_LDS = X_NST * X_STAGE + X_WSLAB;  // 160 KB
+constexpr int X_YQ = X_YPANEL / 1024 / R_NLW;     // DMA instructions per loader wave and stage: 4 + 2
+constexpr int X_XQ = X_XPANEL / 1024 / R_NLW;
+
+__global__ __launch_bounds__(R_NT, 3) void gemm_dwx_kernel(const DwrP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    char* wslab = smem + X_NST * X_STAGE;
+
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % p.ntiles, split = (j / p.ntiles) * 8 + xcd;          // n1 = 256: one tile row, tile = the 128-column slab of n2
+    if (split >= p.splits) return;
+    const int n2_0 = tile * R_TX;
+    const int nst = (p.rows + X_RS - 1) / X_RS;
+    const int s_lo = (int)((int64_t)split * nst / p.splits), s_hi = (int)((int64_t)(split + 1) * nst / p.splits);
+    const int S = s_hi - s_lo;
+    if (S <= 0) return;
+    const int ragged = (s_hi == nst && (p.rows % X_RS) != 0) ? (p.rows - (nst - 1) * X_RS) : 0;
+
+    if (wave >= R_NCW) {
+        // ====== loader waves ======
+        constexpr int PD = X_NST - 1, NPL = X_YQ + X_XQ, LW = NPL * (PD - 1);
+        const int lw = wave - R_NCW;
+        const int ldyB = (int)p.ldy * 2, ldxB = (int)p.ldx * 2;
+        int y_row[X_YQ], y_col[X_YQ], x_row[X_XQ], x_col[X_XQ];
+#pragma unroll
+        for (int q = 0; q < X_YQ; ++q) {
+            const int pos = ((lw * X_YQ + q) * 64 + lane) * 16, row = pos / R_YROWB, c = (pos % R_YROWB) >> 4, pc = c >> 1;
+            y_row[q] = row;
+            y_col[q] = ((((pc & 8) | ((pc ^ r_swz(row)) & 7)) << 1) | (c & 1)) * 16;
+        }
+#pragma unroll
+        for (int q = 0; q < X_XQ; ++q) {
+            const int pos = ((lw * X_XQ + q) * 64 + lane) * 16, row = pos / R_XROWB, c = (pos % R_XROWB) >> 4, pc = c >> 1;
+            x_row[q] = row;
+            x_col[q] = ((((pc ^ r_swz(row)) & 7) << 1) | (c & 1)) * 16;
+        }
+        const char* Yb = reinterpret_cast<const char*>(p.Y);
+        const char* Xb = reinterpret_cast<const char*>(p.X + n2_0);
+        int l_s = s_lo, l_slot = 0;
+        auto issue = [&]() {
+            const int r0 = l_s * X_RS;
+            const int rv = min(X_RS, p.rows - r0);
+            const char* yb = Yb + (int64_t)r0 * ldyB;
+            const char* xb = Xb + (int64_t)r0 * ldxB;
+            const uint32_t slot = lds0 + l_slot * X_STAGE;
+#pragma unroll
+            for (int q = 0; q < X_YQ; ++q)
+                r_dma16((uint32_t)(min(y_row[q], rv - 1) * ldyB + y_col[q]), yb, slot + (lw * X_YQ + q) * 1024);
+#pragma unroll
+            for (int q = 0; q < X_XQ; ++q)
+                r_dma16((uint32_t)(min(x_row[q], rv - 1) * ldxB + x_col[q]), xb, slot + X_YPANEL + (lw * X_XQ + q) * 1024);
+            ++l_s;
+            l_slot = (l_slot + 1 == X_NST) ? 0 : l_slot + 1;
+        };
+#pragma unroll 1
+        for (int i = 0; i < min(PD, S); ++i) issue();
+        __builtin_amdgcn_s_barrier();                                   // (the compute waves have staged the W slab)
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            if (min(S, s + PD) - (s + 1) < PD - 1) r_wait_vm<0>(); else r_wait_vm<LW>();
+            __builtin_amdgcn_s_barrier();
+            if (ragged && s == S - 1) __builtin_amdgcn_s_barrier();
+            if (l_s < s_hi) issue();
+        }
+        return;
+    }
+
+    // =========================== compute waves ===========================
+    // ---- the W slab: W[o][n2_0 + h] -> image [o][ic], ic = column permutation inside every 32-column group: h = 8 g + 4 tl + t
+    // (g < 4, tl < 2, t < 4) sits at ic = 16 tl + 4 g + t, so that the two 16-column fragments tl = 0, 1 of a group give a lane
+    // (MFMA rows 4 g + t) the 8 consecutive output columns 8 g .. 8 g + 7; 32-byte pieces XOR-swizzled by the row like the panels ----
+    {
+        const bf16_t* Wg = p.Wt + n2_0;
+        for (int it = tid; it < R_TY * (R_TX / 8); it += R_NCW * 64) {     // item: 8 consecutive h of one row o
+            const int o = it >> 4, h0 = (it & 15) * 8, g32 = h0 >> 5, g = (h0 >> 3) & 3;
+            const uint4 v = *reinterpret_cast<const uint4*>(Wg + (int64_t)o * p.ldw + h0);
+            const int sw = r_swz(o);
+            const int ic0 = g32 * 32 + 4 * g, ic1 = ic0 + 16;                 // tl = 0: h0 .. h0 + 3;  tl = 1: h0 + 4 .. h0 + 7
+            *reinterpret_cast<uint2*>(wslab + o * R_XROWB + ((((ic0 >> 4) ^ sw) & 7) << 5) + (ic0 & 15) * 2) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(wslab + o * R_XROWB + ((((ic1 >> 4) ^ sw) & 7) << 5) + (ic1 & 15) * 2) = make_uint2(v.z, v.w);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_sum = p.wsb != nullptr && n2_0 == 0;
+    f32x4_t accs[2];
+    accs[0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accs[1] = accs[0];
+    bf16x8_t ones;
+    {
+        const uint4 o = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        ones = __builtin_bit_cast(bf16x8_t, o);
+    }
+    const int r16 = lane & 15, b4 = lane >> 4;
+    const int trow = 8 * b4 + (r16 >> 2), tswz = (r16 >> 2) | ((b4 & 1) << 2), tcol = (r16 & 3) * 8;
+    int ty[4], tx[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int py = wm * 4 + f, px = wn * 4 + f;
+        ty[f] = trow * R_YROWB + (((py & 8) | ((py ^ tswz) & 7)) << 5) + tcol;
+        tx[f] = X_YPANEL + trow * R_XROWB + (((px ^ tswz) & 7) << 5) + tcol;
+    }
+    // dX part: this wave computes rows ru * 16 .. + 15 of the stage x the 32-column group cg of the slab (two 16-column fragments)
+    const int ru = wave & 1, cg = wave >> 1;
+    const int drow = ru * 16 + r16, dsw = r_swz(drow);                  // this lane's dY row as the B operand (row r16 of the unit)
+    int wx[2];                                                          // W fragment tl: image piece 2 cg + tl
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) wx[tl] = trow * R_XROWB + ((((cg * 2 + tl) ^ tswz) & 7) << 5) + tcol;
+    // gate: hidden[row][8 b4 .. 8 b4 + 7 of group cg]: 16-byte chunk 4 cg + b4 of the X panel row
+    const int gate_off = X_YPANEL + drow * R_XROWB + ((((cg * 2 + (b4 >> 1)) ^ dsw) & 7) << 5) + (b4 & 1) * 16;
+    const int out_col = n2_0 + cg * 32 + b4 * 8;
+
+    int slot = 0;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        __builtin_amdgcn_s_barrier();                                   // stage s has landed
+        asm volatile("" ::: "memory");
+        char* sb = smem + slot * X_STAGE;
+        slot = (slot + 1 == X_NST) ? 0 : slot + 1;
+        if (ragged && s == S - 1) {
+            for (int i = tid; i < (X_RS - ragged) * (R_YROWB / 16); i += R_NCW * 64)
+                *reinterpret_cast<uint4*>(sb + ragged * R_YROWB + i * 16) = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < (X_RS - ragged) * (R_XROWB / 16); i += R_NCW * 64)
+                *reinterpret_cast<uint4*>(sb + X_YPANEL + ragged * R_XROWB + i * 16) = make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // ---- weight gradient: one 32-row block ----
+        {
+            bf16x8_t fy[4], fx[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                struct { v4s_t lo, hi; } u, v;
+                u.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + ty[f]));
+                u.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + ty[f] + 4 * R_YROWB));
+                v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + tx[f]));
+                v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sb + tx[f] + 4 * R_XROWB));
+                fy[f] = __builtin_bit_cast(bf16x8_t, u);
+                fx[f] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[jj], acc[i][jj], 0, 0, 0);
+            if (do_sum) {
+                if (wn == 0) {
+                    accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[0], ones, accs[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[1], ones, accs[1], 0, 0, 0);
+                } else {
+                    accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[2], ones, accs[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[3], ones, accs[1], 0, 0, 0);
+                }
+            }
+        }
+        // ---- input gradient block: D'[h][r] = sum_o W[o][h] dY[r][o], transposed product, 8 k-steps of 32 ----
+        f32x4_t dacc[2];
+        dacc[0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dacc[1] = dacc[0];
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq) {
+            const int pc = kq * 2 + (b4 >> 1);                          // 32-byte piece of the dY row holding o = 32 kq + 8 b4 .. + 7
+            const bf16x8_t dyf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(
+                sb + drow * R_YROWB + (((pc & 8) | ((pc ^ dsw) & 7)) << 5) + (b4 & 1) * 16));
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                struct { v4s_t lo, hi; } w;
+                w.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(wslab + wx[tl] + kq * 32 * R_XROWB));
+                w.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(wslab + wx[tl] + (kq * 32 + 4) * R_XROWB));
+                dacc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), dyf, dacc[tl], 0, 0, 0);
+            }
+        }
+        {
+            float v[8] = {dacc[0][0], dacc[0][1], dacc[0][2], dacc[0][3], dacc[1][0], dacc[1][1], dacc[1][2], dacc[1][3]};
+            if (p.gate) {
+                const uint4 hq = *reinterpret_cast<const uint4*>(sb + gate_off);
+                const uint32_t hw[4] = {hq.x, hq.y, hq.z, hq.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = __uint_as_float(hw[e] << 16) > 0.f ? v[2 * e] * p.gate_scale : 0.f;
+                    v[2 * e + 1] = __uint_as_float(hw[e] & 0xffff0000u) > 0.f ? v[2 * e + 1] * p.gate_scale : 0.f;
+                }
+            }
+            const int64_t grow = (int64_t)(s_lo + s) * X_RS + drow;
+            if (grow < p.rows)
+                *reinterpret_cast<uint4*>(p.dx + grow * p.lddx + out_col) =
+                    make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+        }
+        asm volatile("" ::: "memory");
+    }
+
+    if (do_sum && r16 == 0) {
+        float* bp = p.wsb + (int64_t)split * p.n1 + wm * 64 + wn * 32 + b4 * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4_t*>(bp + i * 16) = accs[i];
+    }
+    float* wp = p.ws + ((int64_t)split * p.ntiles + tile) * R_TILE_F + wave * 4096 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wp[((i * 4 + jj) * 4 + t) * 64] = acc[i][jj][t];
+}
+
 // dW[tile] += sum over row ranges of the partial tiles (single owner per element: a plain read-modify-write, fixed order)
 __global__ __launch_bounds__(256) void dwr_reduce_kernel(const DwrP p) {
     const int tile = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;               // e: index inside the 256 x 128 register image
@@ -419,3 +654,56 @@ bool gemm_dwr_try(const GemmK& g, hipStream_t st) {
 }
 
 }  // namespace poet
+
+using namespace poet;
+
+// dW += dY^T X,  db += colsum(dY),  dX = (dY W) [x (X > 0 ? gate_scale : 0)]  in ONE pass (gemm_dwx_kernel above): the backward of the
+// encoder's Linears with a 256-wide output -- FFN linear2 (deformable_transformer.py:193-197; gate = 1: X is the hidden activation after
+// ReLU and dropout, its zeros are the gate) and MSDeformAttn's output_proj (:202-203; gate = 0).  dy bf16 [rows][256], x bf16
+// [rows][n2], w bf16 [256][n2] (the Linear's weight, [out][in]), dw fp32 [256][n2] (accumulated), db fp32 [256] or NULL (accumulated),
+// dx bf16 [rows][n2] (written).  rows >= 8192, n2 a multiple of 128; the workspace takes the partial tiles.  POET_ERR_UNSUPPORTED
+// outside that: callers then issue the two poet_gemm calls.
+extern "C" int poet_linear_bwd(const void* dy, int64_t ldy, const void* x, int64_t ldx, const void* w, int64_t ldw, float* dw, int64_t lddw,
+                               float* db, void* dx, int64_t lddx, int gate, float gate_scale, int64_t rows, int n2, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    POET_CHECK(dy && x && w && dw && dx, POET_ERR_ARG, "linear_bwd: null pointer");
+    POET_CHECK(rows >= 8192 && rows < (1ll << 24) && n2 >= 128 && n2 % R_TX == 0 && n2 <= 4096, POET_ERR_UNSUPPORTED,
+               "linear_bwd: rows=%lld n2=%d outside the fused kernel's range (rows >= 8192, n2 a multiple of 128)", (long long)rows, n2);
+    POET_CHECK(((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dx) |
+                 reinterpret_cast<uintptr_t>(workspace)) & 15) == 0 && (ldy & 7) == 0 && (ldx & 7) == 0 && (ldw & 7) == 0 && (lddx & 7) == 0 &&
+               ldy >= R_TY && ldx >= n2 && ldw >= n2 && lddx >= n2 && lddw >= n2, POET_ERR_ARG, "linear_bwd: 16-byte aligned operands, row strides multiples of 8");
+    POET_CHECK((int64_t)X_RS * ldy * 2 < (1ll << 31) && (int64_t)X_RS * ldx * 2 < (1ll << 31), POET_ERR_UNSUPPORTED, "linear_bwd: 32-bit lane offsets");
+    DwrP p{};
+    p.Y = reinterpret_cast<const bf16_t*>(dy);
+    p.X = reinterpret_cast<const bf16_t*>(x);
+    p.Wt = reinterpret_cast<const bf16_t*>(w);
+    p.dx = reinterpret_cast<bf16_t*>(dx);
+    p.C = dw; p.ysum = db;
+    p.ldy = ldy; p.ldx = ldx; p.ldc = lddw; p.ldw = ldw; p.lddx = lddx;
+    p.rows = (int)rows; p.n1 = R_TY; p.n2 = n2;
+    p.tiles_n2 = n2 / R_TX; p.ntiles = p.tiles_n2;
+    p.gate = gate ? 1 : 0; p.gate_scale = gate_scale;
+    p.seg_n = 0; p.seg_period = 1;
+    const int cus = dwr_cus();
+    int per = cus / 8 / p.ntiles;
+    if (per < 1) per = 1;
+    p.splits = per * 8;
+    const int nst = (p.rows + X_RS - 1) / X_RS;
+    if (p.splits > nst) p.splits = nst;
+    const int64_t tile_bytes = (int64_t)p.splits * p.ntiles * R_TILE_F * 4;
+    const int64_t need = tile_bytes + (db ? (int64_t)p.splits * p.n1 * 4 : 0);
+    POET_CHECK(workspace && workspace_bytes >= need, POET_ERR_UNSUPPORTED, "linear_bwd: workspace of %lld bytes needed", (long long)need);
+    p.ws = reinterpret_cast<float*>(workspace);
+    p.wsb = db ? p.ws + tile_bytes / 4 : nullptr;
+    const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dwx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS);
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_dwx_kernel, dim3(nblocks), dim3(R_NT), X_LDS, st, p);
+    hipLaunchKernelGGL(dwr_reduce_kernel, dim3(R_TILE_F / 256, p.ntiles), dim3(256), 0, st, p);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}

@@ -290,6 +290,36 @@ def linear_dx(dy: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, rows: int
                 add_src=add_src, ld_add=(ldc or k_in), gate_ref=gate_ref, gate_scale=gate_scale)
 
 
+def linear_bwd_ok(dy, x, W16, dW, rows) -> bool:
+    """Shapes poet_linear_bwd takes: a 256-wide output, bf16 operands, >= 8192 rows, n2 % 128 == 0 (POET_NO_LINEAR_BWD=1: off, A/B aid)."""
+    if _NO_LINEAR_BWD:
+        return False
+    n2 = x.shape[1]
+    return (dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and W16 is not None and W16.dtype == torch.bfloat16
+            and dy.shape[1] == 256 and tuple(W16.shape) == (256, n2) and tuple(dW.shape) == (256, n2) and dW.dtype == torch.float32
+            and rows >= 8192 and n2 % 128 == 0 and n2 <= 4096 and dy.stride(-1) == 1 and x.stride(-1) == 1 and W16.stride(-1) == 1 and dW.stride(-1) == 1
+            and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and W16.stride(0) % 8 == 0
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and W16.data_ptr() % 16 == 0 and defer_small_dw.active is None)
+
+
+_NO_LINEAR_BWD = os.environ.get("POET_NO_LINEAR_BWD", "0") not in ("", "0")
+
+
+def linear_bwd(dy, x, W16, dW, db, dx_out, *, rows, gate=False, gate_scale=1.0):
+    """dW += dy^T x, db += colsum(dy), dx_out = (dy W16) [gated by x > 0] in one launch pair (poet_linear_bwd)."""
+    lib = _lib.load()
+    n2 = x.shape[1]
+    ws = _workspace(dW.device)
+    if PROFILE.on:
+        e0 = PROFILE.begin()
+    _lib.check(lib.poet_linear_bwd(_req(dy, "dy").data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), W16.data_ptr(), W16.stride(0),
+                                   dW.data_ptr(), dW.stride(0), _ptr(db), dx_out.data_ptr(), dx_out.stride(0), int(bool(gate)), float(gate_scale),
+                                   rows, n2, ws.data_ptr(), _WORKSPACE_BYTES, _stream()), "poet_linear_bwd")
+    if PROFILE.on:
+        PROFILE.end(f"gemm_dwx_dW_dX_256x{n2}", e0, 4.0 * rows * 256 * n2, rows * (256 * 2 + n2 * 2 + n2 * 2))
+    return dx_out
+
+
 def _splitk_for(M, N, K):
     big = M >= 256 and N >= 128 and K >= 4096
     t = 128 if big else 64

@@ -1454,3 +1454,43 @@ def test_gemm_dw_segment_sums(ops, n_img, shapes, n_out, k_in):
     scale = ref.abs().max().item()
     assert (seg_a.double().cpu() - ref).abs().max().item() < 2e-5 * scale + 1e-3
     assert (seg_a - seg_b).abs().max().item() < 2e-5 * scale + 1e-3
+
+
+@pytest.mark.parametrize("rows,n2,gate", [(102080, 1024, True), (102080, 256, False), (8192 + 13, 1024, True), (204000, 1024, True), (9000, 128, False),
+                                          (51200, 256, True)])
+def test_linear_bwd_fused_equals_dw_plus_dx(ops, rows, n2, gate):
+    """poet_linear_bwd (gemm_dwx_kernel: the weight-gradient ring with the Linear's input gradient computed from the SAME staged
+    panels) against the two poet_gemm calls it replaces -- dW (+ db) by the weight-gradient kernels, dX by the streaming input-gradient
+    kernel with its ReLU / dropout gate -- and against fp64 on the same bf16 operands.  FFN linear2 (n2 = 1024, gated by the hidden
+    activation: deformable_transformer.py:193-197) and output_proj (n2 = 256, plain: :202-203); ragged row counts."""
+    dy = (_rand(rows, 256, seed=700) * 0.5).to(torch.bfloat16)
+    x = torch.relu(_rand(rows, n2, seed=701))
+    x = (x * (torch.from_numpy(np.random.default_rng(5).random((rows, n2)).astype(np.float32)) > 0.1)).to(torch.bfloat16)   # ReLU + dropout zeros
+    w = (_rand(256, n2, seed=702) / 16).to(torch.bfloat16)
+    dyd, xd, wd = dev(dy), dev(x), dev(w)
+    assert ops.linear_bwd_ok(dyd, xd, wd, torch.zeros(256, n2, device="cuda"), rows)
+    scale = 1.0 / 0.9
+    dw_f, db_f = torch.full((256, n2), 0.25, device="cuda"), torch.full((256,), 0.25, device="cuda")          # accumulate on top of a non-zero value
+    dx_f = torch.full((rows + 2, n2), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.linear_bwd(dyd, xd, wd, dw_f, db_f, dx_f[:rows], rows=rows, gate=gate, gate_scale=scale if gate else 1.0)
+    dw_t, db_t = torch.full((256, n2), 0.25, device="cuda"), torch.full((256,), 0.25, device="cuda")
+    dx_t = torch.empty(rows, n2, dtype=torch.bfloat16, device="cuda")
+    ops.linear_dw(dyd, xd, dw_t, rows=rows, db=db_t)
+    ops.linear_dx(dyd, wd, dx_t, rows=rows, gate_ref=xd if gate else None, gate_scale=scale if gate else 1.0)
+    torch.cuda.synchronize()
+    assert bool((dx_f[rows:] == 7.0).all())
+    # fp64 yardsticks
+    dwr = dy.double().t() @ x.double() + 0.25
+    dbr = dy.double().sum(0) + 0.25
+    sw, sb = dwr.abs().max().item(), dbr.abs().max().item()
+    assert (dw_f.double().cpu() - dwr).abs().max().item() < 2e-5 * sw + 1e-3 and (dw_t.double().cpu() - dwr).abs().max().item() < 2e-5 * sw + 1e-3
+    assert (db_f.double().cpu() - dbr).abs().max().item() < 2e-5 * sb + 1e-3
+    idx = torch.linspace(0, rows - 1, 509).long()
+    dxr = dy[idx].double() @ w.double()
+    if gate:
+        dxr = torch.where(x[idx].double() > 0, dxr * scale, torch.zeros_like(dxr))
+    sx = dxr.abs().max().item()
+    assert (dx_f[:rows].cpu()[idx].double() - dxr).abs().max().item() <= 2.0 ** -8 * sx + 1e-6          # one bf16 rounding of the result
+    assert (dx_f[:rows].float() - dx_t.float()).abs().max().item() <= 2.0 ** -7 * sx                     # two kernels, two summation orders
+    if gate:
+        assert bool(((dx_f[:rows] == 0) | (xd > 0)).all())                                               # the gate's zeros exactly
