@@ -94,7 +94,7 @@ def gemm_flops_per_image(cfg):
 # the family is not in the summary.
 # profile tag (poet_amd/ops.py) -> substring of the kernel symbols in the summaries
 _PMC_NAMES = {"gemm_pipe": "gemm_pipe_kernel", "msda_bwd_dvalue_scatter_tiled": "msda_bwd_dv_tiled_kernel", "msda_bwd_dq": "msda_bwd_shared_kernel|msda_bwd_kernel<bf16, bf16", "msda_fused_fwd": "msda_fwd_shared_kernel|msda_fwd_kernel<bf16, bf16",
-              "gemm_dw_dW": "gemm_dw_kernel", "gemm_stream_dX": "gemm_ws", "gemm_stream_fwd": "gemm_ws",
+              "gemm_dw_dW": "gemm_dwr_kernel|gemm_dw_kernel", "gemm_dwx_dW_dX": "gemm_dwx_kernel", "gemm_stream_dX": "gemm_ws", "gemm_stream_fwd": "gemm_ws",
               "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
               "gemm_small_fwd": "gemm_small_kernel<false", "gemm_small_dX": "gemm_small_kernel<true", "gemm_small_dW": "gemm_small_dw_kernel",
               "ln_fwd": "ln_fwd_kernel<float, float, bf16>|ln_fwd_kernel<bf16", "ln_bwd": "ln_bwd_kernel<bf16"}

@@ -140,6 +140,14 @@ typedef struct PoetGemmDesc {
     int64_t ld_seg;        /* row stride of seg_sums (elements) */
     int32_t seg_n, seg_period;
     int32_t seg_start[10]; /* seg_n + 1 entries used */
+    /* ABI version 4, weight-gradient form: the rows m >= m_alt of C pair with B_alt (row stride ldb_alt) instead of B -- two Linears
+       that share their gradient rows' buffer (A = [dY1 | dY2], column blocks of one row-major buffer) but not their input: the
+       encoder's stacked [sampling_offsets ; attention_weights ; value_proj] gradient, whose first two blocks pair with the query
+       src + pos and the third with src (deformable_transformer.py:199-201).  One launch of 8 tiles instead of 6 + 2 (the 2-tile
+       launch is the slow shape of this product).  NULL = off; m_alt a multiple of 256. */
+    const void* B_alt;
+    int64_t ldb_alt;
+    int32_t m_alt, reserved_alt;
 } PoetGemmDesc;
 int poet_gemm(const PoetGemmDesc* desc, void* stream);
 /* Backward of y = x W^T + b for a Linear with a 256-wide OUTPUT, all three results in one pass over dy and x (ABI v4, gemm_dwr.hip):

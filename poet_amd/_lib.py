@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("seed_dev", vp), ("b_split", C.c_int32), ("c_f16", C.c_int32), ("workspace", vp), ("workspace_bytes", i64),
         ("B_lo", vp),
         ("seg_sums", vp), ("ld_seg", i64), ("seg_n", C.c_int32), ("seg_period", C.c_int32), ("seg_start", C.c_int32 * 10),
+        ("B_alt", vp), ("ldb_alt", i64), ("m_alt", C.c_int32), ("reserved_alt", C.c_int32),
     ]
 
 

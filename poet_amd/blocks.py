@@ -27,6 +27,7 @@ def next_seed() -> int:
 
 
 _ENV_SEG_FUSE = __import__("os").environ.get("POET_NO_SEG_FUSE", "0") in ("", "0")      # (A/B aid, read at import)
+_ENV_DW_MERGE = __import__("os").environ.get("POET_NO_DW_MERGE", "0") in ("", "0")
 
 
 def empty(shape, dtype, like):
@@ -322,7 +323,6 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
             and ops.tiled_scatter_bf16())
     dV = torch.zeros(sv["V"].shape, dtype=torch.bfloat16 if gv16 else torch.float32, device=dx2.device)
     mlp = M * geom.L * npts
-    seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
     so_w = P_["self_attn.sampling_offsets.weight"]
     tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and sv["V"].dtype == torch.bfloat16 else None
     if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d or dpos is not None or (3 * mlp) % 8 != 0):
@@ -333,9 +333,32 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
         # (rows, 3 M L P + d) buffer and the two input-gradient products (K = 768 and K = 256, each a read-modify-write of the
         # fp32 stream) become one with K = 1024
         G2 = torch.empty((N * S, 3 * mlp + d), dtype=torch.bfloat16, device=dx2.device)
+    g_so_w = g("self_attn.sampling_offsets.weight")
+    if (G2 is not None and _ENV_DW_MERGE and tri.get("gw") is not None and tri["gw"].data_ptr() == g_so_w.data_ptr() and S >= 64
+            and sv["src"].dtype == torch.bfloat16 and sv["q"].dtype == torch.bfloat16):
+        # The weight gradients of the three stacked Linears [sampling_offsets ; attention_weights ; value_proj] as ONE launch: their
+        # gradient rows are the column blocks of G2 = [d(offsets | logits) | d(value) rows]; the first two pair with the query src + pos,
+        # the third with src (PoetGemmDesc.B_alt).  The per-level column sums of ALL 3 M L P + d columns ride in the same pass: bias
+        # gradients of the three Linears and d(level_embed).  8 tiles x 32 row ranges instead of 6 x 40 + (2 x 128 on the slow shape).
+        ldg = G2.stride(0)
+        ops.msda_fused_bwd(sv["V"], vstrides_of(sv["V"]), geom, sv["OA"], 3 * mlp, 2 * mlp, ref, ref_bs, d_out_m, dV, G2, N, M, D, npts, S,
+                           grid_queries=True, ld_grad=ldg)
+        ops.vgrad_to_rows(dV, vstrides(M, S, D), mask, G2[:, 3 * mlp:], N, S, M, D, ld_out=ldg)
+        segw = torch.zeros((geom.L, 3 * mlp + d), dtype=torch.float32, device=dx2.device)
+        ops.linear_dw(G2, sv["q"], tri["gw"], rows=N * S, ldy=ldg, seg=(segw, geom.c_segs, S), x_alt=(sv["src"], 3 * mlp))
+        ops.colsum(segw, ldg, g("self_attn.sampling_offsets.bias"), 1, geom.L, 2 * mlp)
+        ops.colsum(segw[:, 2 * mlp:], ldg, g("self_attn.attention_weights.bias"), 1, geom.L, mlp)
+        ops.colsum(segw[:, 3 * mlp:], ldg, g("self_attn.value_proj.bias"), 1, geom.L, d)
+        if g_level is not None:               # d(level_embed)[l] += colsum_l(dOA) @ [W_so ; W_aw]   (pos = sine + level_embed, q = src + pos)
+            aw_w = P_["self_attn.attention_weights.weight"]
+            ops.gemm(segw, so_w, g_level, geom.L, d, 2 * mlp, lda=ldg, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
+            ops.gemm(segw[:, 2 * mlp:], aw_w, g_level, geom.L, d, mlp, lda=ldg, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
+        ops.linear_dx(G2, tri["w16"], dsrc, rows=N * S, add_src=dsrc)
+        return dsrc
+    seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
     sample_bwd(d_out_m, sv["q"], sv["OA"], so_w, P_["self_attn.attention_weights.weight"],
                sv["V"], geom, ref, ref_bs, N, S, M, D, npts, dV,
-               g("self_attn.sampling_offsets.weight"), g("self_attn.sampling_offsets.bias"),
+               g_so_w, g("self_attn.sampling_offsets.bias"),
                g("self_attn.attention_weights.weight"), g("self_attn.attention_weights.bias"),
                None if G2 is not None else (dsrc if dpos is None else dpos), dpos is None, seg_sums=seg, grid_queries=True,
                dOA=None if G2 is None else G2[:, : 3 * mlp])

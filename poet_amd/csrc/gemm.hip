@@ -485,6 +485,9 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
                    d.seg_start[d.seg_n] == d.seg_period, POET_ERR_ARG, "poet_gemm: seg_sums: 1..8 segments covering a period >= 64 that divides the row count");
         for (int i = 0; i < d.seg_n; ++i) POET_CHECK(d.seg_start[i] <= d.seg_start[i + 1], POET_ERR_ARG, "poet_gemm: seg_start must ascend");
     }
+    if (d.B_alt)                                           // rows m >= m_alt of C pair with B_alt (ABI v4)
+        POET_CHECK(dw_form && d.batch == 1 && d.m_alt > 0 && d.m_alt < d.M && d.m_alt % 256 == 0 && d.ldb_alt >= d.N, POET_ERR_ARG,
+                   "poet_gemm: B_alt belongs to the weight-gradient form, batch 1, 0 < m_alt < M a multiple of 256");
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.c_f16)
         POET_CHECK(d.c_dtype == POET_BF16 && !d.add_src && !d.gate_ref && !atomic, POET_ERR_ARG,
@@ -511,6 +514,33 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     if (d.gate_scale == 0.f) d.gate_scale = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+    if (d.B_alt && !gemm_dwr_try(p, st)) {
+        // no kernel but the DMA ring pairs two inputs in one launch: (per-segment sums over ALL of A first, then) two plain products
+        if (d.seg_sums) {
+            POET_CHECK(d.ld_seg == d.M, POET_ERR_UNSUPPORTED, "poet_gemm: seg_sums with ld_seg != M needs the DMA-ring weight-gradient kernel");
+            int64_t segs[10];
+            for (int i = 0; i <= d.seg_n; ++i) segs[i] = d.seg_start[i];
+            const int rc = poet_colsum(d.A, d.lda, d.seg_sums, d.K / d.seg_period, d.seg_period, d.M, segs, d.seg_n, d.a_dtype, stream);
+            if (rc) return rc;
+        }
+        const int esz = d.a_dtype == POET_F32 ? 4 : 2;
+        PoetGemmDesc lo = *desc, hi = *desc;
+        lo.seg_sums = nullptr; hi.seg_sums = nullptr; lo.B_alt = nullptr; hi.B_alt = nullptr;
+        lo.M = d.m_alt;
+        hi.M = d.M - d.m_alt;
+        hi.A = reinterpret_cast<const char*>(d.A) + (int64_t)d.m_alt * esz;
+        hi.B = d.B_alt; hi.ldb = d.ldb_alt;
+        hi.C = reinterpret_cast<char*>(d.C) + (int64_t)d.m_alt * d.ldc * 4;
+        if (d.bias) hi.bias = d.bias + d.m_alt;
+        int rc = poet_gemm(&lo, stream);
+        if (rc) return rc;
+        return poet_gemm(&hi, stream);
+    }
+    if (d.B_alt) {
+        g_last_path = POET_GEMM_PATH_DW;
+        POET_LAUNCH_CHECK();
+        return POET_OK;
+    }
     if (d.seg_sums && gemm_dwr_try(p, st)) {                // the DMA-ring dW forms the per-segment sums in its own pass over A
         g_last_path = POET_GEMM_PATH_DW;
         POET_LAUNCH_CHECK();

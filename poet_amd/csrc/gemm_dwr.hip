@@ -53,6 +53,9 @@ struct DwrP {
     int64_t ld_seg;
     int seg_n, seg_period;
     int seg_start[9];
+    const bf16_t* X_alt;  // tiles with n1_0 >= m_alt pair with X_alt (PoetGemmDesc.B_alt); nullptr: off
+    int64_t ldx_alt;
+    int m_alt;
     // fused input gradient (gemm_dwx_kernel): dX[rows][n2] = (dY W) (x gate), W bf16 [256][n2]
     const bf16_t* Wt;
     bf16_t* dx;
@@ -95,7 +98,8 @@ __global__ __launch_bounds__(R_NT, 3) void gemm_dwr_kernel(const DwrP p) {
         // ====== loader waves: the two panels of every stage by LDS-DMA, R_NST - 1 stages ahead ======
         constexpr int PD = R_NST - 1, NPL = R_YQ + R_XQ, LW = NPL * (PD - 1);
         const int lw = wave - R_NCW;
-        const int ldyB = (int)p.ldy * 2, ldxB = (int)p.ldx * 2;
+        const bool alt = p.X_alt != nullptr && n1_0 >= p.m_alt;          // (uniform) this tile's rows of dW pair with the second input
+        const int ldyB = (int)p.ldy * 2, ldxB = (int)(alt ? p.ldx_alt : p.ldx) * 2;
         // instruction q of this wave covers 1 KB of a panel image: dY 2 rows x 512 B, X 4 rows x 256 B; lane -> (row, 16-byte chunk)
         // of the IMAGE, whose content is the source chunk with its 32-byte piece un-swizzled
         int y_row[R_YQ], y_col[R_YQ], x_row[R_XQ], x_col[R_XQ];
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(R_NT, 3) void gemm_dwr_kernel(const DwrP p) {
             x_col[q] = ((((pc ^ r_swz(row)) & 7) << 1) | (c & 1)) * 16;
         }
         const char* Yb = reinterpret_cast<const char*>(p.Y + n1_0);
-        const char* Xb = reinterpret_cast<const char*>(p.X + n2_0);
+        const char* Xb = reinterpret_cast<const char*>((alt ? p.X_alt : p.X) + n2_0);
         int l_s = s_lo, l_slot = 0;
         auto issue = [&]() {
             const int r0 = l_s * R_RS;
@@ -615,6 +619,7 @@ bool gemm_dwr_try(const GemmK& g, hipStream_t st) {
     if (d.M % R_TY != 0 || d.N % R_TX != 0 || d.K < 8192 || d.alpha != 1.f) return false;
     if (!g.a_vec || !g.b_vec) return false;
     if ((int64_t)R_RS * d.lda * 2 >= (1LL << 31) || (int64_t)R_RS * d.ldb * 2 >= (1LL << 31)) return false;   // 32-bit lane offsets inside a stage
+    if (d.B_alt && ((int64_t)R_RS * d.ldb_alt * 2 >= (1LL << 31) || (reinterpret_cast<uintptr_t>(d.B_alt) & 15) || (d.ldb_alt & 7) || d.m_alt % R_TY != 0)) return false;
     if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B)) & 15) return false;
     if ((d.lda & 7) || (d.ldb & 7)) return false;
     DwrP p;
@@ -633,6 +638,7 @@ bool gemm_dwr_try(const GemmK& g, hipStream_t st) {
     p.splits = per * 8;
     const int nst = (p.rows + R_RS - 1) / R_RS;
     if (p.splits > nst) p.splits = nst;
+    p.X_alt = reinterpret_cast<const bf16_t*>(d.B_alt); p.ldx_alt = d.ldb_alt; p.m_alt = d.m_alt;
     p.seg_out = d.seg_sums; p.ld_seg = d.ld_seg; p.seg_n = d.seg_sums ? d.seg_n : 0; p.seg_period = d.seg_sums ? d.seg_period : 1;
     for (int i = 0; i < 9; ++i) p.seg_start[i] = d.seg_sums ? d.seg_start[i] : 0;
     const int nsum = p.seg_n > 0 ? p.seg_n : 1;

@@ -208,7 +208,8 @@ class ParamArena:
             vp = pos.get(pre + "value_proj.weight")
             if vp is not None and vp[1] == o + rows * d and vp[0].shape[1] == d:       # [W_so ; W_aw ; W_v]: bf16 operand of the merged dX
                 r3 = rows + vp[0].shape[0]
-                w._triple = dict(w16=self.flat_bf16[o:o + r3 * d].view(r3, d), w=self.flat[o:o + r3 * d].view(r3, d), n_oa=rows)
+                w._triple = dict(w16=self.flat_bf16[o:o + r3 * d].view(r3, d), w=self.flat[o:o + r3 * d].view(r3, d), n_oa=rows,
+                                 gw=self.grad[o:o + r3 * d].view(r3, d))          # (the stacked GRADIENT: one weight-gradient launch for all three)
 
     def _link_value_stack(self, vstack):
         """Hang the stacked views of the decoder layers' value projections on layer 0's weight (`_vstack`: fp32 / bf16 /

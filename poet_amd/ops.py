@@ -16,8 +16,8 @@ import struct as _struct
 F16 = 2                                        # POET_F16: IEEE half STORAGE of the offsets | logits buffer (include/poet_hip.h)
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 # PoetGemmDesc as one packed record (natural C layout of include/poet_hip.h; checked against ctypes below)
-_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i Q q Q Q q 2i 10i")     # native alignment inserts the same padding as the C compiler
-assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 40 + 64 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
+_GEMM_PACK = _struct.Struct("@8Q 3i 4q 2i 4i i 4q 3i 3f I 4i Q 2i Q q Q Q q 2i 10i Q q 2i")     # native alignment inserts the same padding as the C compiler
+assert _GEMM_PACK.size == C.sizeof(GemmDesc) and GemmDesc.seed_dev.offset + 40 + 64 + 24 == _GEMM_PACK.size, "PoetGemmDesc layout drift"
 
 # Device word mixed into every dropout seed (and the Adam step) at run time.  None in eager mode; engine.GraphedTrainer
 # sets it so captured hipGraphs draw fresh masks on each replay.
@@ -220,9 +220,9 @@ class LevelGeom:
 def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
          a_kmajor=False, b_kmajor=False, bias=None, act=0, add_src=None, ld_add=0, gate_ref=None, gate_scale=1.0,
          row_mask=None, drop_p=0.0, seed=0, compute=None, batch=1, strideA=0, strideB=0, strideC=0, stride_bias=0,
-         splitk=1, atomic=False, alpha=1.0, head_major=None, b_split=False, B_lo=None, seg=None):
+         splitk=1, atomic=False, alpha=1.0, head_major=None, b_split=False, B_lo=None, seg=None, b_alt=None):
     """seg = (seg_sums fp32 [n_seg, >= M], starts (n_seg + 1 ints), period): per-segment column sums of A out of the weight-gradient
-    form's own pass (PoetGemmDesc.seg_sums)."""
+    form's own pass (PoetGemmDesc.seg_sums).  b_alt = (B_alt, ldb_alt, m_alt): rows m >= m_alt of C pair with B_alt (PoetGemmDesc.B_alt)."""
     lib = _lib.load()
     if not (A.is_cuda and B.is_cuda and Cout.is_cuda):
         raise _lib.PoetHipError("poet_amd: GEMM operands must live on the GPU (no CPU path exists)")
@@ -249,7 +249,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
                          (_seed_dev() or 0) if drop_p > 0 else 0, int(b_split), c_f16, ws, _WORKSPACE_BYTES if ws else 0,
                          0 if B_lo is None else B_lo.data_ptr(),
                          *((0, 0, 0, 0) + (0,) * 10 if seg is None else
-                           (seg[0].data_ptr(), seg[0].stride(0), len(seg[1]) - 1, int(seg[2])) + tuple(int(v) for v in seg[1]) + (0,) * (10 - len(seg[1]))))
+                           (seg[0].data_ptr(), seg[0].stride(0), len(seg[1]) - 1, int(seg[2])) + tuple(int(v) for v in seg[1]) + (0,) * (10 - len(seg[1]))),
+                         *((0, 0, 0, 0) if b_alt is None else (b_alt[0].data_ptr(), int(b_alt[1]), int(b_alt[2]), 0)))
     if PROFILE.on:
         e0 = PROFILE.begin()
         _lib.check(lib.poet_gemm(C.byref(d), _stream()), "poet_gemm")
@@ -383,11 +384,13 @@ def _linear_dw_now(dy, x, dW, rows, ldy, ldx, db):
                           b_kmajor=True, splitk=_splitk_for(n_out, k_in, rows), atomic=True, bias=db), dy, x)
 
 
-def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None, db=None, seg=None):
+def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int, ldy=None, ldx=None, db=None, seg=None, x_alt=None):
     """dW[N_out, K_in] += dy[rows, N_out]^T @ x[rows, K_in]   (fp32 atomics, split-K over rows);
     db[N_out] += column sums of dy (optional: the bias gradient, fused into the same pass where possible).
     seg = (seg_sums [n_seg, >= N_out] fp32, starts, period): seg_sums[s] += the column sums of dy over the rows of segment s of every
-    period (the encoder's per-LEVEL sums of d(offsets | logits)), formed in the same pass over dy instead of by a colsum launch."""
+    period (the encoder's per-LEVEL sums of d(offsets | logits)), formed in the same pass over dy instead of by a colsum launch.
+    x_alt = (x2, m_alt): the output rows >= m_alt of dW pair with x2 instead of x (two stacked Linears with different inputs whose
+    gradient rows share one buffer: PoetGemmDesc.B_alt)."""
     D = defer_small_dw.active
     if (D is not None and D.layers and rows <= 1024 and dy.dtype == torch.float32 and x.dtype == torch.float32
             and dW.dtype == torch.float32 and dW.is_contiguous()):
@@ -395,7 +398,8 @@ def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int,
         return dW
     n_out, k_in = dW.shape
     SIDE.run(lambda: gemm(dy, x, dW, n_out, k_in, rows, lda=ldy or n_out, ldb=ldx or k_in, ldc=k_in, a_kmajor=True,
-                          b_kmajor=True, splitk=_splitk_for(n_out, k_in, rows), atomic=True, bias=db, seg=seg), dy, x)
+                          b_kmajor=True, splitk=_splitk_for(n_out, k_in, rows), atomic=True, bias=db, seg=seg,
+                          b_alt=None if x_alt is None else (x_alt[0], x_alt[0].stride(0), x_alt[1])), dy, x)
     return dW
 
 

@@ -1494,3 +1494,29 @@ def test_linear_bwd_fused_equals_dw_plus_dx(ops, rows, n2, gate):
     assert (dx_f[:rows].float() - dx_t.float()).abs().max().item() <= 2.0 ** -7 * sx                     # two kernels, two summation orders
     if gate:
         assert bool(((dx_f[:rows] == 0) | (xd > 0)).all())                                               # the gate's zeros exactly
+
+
+@pytest.mark.parametrize("rows,with_seg", [(102080, True), (6380 * 3, True), (6380, True), (9000, False)])
+def test_gemm_dw_two_inputs(ops, rows, with_seg):
+    """PoetGemmDesc.B_alt (ABI v4): the rows m >= m_alt of the weight gradient pair with a second input -- the encoder's stacked
+    [sampling_offsets ; attention_weights ; value_proj] gradient in ONE launch (gradient rows = column blocks of one buffer; inputs src + pos
+    and src) -- against two separate products and fp64; with the per-level column sums over all columns riding along.  6380-row case: the
+    DMA ring declines (row count), poet_gemm falls back to a column-sum launch + two plain products."""
+    shapes = [(60, 80), (30, 40), (15, 20), (8, 10)]
+    geom = ops.LevelGeom(shapes)
+    S, L = geom.S, 4
+    if not with_seg:
+        S = rows
+    G2 = (_rand(rows, 1024, seed=800) * 0.5).to(torch.bfloat16)
+    q, src = _rand(rows, 256, seed=801).to(torch.bfloat16), _rand(rows, 256, seed=802).to(torch.bfloat16)
+    g2, qd, sd = dev(G2), dev(q), dev(src)
+    gw = torch.full((1024, 256), 0.25, device="cuda")
+    seg = torch.full((L, 1024), 0.5, device="cuda") if with_seg else None
+    ops.linear_dw(g2, qd, gw, rows=rows, ldy=1024, seg=(seg, geom.c_segs, S) if with_seg else None, x_alt=(sd, 768))
+    ref_w = torch.cat([G2[:, :768].double().t() @ q.double(), G2[:, 768:].double().t() @ src.double()]) + 0.25
+    sc = ref_w.abs().max().item()
+    assert (gw.double().cpu() - ref_w).abs().max().item() < 2e-5 * sc + 1e-3
+    if with_seg:
+        starts = [int(v) for v in geom.c_segs]
+        ref_s = torch.stack([G2.float().view(rows // S, S, 1024)[:, starts[l]:starts[l + 1]].double().sum((0, 1)) for l in range(L)]) + 0.5
+        assert (seg.double().cpu() - ref_s).abs().max().item() < 2e-5 * ref_s.abs().max().item() + 1e-3
