@@ -134,17 +134,16 @@ def pmc_source(config="ycbv", kind="hbm"):
             "measured_in_this_run": False, "fetch_correction": FETCH_CORRECTION_NOTE}
 
 
-FETCH_CORRECTION_NOTE = ("traffic = (f x FETCH_SIZE + WRITE_SIZE) KiB with f calibrated per access pattern (profiles/probes/fetch_calib.hip, "
-                         "round 4): FETCH_SIZE counts 64 B per memory-side read request, so it is EXACT for the 32 / 64-byte segment reads of the "
-                         "MSDA kernels (f = 1: 2 B and 4 B per lane, 16 B per lane at row stride) and HALF of a wide coalesced 16-B-per-lane stream "
-                         "(128-byte requests: f = 2, the guide's gfx950 correction, used for the GEMM / LayerNorm kernels); traffic_raw = f = 1")
-# kernels whose reads are 32 / 64-byte segments of strided rows (calibrated: the raw counter is their real traffic)
-_FETCH_FACTOR_1 = ("msda_",)
+FETCH_CORRECTION_NOTE = ("traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB: the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide "
+                         "coalesced read stream).  Calibration on known byte counts, profiles/round5_fetch_calib.csv (profiles/probes/fetch_calib.hip): "
+                         "counter / known bytes = 0.50 for 16-byte-per-lane streams, 1.00 for 64-byte segments of strided rows, 2.00 for 32-byte "
+                         "segments (fetched as 64-byte sectors) -- so the x2 is exact for streams and for the scatter since its 16 heads share an XCD "
+                         "(whole rows arrive as wide requests), and an upper bound for the L2-served gathers; traffic_raw = FETCH_SIZE + WRITE_SIZE")
 
 
 def pmc_traffic_bytes(tag, config="ycbv", fetch_factor=None):
     if fetch_factor is None:
-        fetch_factor = 1.0 if tag.startswith(_FETCH_FACTOR_1) else 2.0
+        fetch_factor = 2.0
     tag = _pmc_key(tag)
     key = _PMC_NAMES.get(tag)
     _, rows = _pmc_rows(config, "hbm")
