@@ -144,7 +144,8 @@ typedef struct PoetGemmDesc {
        that share their gradient rows' buffer (A = [dY1 | dY2], column blocks of one row-major buffer) but not their input: the
        encoder's stacked [sampling_offsets ; attention_weights ; value_proj] gradient, whose first two blocks pair with the query
        src + pos and the third with src (deformable_transformer.py:199-201).  One launch of 8 tiles instead of 6 + 2 (the 2-tile
-       launch is the slow shape of this product).  NULL = off; m_alt a multiple of 256. */
+       launch is the slow shape of this product) when m_alt is a multiple of 256 and the shape is one the DMA-ring kernel takes;
+       two products otherwise.  NULL = off. */
     const void* B_alt;
     int64_t ldb_alt;
     int32_t m_alt, reserved_alt;

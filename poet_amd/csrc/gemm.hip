@@ -486,8 +486,8 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         for (int i = 0; i < d.seg_n; ++i) POET_CHECK(d.seg_start[i] <= d.seg_start[i + 1], POET_ERR_ARG, "poet_gemm: seg_start must ascend");
     }
     if (d.B_alt)                                           // rows m >= m_alt of C pair with B_alt (ABI v4)
-        POET_CHECK(dw_form && d.batch == 1 && d.m_alt > 0 && d.m_alt < d.M && d.m_alt % 256 == 0 && d.ldb_alt >= d.N, POET_ERR_ARG,
-                   "poet_gemm: B_alt belongs to the weight-gradient form, batch 1, 0 < m_alt < M a multiple of 256");
+        POET_CHECK(dw_form && d.batch == 1 && d.m_alt > 0 && d.m_alt < d.M && d.ldb_alt >= d.N, POET_ERR_ARG,
+                   "poet_gemm: B_alt belongs to the weight-gradient form, batch 1, 0 < m_alt < M");       // (one launch needs m_alt % 256 == 0; else two products)
     POET_CHECK(d.drop_p >= 0.f && d.drop_p < 1.f, POET_ERR_ARG, "poet_gemm: drop_p");
     if (d.c_f16)
         POET_CHECK(d.c_dtype == POET_BF16 && !d.add_src && !d.gate_ref && !atomic, POET_ERR_ARG,

@@ -1496,8 +1496,8 @@ def test_linear_bwd_fused_equals_dw_plus_dx(ops, rows, n2, gate):
         assert bool(((dx_f[:rows] == 0) | (xd > 0)).all())                                               # the gate's zeros exactly
 
 
-@pytest.mark.parametrize("rows,with_seg", [(102080, True), (6380 * 3, True), (6380, True), (9000, False)])
-def test_gemm_dw_two_inputs(ops, rows, with_seg):
+@pytest.mark.parametrize("rows,with_seg,m_alt", [(102080, True, 768), (6380 * 3, True, 768), (6380, True, 768), (9000, False, 768), (6380 * 2, True, 96)])
+def test_gemm_dw_two_inputs(ops, rows, with_seg, m_alt):
     """PoetGemmDesc.B_alt (ABI v4): the rows m >= m_alt of the weight gradient pair with a second input -- the encoder's stacked
     [sampling_offsets ; attention_weights ; value_proj] gradient in ONE launch (gradient rows = column blocks of one buffer; inputs src + pos
     and src) -- against two separate products and fp64; with the per-level column sums over all columns riding along.  6380-row case: the
@@ -1512,8 +1512,8 @@ def test_gemm_dw_two_inputs(ops, rows, with_seg):
     g2, qd, sd = dev(G2), dev(q), dev(src)
     gw = torch.full((1024, 256), 0.25, device="cuda")
     seg = torch.full((L, 1024), 0.5, device="cuda") if with_seg else None
-    ops.linear_dw(g2, qd, gw, rows=rows, ldy=1024, seg=(seg, geom.c_segs, S) if with_seg else None, x_alt=(sd, 768))
-    ref_w = torch.cat([G2[:, :768].double().t() @ q.double(), G2[:, 768:].double().t() @ src.double()]) + 0.25
+    ops.linear_dw(g2, qd, gw, rows=rows, ldy=1024, seg=(seg, geom.c_segs, S) if with_seg else None, x_alt=(sd, m_alt))      # (m_alt = 96: 4 heads x 2 levels, no ring tile boundary)
+    ref_w = torch.cat([G2[:, :m_alt].double().t() @ q.double(), G2[:, m_alt:].double().t() @ src.double()]) + 0.25
     sc = ref_w.abs().max().item()
     assert (gw.double().cpu() - ref_w).abs().max().item() < 2e-5 * sc + 1e-3
     if with_seg:
