@@ -536,7 +536,9 @@ class InputProjFn(torch.autograd.Function):
                     inp = torch.empty((N, d, Hp, Wp), dtype=act_dtype, device=src.device)
                     ops.tokens_to_nchw(src, inp, N, d, Hp * Wp, geom.starts[lvl - 1], S)
                 C, Hi, Wi = inp.shape[1:]
-                if split and inp.dtype == torch.float32 and C % 16 == 0 and ops.inproj_exact():
+                if split and inp.dtype == torch.float32 and C % 16 == 0 and 9 * C <= 4096 and ops.inproj_exact():
+                    # (9 C <= 4096: gemm_small's K limit -- a real backbone's C = 512 .. 2048 takes the bf16 [hi | lo] path below instead of
+                    # the generic fp32 tiled kernel with a very long K)
                     # the 3x3 stride-2 convolution of the extra level in fp32 end to end: a few hundred token rows (80 per image at
                     # 640 x 480) with K = 9 C -- the latency-oriented fp32 kernels of the decoder (gemm_small.hip: <= 1024 rows per
                     # call, the reduction split over the 4 waves of a workgroup) run it in ~30 us where the tiled bf16 kernel walks
