@@ -323,6 +323,197 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
     if (u < u_hi) iteration(u, std::true_type{});
 }
 
+// ---- software-pipelined form of the wide split-weight forward products (FFN1: ReLU + dropout, bf16; offsets | logits: fp16) ----
+// gemm_ws_kernel above runs a 32-row x 128-column unit as two serial phases -- 256 matrix instructions, then ~17 vector instructions
+// per output for the epilogue -- and with two waves per SIMD that start in step the phases of the partner coincide: the matrix pipe
+// idles while both run their epilogues (measured: MFMA, epilogue and store time ADD).  Here the unit is cut into its two
+// 64-column halves and the wave's own stream is interleaved BY HAND: the 128 matrix instructions of one half are issued in 32 fenced chunks
+// of four, and every second chunk carries the epilogue of one output pair of the half finished before, inside the same 64 accumulator
+// registers (a `sched_group_barrier` pipeline of the same shape was not honoured by the scheduler and took minutes to compile).  The epilogue is put on a diet for the same reason (the vector pipe is the
+// longer of the two): the bias IS the initial accumulator (no add), the dropout's 1 / (1 - p) is folded into the weight images and
+// the bias while they are staged (ReLU commutes with a positive scale; no multiply), the high half of a hash word is compared in
+// place (h >= T << 16; no shift).  Numerically this equals gemm_ws up to fp32 rounding (bias first instead of last, scale on the fp32
+// weight before its hi / lo split); the dropout MASK is identical.
+#ifndef WSP_AHEAD
+#define WSP_AHEAD 2
+#endif
+template <typename TC, bool ACT, bool DROP>
+__global__ __launch_bounds__(512, 2) void gemm_wsp_kernel(const GemmK p) {
+    constexpr int KS = 8, FM = 2, BN = 128, NTH = 512, NWV = NTH / 64;
+    constexpr int K = KS * 32, PITCH = K * 2, LO = BN * PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // hi image | lo image | bias[BN] f32 in LDS-row order, scaled
+    float* sbias = reinterpret_cast<float*>(smem + 2 * BN * PITCH);
+    const PoetGemmDesc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, g = lane >> 4;
+
+    // ---- work assignment (as gemm_ws_kernel) ----
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int NT = d.N / BN, groups = per / NT;
+    if (j >= groups * NT) return;
+    const int nt = j % NT, G = (j / NT) * 8 + xcd, NW = groups * 8 * NWV;
+    const int n0 = nt * BN;
+    const int U = (d.M + 15) >> 4, wv = G * NWV + wid;
+    const int u_lo = (int)((int64_t)wv * U / NW), u_hi = (int)((int64_t)(wv + 1) * U / NW);
+
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(d.A);
+    uint4 a[FM][KS];
+    auto arow = [&](int u, int fm) { return max(min(min(u + fm, u_hi - 1) * 16 + frow, d.M - 1), 0); };
+    if (u_lo < u_hi) {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const bf16_t* p0 = A + (int64_t)arow(u_lo, fm) * d.lda + g * 8;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a[fm][kk] = *reinterpret_cast<const uint4*>(p0 + kk * 32);
+        }
+    }
+
+    // ---- stationary weight slice: fp32 W x (dropout scale) -> hi | lo images ----
+    const float wscale = DROP ? p.drop_scale : 1.f;
+    {
+        const float* Bf = reinterpret_cast<const float*>(d.B);
+        constexpr int CPR = K / 4, NCH = BN * CPR, GRP = 8;
+        static_assert(NCH % (NTH * GRP) == 0, "split W staging");
+#pragma unroll 1
+        for (int base = 0; base < NCH; base += NTH * GRP) {
+            float4 wv4[GRP];
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                wv4[i] = *reinterpret_cast<const float4*>(Bf + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                const float w0 = wv4[i].x * wscale, w1 = wv4[i].y * wscale, w2 = wv4[i].z * wscale, w3 = wv4[i].w * wscale;
+                const uint2 hi = make_uint2(pack_bf2(w0, w1), pack_bf2(w2, w3));
+                const uint2 lo = make_uint2(pack_bf2(w0 - __uint_as_float(hi.x << 16), w1 - __uint_as_float(hi.x & 0xffff0000u)),
+                                            pack_bf2(w2 - __uint_as_float(hi.y << 16), w3 - __uint_as_float(hi.y & 0xffff0000u)));
+                *reinterpret_cast<uint2*>(smem + ws_sw<PITCH>(rho, kc * 8)) = hi;
+                *reinterpret_cast<uint2*>(smem + LO + ws_sw<PITCH>(rho, kc * 8)) = lo;
+            }
+        }
+    }
+    if (tid < BN) sbias[tid] = (d.bias ? d.bias[n0 + ws_perm(tid)] : 0.f) * wscale;      // row order of the image: fragment jn, rows 4g .. 4g + 3 are one float4
+    __syncthreads();
+
+    TC* C = reinterpret_cast<TC*>(d.C);
+    const uint32_t sd = (d.seed ^ (d.seed_dev ? *d.seed_dev * 0x9E3779B1u : 0u)) * 0x9E3779B9u;      // drop_pair(seed, i) = hash32(i ^ this)
+    const uint32_t thr_lo = p.drop_thresh, thr_hi = p.drop_thresh << 16;
+    int wsw[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) wsw[jj] = ws_sw<PITCH>(frow, (jj * 4 + g) * 16);
+    const float* bl = sbias + 4 * g;
+
+    f32x4_t acc[FM][8];
+    // One PHASE = the 128 matrix instructions of half H (fragments 4H .. 4H + 3) of the unit pair whose rows are in a[], cut into 32
+    // chunks of four (one weight fragment pair x two row fragments), each fenced from the next; EPI: every second chunk also carries
+    // the epilogue of ONE output pair of the OTHER half (finished by the phase before) of the unit pair starting at ue -- 16 pairs
+    // per lane and half, a 16-byte store after every fourth.  REFILL: a[][kk] is re-requested for the rows qn[] once step kk has used it.
+    // The weight fragments of chunk c + 1 are read before the matrix instructions of chunk c are issued.
+    auto phase = [&](auto htag, auto rtag, auto etag, auto ttag, const bf16_t* const* qn, int ue) __attribute__((always_inline)) {
+        constexpr int H = decltype(htag)::value, HE = 1 - H;
+        constexpr bool REFILL = decltype(rtag)::value, EPI = decltype(etag)::value, TAIL = decltype(ttag)::value;
+        asm volatile("" : "+v"(wsw[0]), "+v"(wsw[1]), "+v"(wsw[2]), "+v"(wsw[3]));      // fragments stay in LDS (not hoisted into registers)
+        const char* wl[4] = {smem + wsw[0], smem + wsw[1], smem + wsw[2], smem + wsw[3]};
+        f32x4_t acn[FM][4];                                              // this phase's accumulators start as the bias
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4_t b = *reinterpret_cast<const f32x4_t*>(bl + (H * 4 + jj) * 16);
+            acn[0][jj] = b;
+            acn[1][jj] = b;
+        }
+        TC* crow[FM];
+        uint32_t hb[FM];
+        bool live[FM];
+        if constexpr (EPI) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int grow = TAIL ? arow(ue, fm) : (ue + fm) * 16 + frow;
+                live[fm] = !TAIL || ((ue + fm) < u_hi && (ue + fm) * 16 + frow < d.M);
+                crow[fm] = C + (int64_t)grow * d.ldc + n0 + HE * 64 + g * 8;
+                hb[fm] = (((uint32_t)grow * (uint32_t)d.N + (uint32_t)(n0 + HE * 64 + g * 8)) >> 1) ^ sd;     // (bits 0, 1 and 4 of the pair index are 0 here: + (r * 16 + pp) == ^)
+            }
+        }
+        uint32_t pk[4];
+        // chunk c: k-step kk = c >> 2, image (c >> 1) & 1 (hi, hi, lo, lo), fragments jj = 2 (c & 1), + 1: the hi and the lo product of
+        // one accumulator are eight matrix instructions apart.  The two fragments of chunk c + WSP_AHEAD are read while chunk c is issued.
+        auto frag = [&](int c, int i) {
+            const int kk = c >> 2, img = (c >> 1) & 1, jn = H * 4 + 2 * (c & 1) + i;
+            return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl[kk & 3] + img * LO + jn * 16 * PITCH + (kk >> 2) * 256));
+        };
+        constexpr int AH = WSP_AHEAD;
+        bf16x8_t wq[AH][2];
+#pragma unroll
+        for (int c = 0; c < AH; ++c) { wq[c][0] = frag(c, 0); wq[c][1] = frag(c, 1); }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int kk = c >> 2, j0 = 2 * (c & 1);
+            const bf16x8_t w0 = wq[c % AH][0], w1 = wq[c % AH][1];
+            if (c + AH < 32) { wq[c % AH][0] = frag(c + AH, 0); wq[c % AH][1] = frag(c + AH, 1); }
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) acn[fm][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acn[fm][j0], 0, 0, 0);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) acn[fm][j0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, __builtin_bit_cast(bf16x8_t, a[fm][kk]), acn[fm][j0 + 1], 0, 0, 0);
+            if constexpr (EPI) {
+                if (c & 1) {
+                    const int q = c >> 1, fm = q >> 3, r = (q >> 2) & 1, pp = q & 3;
+                    const f32x4_t av = acc[fm][HE * 4 + r * 2 + (pp >> 1)];
+                    float v0 = av[(pp & 1) * 2], v1 = av[(pp & 1) * 2 + 1];
+                    if constexpr (ACT) {                                 // max(x, 0) on the bit pattern: one v_max_i32, nothing to canonicalise
+                        v0 = __int_as_float(max(__float_as_int(v0), 0));
+                        v1 = __int_as_float(max(__float_as_int(v1), 0));
+                    }
+                    if constexpr (DROP) {
+                        const uint32_t hsh = hash32(hb[fm] ^ (uint32_t)(r * 16 + pp));
+                        v0 = (hsh & 0xffffu) >= thr_lo ? v0 : 0.f;
+                        v1 = hsh >= thr_hi ? v1 : 0.f;
+                    }
+                    pk[pp] = std::is_same<TC, f16_t>::value ? pack_h2(v0, v1) : pack_bf2(v0, v1);
+                    if (pp == 3 && live[fm]) *reinterpret_cast<uint4*>(crow[fm] + r * 32) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+            }
+            if constexpr (REFILL) {
+                if ((c & 3) == 3) {
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) a[fm][kk] = *reinterpret_cast<const uint4*>(qn[fm] + kk * 32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[fm][H * 4 + jj] = acn[fm][jj];
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    using Y = std::true_type;
+    using N_ = std::false_type;
+
+    int u = u_lo;
+    const int u_full = min(u_hi, d.M >> 4);
+    const bf16_t* qn[FM] = {A, A};
+    if (u < u_hi) {
+        phase(H0{}, N_{}, N_{}, N_{}, qn, u);                             // prologue: half 0 of the first pair (rows clamped on load)
+        while (u + FM <= u_full) {                                        // the pair at u is whole
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) qn[fm] = A + (int64_t)arow(u + FM, fm) * d.lda + g * 8;
+            phase(H1{}, Y{}, Y{}, N_{}, qn, u);                           // half 1 of this pair (+ refills)  ||  epilogue of its half 0
+            phase(H0{}, N_{}, Y{}, N_{}, qn, u);                          // half 0 of the next pair (whole, ragged or none)  ||  epilogue of half 1
+            u += FM;
+        }
+        if (u < u_hi) {                                                   // ragged end of the wave's range: masked stores
+            phase(H1{}, N_{}, Y{}, Y{}, qn, u);
+            phase(H0{}, N_{}, Y{}, Y{}, qn, u);
+        }
+    }
+}
+
+#ifdef POET_PROBE_KERNELS
+#include "gemm_wss.inc"      // store waves + LDS ring for the same products: measured slower (profiles/probes/kernels/)
+#endif
+
 // ---- K-chunked variant: K = KC x 128 (FFN2 and the K = 512 / 768 / 1024 input-gradient products) ----------------------
 // The weight no longer fits LDS whole, so the loop nest is turned inside out: a workgroup owns ONE (256-row block, 128-column
 // slice) item, its 8 waves keep the 32 x 128 accumulators of their rows in registers for the whole K loop, and the W chunk
@@ -631,6 +822,18 @@ bool ws_launch(const GemmK& p, int nblocks, hipStream_t st) {
     else { ws_launch_cfg<TC, KIND, WKM, 2, 256>(p, nblocks, st); return true; }
 }
 
+template <typename TC, bool ACT, bool DROP>
+void wsp_launch(const GemmK& p, int nblocks, hipStream_t st) {
+    constexpr int LDS = 2 * 128 * 512 + 128 * 4;
+    auto kern = gemm_wsp_kernel<TC, ACT, DROP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), LDS, st, p);
+}
+
 // b_split shapes.  The two weight images take 135 KB of LDS for a 128-column slice: ONE workgroup per CU with twice the
 // waves keeps the occupancy of the plain kernel (wide outputs: 8 waves; narrow: 16 waves need <= 128 VGPRs -- variant 0),
 // or a 64-column slice keeps two workgroups per CU at twice the A re-reads through L2 (variant 1; variant 2, the default =
@@ -646,7 +849,30 @@ bool ws_launch_split(const GemmK& p, hipStream_t st) {
         return true;
     }
     if constexpr (sizeof(TC) == 4 && (KIND & (WS_ADD | WS_GATE))) return false;
-    else { ws_launch_cfg<TC, KIND, false, 2, 512, true, 128>(p, ws_blocks(p.d.N, 128, 1), st); return true; }
+    else {
+        if constexpr (KIND == 0 && sizeof(TC) == 2) {
+            // the software-pipelined form (gemm_wsp_kernel): plain stores, no epilogue operands, alpha = 1.  POET_WS_PIPE=0: off (A/B aid)
+            static const int pipe = [] { const char* e = getenv("POET_WS_PIPE"); return e ? atoi(e) : 1; }();
+            const PoetGemmDesc& d = p.d;
+            if (pipe && d.out_mode == 0 && d.alpha == 1.f && (d.act == 0 || d.act == 1) && (p.drop_thresh == 0 || d.act == 1)) {
+                const int nb = ws_blocks(d.N, 128, 1);
+#ifdef POET_PROBE_KERNELS
+                if (pipe == 2 && (uint64_t)d.M * (uint64_t)d.lda * 2u < (1ull << 32)) {      // (32-bit byte offsets into A)
+                    if (d.act == 1 && p.drop_thresh) wss_launch<TC, true, true>(p, nb, st);
+                    else if (d.act == 1) wss_launch<TC, true, false>(p, nb, st);
+                    else wss_launch<TC, false, false>(p, nb, st);
+                    return true;
+                }
+#endif
+                if (d.act == 1 && p.drop_thresh) wsp_launch<TC, true, true>(p, nb, st);
+                else if (d.act == 1) wsp_launch<TC, true, false>(p, nb, st);
+                else wsp_launch<TC, false, false>(p, nb, st);
+                return true;
+            }
+        }
+        ws_launch_cfg<TC, KIND, false, 2, 512, true, 128>(p, ws_blocks(p.d.N, 128, 1), st);
+        return true;
+    }
 }
 
 // the epilogue kinds that occur on the path: forward {plain, +residual, +row mask}, input gradient {plain, ReLU gate,
