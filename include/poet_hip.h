@@ -80,9 +80,9 @@ const char* poet_hip_last_error(void);
  *                   -> row_mask (row_mask[row] != 0 -> 0) -> store.
  *   out_mode 0: C[row*ldc + col].  out_mode 1 (head-major value maps): row=(n,s), col=(m,d) ->
  *               C[((n*hm_M + m)*hm_S + s)*hm_D + d].
- *   batch > 1: A/B/C advance by strideA/B/C elements per batch index (gate_ref / add_src, laid out like C, by strideC --
- *   in the <= 1024-row fp32 kernels only, other shapes reject batched gate_ref / add_src; bias shared or strided by
- *   stride_bias).  splitk > 1 or atomic != 0: fp32 atomicAdd into C (C must be f32, pre-zeroed
+ *   batch > 1: A/B/C advance by strideA/B/C elements per batch index (gate_ref / add_src, laid out like C, by strideC:
+ *   the <= 1024-row fp32 kernels and the generic tiled kernel; the streaming / long-K kernels take batch 1 only; bias shared
+ *   or strided by stride_bias).  splitk > 1 or atomic != 0: fp32 atomicAdd into C (C must be f32, pre-zeroed
  *   or holding the value to accumulate onto); bias/act/gate are then not allowed -- with one
  *   exception, the WEIGHT-GRADIENT FORM (a_kmajor && b_kmajor && atomic: A = dY stored [rows][M],
  *   B = X stored [rows][N], C = dW): there `bias` is an optional fp32 OUTPUT [M] that receives

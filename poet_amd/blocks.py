@@ -26,6 +26,7 @@ def next_seed() -> int:
     return (_seed_state["base"] + _seed_state["count"] * 0x9E3779B1) & 0xFFFFFFFF
 
 
+_ENV_HEAD_LOOP = __import__("os").environ.get("POET_HEAD_DX_LOOP", "0") not in ("", "0")      # (A/B aid, read at import)
 _ENV_SEG_FUSE = __import__("os").environ.get("POET_NO_SEG_FUSE", "0") in ("", "0")      # (A/B aid, read at import)
 _ENV_DW_MERGE = __import__("os").environ.get("POET_NO_DW_MERGE", "0") in ("", "0")
 
@@ -523,10 +524,12 @@ def mlp3_bwd_batched(dc, h, Ws, saved, gWs, gbs, sW, sgW, sgb, dh, accumulate, W
                  bias=gbs[k], batch=nb, strideA=rows * n_out, strideB=rows * k_in, strideC=sgW[k], stride_bias=sgb[k])
         if k > 0:
             dx = torch.empty_like(x)
-            if n_out % 16 == 0:
+            # ((n_classes+1) * 6 or * 3 wide outputs are outside the <= 1024-row kernel's K % 16 == 0: the generic tiled kernel takes
+            # the batch as well -- one launch instead of one per decoder layer)
+            if n_out % 16 == 0 or not _ENV_HEAD_LOOP:
                 ops.gemm(dy, Ws[k], dx, rows, k_in, n_out, lda=n_out, ldb=k_in, ldc=k_in, b_kmajor=True, gate_ref=x, batch=nb,
                          strideA=rows * n_out, strideB=sW[k], strideC=rows * k_in)
-            else:                                   # (n_classes+1) * 6 or * 3 wide outputs: outside the batched kernel's K % 16 == 0
+            else:                                   # (POET_HEAD_DX_LOOP=1: one launch per decoder layer, A/B aid)
                 for j in range(nb):
                     ops.linear_dx(dy[j], Ws_all[k][j], dx[j], rows=rows, gate_ref=x[j])
             dy = dx

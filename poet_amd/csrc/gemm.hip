@@ -301,8 +301,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmK p) {
         return;
     }
     const float* bias = d.bias ? d.bias + (int64_t)zb * d.stride_bias : nullptr;
-    const TC* addp = reinterpret_cast<const TC*>(d.add_src);
-    const TC* gate = reinterpret_cast<const TC*>(d.gate_ref);
+    // (gate_ref and add_src are laid out like C: they take C's batch stride)
+    const TC* addp = d.add_src ? reinterpret_cast<const TC*>(d.add_src) + (int64_t)zb * d.strideC : nullptr;
+    const TC* gate = d.gate_ref ? reinterpret_cast<const TC*>(d.gate_ref) + (int64_t)zb * d.strideC : nullptr;
     constexpr int C8 = BN / 8;
     for (int idx = tid; idx < BM * C8; idx += 256) {
         const int row = idx / C8, c8 = idx - row * C8;
@@ -570,8 +571,6 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
         if (rc) return rc;
         d.bias = nullptr;
     }
-    POET_CHECK(d.batch == 1 || (!d.add_src && !d.gate_ref), POET_ERR_UNSUPPORTED,
-               "poet_gemm: batched add_src / gate_ref only in the <= 1024-row kernels");
     if (gemm_pipe_try(p, st)) {                             // plain N = 256, K >= 512 products: the deep-pipeline kernel (gemm_pipe.hip)
         g_last_path = POET_GEMM_PATH_PIPE;
         POET_LAUNCH_CHECK();

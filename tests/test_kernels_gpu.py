@@ -886,6 +886,45 @@ def test_gemm_register_stationary_equals_lds_stationary(ops, monkeypatch, N, act
     assert ((got * (1 - dp) - ref).abs() * keep).max().item() <= 6e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("N,act,dp,f16", [(1024, 1, 0.1, 0), (768, 0, 0.0, 1), (512, 1, 0.0, 0)])
+@pytest.mark.parametrize("rows", [102080, 4096 + 23])
+def test_gemm_split_pipelined_vs_plain_streaming(ops, tmp_path, N, act, dp, f16, rows):
+    """gemm_wsp_kernel (the default for the wide split-weight forward products: matrix instructions of one 64-column half interleaved
+    with the epilogue of the other, the dropout scale folded into the staged weights) against gemm_ws_kernel (POET_WS_PIPE=0, own
+    process): BIT-IDENTICAL without dropout (so the goldens' realisation of the bf16 policy is the same under either kernel); with
+    dropout the SAME mask and values within one rounding of the 2-byte output; whole and ragged row counts, nothing written past the
+    last row; and against torch."""
+    import subprocess, sys as _sys
+    x = _rand(rows, 256, seed=400 + N).to(torch.bfloat16)
+    w = _rand(N, 256, seed=401, scale=1 / 16)
+    b = _rand(N, seed=402)
+    odt = torch.float16 if f16 else torch.bfloat16
+    out = torch.full((rows + 3, N), 7.0, dtype=odt, device="cuda")
+    ops.linear_fwd(dev(x), dev(w), dev(b), out[:rows], split=True, act=act, drop_p=dp, seed=99)
+    assert bool((out[rows:] == 7.0).all())
+    got = out[:rows].float().cpu()
+    here = os.path.dirname(os.path.abspath(__file__))
+    fin, fout = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(fin, x=x.float().numpy(), w=w.numpy(), b=b.numpy(), act=act, dp=dp, seed=99, f16=f16)
+    r_ = subprocess.run([_sys.executable, os.path.join(here, "ws_pipe_worker.py"), fin, fout], capture_output=True, text=True, timeout=600)
+    assert r_.returncode == 0, r_.stderr[-3000:]
+    plain = torch.from_numpy(np.load(fout)["out"])
+    scale = plain.abs().max().item()
+    ulp = 2.0 ** (-10 if f16 else -7)
+    if dp == 0:
+        assert torch.equal(got, plain)                                   # same accumulation order, bias last: bit-identical
+    assert (got - plain).abs().max().item() <= ulp * scale                       # (dropout: the scale sits in the staged weights) one rounding step
+    if dp > 0:                                                           # the mask is a function of (seed, row, column) only
+        tiny = plain.abs() < 1e-3 * scale                                # (an output the ReLU may or may not have clipped, by one rounding)
+        assert bool((((got == 0) == (plain == 0)) | tiny).all())
+        assert abs((got == 0).float().mean().item() - (plain == 0).float().mean().item()) < 1e-5
+    ref = x.float() @ w.t() + b
+    if act:
+        ref = torch.relu(ref)
+    keep = got != 0 if dp > 0 else torch.ones_like(got, dtype=torch.bool)
+    assert ((got * (1 - dp) - ref).abs() * keep).max().item() <= (1.5e-3 if f16 else 6e-3) * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("rows", [5000 + 7, 700])
 def test_gemm_fp16_output_storage(ops, rows):
     """PoetGemmDesc.c_f16: the 2-byte outputs of a bf16-typed C written as IEEE fp16 (the offsets | logits buffer of the encoder's
@@ -1230,6 +1269,34 @@ def test_gemm_small_batched_matches_loop(ops):
         ops.linear_dw(dy[j], x[j], g2[j * sW: j * sW + n_out * k_in].view(n_out, k_in), rows=rows, db=d2[j * sb: j * sb + n_out])
     assert torch.equal(g1, g2) and torch.equal(d1, d2)
     assert float(g1[n_out * k_in: sW].abs().max()) == 0.0        # the gaps between the copies stay untouched
+
+
+def test_gemm_tiled_batched_gate_matches_loop(ops):
+    """batch > 1 with gate_ref / add_src in the GENERIC tiled kernel (the gated input gradient of the pose heads' last Linear,
+    (n_classes + 1) * 3 = 66 or * 6 = 132 outputs wide: K % 16 != 0 keeps it out of the <= 1024-row kernel): one launch for the L
+    decoder layers' heads must equal one launch per head, bit for bit, and torch."""
+    nb, rows, k_in = 5, 800, 256
+    for n_out in (66, 132):
+        pad = 1000
+        Wbuf = dev(_rand(nb * (n_out * k_in + pad), seed=1, scale=0.06))
+        sW = n_out * k_in + pad
+        Ws = [Wbuf[j * sW: j * sW + n_out * k_in].view(n_out, k_in) for j in range(nb)]
+        x = dev(_rand(nb, rows, k_in, seed=3))
+        dy = dev(_rand(nb, rows, n_out, seed=4))
+        a1 = dev(_rand(nb, rows, k_in, seed=5)); a2 = a1.clone()
+        ops.gemm(dy, Ws[0], a1, rows, k_in, n_out, lda=n_out, ldb=k_in, ldc=k_in, b_kmajor=True, gate_ref=x, add_src=a1, ld_add=k_in,
+                 batch=nb, strideA=rows * n_out, strideB=sW, strideC=rows * k_in)
+        from poet_amd import _lib
+        assert _lib.load().poet_gemm_last_path() == 1                    # POET_GEMM_PATH_TILED
+        b1 = torch.empty(nb, rows, k_in, device="cuda"); b2 = torch.empty_like(b1)
+        ops.gemm(dy, Ws[0], b1, rows, k_in, n_out, lda=n_out, ldb=k_in, ldc=k_in, b_kmajor=True, gate_ref=x,
+                 batch=nb, strideA=rows * n_out, strideB=sW, strideC=rows * k_in)
+        for j in range(nb):
+            ops.linear_dx(dy[j], Ws[j], a2[j], rows=rows, gate_ref=x[j], add_src=a2[j])
+            ops.linear_dx(dy[j], Ws[j], b2[j], rows=rows, gate_ref=x[j])
+        assert torch.equal(a1, a2) and torch.equal(b1, b2)
+        ref = (dy[2].cpu() @ Ws[2].cpu()) * (x[2].cpu() > 0)
+        assert (b1[2].cpu() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-4
 
 
 def test_gemm_dw_list_matches_loop(ops):
