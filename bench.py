@@ -98,7 +98,15 @@ _PMC_NAMES = {"gemm_pipe": "gemm_pipe_kernel", "msda_bwd_dvalue_scatter_tiled": 
               "gemm_tiled_fwd": "gemm_kernel<", "gemm_tiled_dX": "gemm_kernel<", "gemm_tiled_dW": "gemm_kernel<",
               "gemm_small_fwd": "gemm_small_kernel<false", "gemm_small_dX": "gemm_small_kernel<true", "gemm_small_dW": "gemm_small_dw_kernel",
               "ln_fwd": "ln_fwd_kernel<float, float, bf16>|ln_fwd_kernel<bf16", "ln_bwd": "ln_bwd_kernel<bf16"}
-_PMC_FILTER = {"gemm_stream_dX": ", true,", "gemm_stream_fwd": ", false,"}     # ws kernels: W stored [K][N] (dX) or not
+# ws kernels: W stored [K][N] (dX) or not; the software-pipelined forward form (gemm_wsp_kernel<TC, ACT, DROP>) is forward only
+def _ws_wkm(n):
+    import re
+    m = re.search(r"gemm_wsk?_kernel<[^,]+(?:::[^,]+)?, \d+, (true|false)", n)      # gemm_ws_kernel<TC, KIND, WKM, ...>, gemm_wsk_kernel<TC, KIND, WKM, ...>
+    return None if m is None else m.group(1) == "true"
+
+
+_PMC_FILTER = {"gemm_stream_dX": lambda n: _ws_wkm(n) is True,
+               "gemm_stream_fwd": lambda n: "gemm_wsp_kernel" in n or _ws_wkm(n) is False}
 
 
 def _pmc_rows(config, kind):
@@ -149,11 +157,11 @@ def pmc_traffic_bytes(tag, config="ycbv", fetch_factor=None):
     _, rows = _pmc_rows(config, "hbm")
     if key is None or len(rows) < 2:
         return None
-    flt = _PMC_FILTER.get(tag, "")
+    flt = _PMC_FILTER.get(tag, lambda n: True)
     tot = n = 0.0
     for alt in key.split("|"):                          # first alternative present in the summary; launch-weighted mean over
         for r in rows[1:]:                              # its symbols
-            if alt in r[0] and flt in r[0]:
+            if alt in r[0] and flt(r[0]):
                 tot += float(r[1]) * (fetch_factor * float(r[2]) + float(r[4])) * 1024
                 n += float(r[1])
         if n:
