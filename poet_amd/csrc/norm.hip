@@ -494,7 +494,12 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     int nb = cdiv(rows, 4);
-    if (nb > 512) nb = 512;          // one row per wave iteration, no prefetch: occupancy is what hides the load latency
+    // One row per wave iteration, no prefetch: occupancy is what hides the load latency, and 4 workgroups per CU is where it stops paying
+    // (102 080 x 256, us per launch by grid: 256: 114, 512: 77, 768: 68, 1024: 67, 1280: 80, 2048: 78, 4096: 114 -- not the per-column atomics
+    // of the epilogue: with the blocks' column sums stored to a workspace and added by a second launch the larger grids measured 81 / 76 / 90).
+    // POET_LN_BWD_NB: the cap (A/B aid, read once).
+    static const int cap = [] { const char* e = getenv("POET_LN_BWD_NB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    if (nb > cap) nb = cap;
     dim3 grid(nb), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev)
