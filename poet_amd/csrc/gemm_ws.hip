@@ -326,15 +326,16 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
 // ---- software-pipelined form of the wide split-weight forward products (FFN1: ReLU + dropout, bf16; offsets | logits: fp16) ----
 // gemm_ws_kernel above runs a 32-row x 128-column unit as two serial phases -- 256 matrix instructions, then ~17 vector instructions
 // per output for the epilogue -- and with two waves per SIMD that start in step the phases of the partner coincide: the matrix pipe
-// idles while both run their epilogues (measured: MFMA, epilogue and store time ADD).  Here the unit is cut into its two
-// 64-column halves and the wave's own stream is interleaved BY HAND: the 128 matrix instructions of one half are issued in 32 fenced chunks
-// of four, and every second chunk carries the epilogue of one output pair of the half finished before, inside the same 64 accumulator
-// registers (a `sched_group_barrier` pipeline of the same shape was not honoured by the scheduler and took minutes to compile).  The epilogue is put on a diet for the same reason (the vector pipe is the
-// longer of the two): the dropout's 1 / (1 - p) is folded into the weight images and
-// the bias while they are staged (ReLU commutes with a positive scale; no multiply), the high half of a hash word is compared in
-// place (h >= T << 16; no shift), the bias is added per output PAIR.  Without dropout the outputs are BIT-IDENTICAL to gemm_ws_kernel's
-// (same accumulation order, bias last) -- the goldens' realisation of the bf16 policy does not move; with dropout they differ by the fp32
-// rounding of the scaled weight (before its hi / lo split), and the dropout MASK is identical.
+// idles while both run their epilogues (measured: MFMA, epilogue and store time ADD).  Here the unit is cut
+// into its two 64-column halves and the wave's own stream is interleaved BY HAND: the 128 matrix instructions of one half are issued
+// in 32 fenced chunks of four, and every second chunk carries the epilogue of one output pair of the half finished before, inside
+// the same 64 accumulator registers (a `sched_group_barrier` pipeline of the same shape was not honoured by the scheduler and took
+// minutes to compile).  The epilogue is on a diet for the same reason: the dropout's 1 / (1 - p) is folded into the weight images
+// and the bias while they are staged (ReLU commutes with a positive scale: no multiply), ReLU is one v_max_i32 on the bit pattern,
+// the high half of a hash word is compared in place (h >= T << 16: no shift), the bias of a lane's 16 columns is read once per
+// phase.  Without dropout the outputs are BIT-IDENTICAL to gemm_ws_kernel's (same accumulation order, bias last), so the goldens'
+// realisation of the bf16 policy does not move; with dropout they differ by the fp32 rounding of the scaled weight (before its
+// hi / lo split), and the dropout MASK is identical.  WSP_AHEAD: chunks of fragment prefetch (1, 2 and 4 measured equal).
 #ifndef WSP_AHEAD
 #define WSP_AHEAD 2
 #endif
@@ -342,7 +343,7 @@ template <typename TC, bool ACT, bool DROP>
 __global__ __launch_bounds__(512, 2) void gemm_wsp_kernel(const GemmK p) {
     constexpr int KS = 8, FM = 2, BN = 128, NTH = 512, NWV = NTH / 64;
     constexpr int K = KS * 32, PITCH = K * 2, LO = BN * PITCH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // hi image | lo image | bias[BN] f32 in LDS-row order, scaled
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // hi image | lo image | bias[BN] f32 (x the dropout scale)
     float* sbias = reinterpret_cast<float*>(smem + 2 * BN * PITCH);
     const PoetGemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
