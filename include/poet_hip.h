@@ -29,7 +29,8 @@
  *   poet_ln_fwd / poet_ln_bwd
  *       `x = norm(x + dropout(y))`  (deformable_transformer.py:202-203,195-196,279-287,271-272).
  *   poet_mha_fwd / poet_mha_bwd
- *       nn.MultiheadAttention core over <=64 queries (deformable_transformer.py:277-278).
+ *       nn.MultiheadAttention core over <= 128 queries, head dim 16 / 32 / 64 (deformable_transformer.py:277-278; backward at
+ *       head dim 64: <= 111 queries -- the Q x Q score matrices live in the CU's 160 KB of LDS).
  *   poet_pos_sine / poet_bbox_sine
  *       models/position_encoding.py:40-60 and :71-84.
  *   poet_groupnorm_* / poet_im2col3x3s2 / poet_col2im3x3s2_add / poet_nchw_to_tokens / poet_tokens_to_nchw
@@ -251,7 +252,9 @@ int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* r
 /* ------------------------------------------------------------------------------------------------
  * Small multi-head self-attention core (nn.MultiheadAttention without the projections):
  * q,k,v (N,Q,M*hd) fp32 with row stride ld (so they may be column slices of one packed buffer);
- * out (N,Q,M*hd).  Q <= 64, hd <= 64.  softmax(q k^T / sqrt(hd)) with dropout(p) on the
+ * out (N,Q,M*hd).  hd in {16, 32, 64}; Q <= 128 (one wave up to 64 queries, two waves above), except poet_mha_bwd at hd = 64:
+ * Q <= 111 (2 Q hd + 2 Q (Q + 1) floats of LDS; Q = 128 at hd = 32 runs with swizzled, unpadded score matrices = exactly
+ * 160 KB).  Anything else returns POET_ERR_UNSUPPORTED.  softmax(q k^T / sqrt(hd)) with dropout(p) on the
  * probabilities, no key-padding mask (the reference passes none).
  * ---------------------------------------------------------------------------------------------- */
 int poet_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, float* out, int64_t ld_out,

@@ -126,7 +126,7 @@ def sample_fwd(q2d, so_w, so_b, aw_w, aw_b, V, geom, ref, ref_bs, N, Lq, M, D, P
     odt = act or q2d.dtype
     # offsets | logits in fp16 where their readers take it (ops.oa_f16): the sampling offsets are the largest single rounding site of
     # the bf16 policy (1/32 px at |offset| ~ 4), fp16 stores them 8x finer in the same bytes
-    oa16 = odt == torch.bfloat16 and V.dtype == torch.bfloat16 and ops.oa_f16(M, D, geom.L, P, grid_queries)
+    oa16 = odt == torch.bfloat16 and V.dtype in (torch.bfloat16, torch.float16) and ops.oa_f16(M, D, geom.L, P, grid_queries)
     OA = empty((rows, ldq), torch.float16 if oa16 else odt, q2d)
     pr = getattr(so_w, "_pair", None)
     if pr is not None:                        # offsets | logits = ONE Linear over the adjacent parameters
@@ -162,7 +162,7 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
     if pr is not None and pr[2].data_ptr() == g_so_w.data_ptr():      # (the gradient sink is the arena: stacked dW + db)
         # the per-level column sums ride in the weight-gradient kernel's own pass over d(offsets | logits) (PoetGemmDesc.seg_sums):
         # no 157 MB column-sum launch per layer
-        seg_done = seg_sums is not None and seg_sums.stride(0) == ldq and Lq >= 64 and _ENV_SEG_FUSE
+        seg_done = seg_sums is not None and seg_sums.stride(0) == ldq and Lq >= 64 and geom.L <= 8 and _ENV_SEG_FUSE
         ops.linear_dw(dOA, q2d, pr[2], rows=rows, ldy=ldg, db=pr[3] if plain else None,
                       seg=(seg_sums, geom.c_segs, Lq) if seg_done else None)
     else:
@@ -189,7 +189,9 @@ def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=Non
     rows, d = res.shape[0], W.shape[0]
     mixed = x_in.dtype == torch.bfloat16 and res.dtype == torch.float32
     Wt, sp = Wf(W, x_in, split)
-    tmp = empty((rows, d), torch.float32 if (sp and mixed) else x_in.dtype, res)
+    # (round 6) ... as IEEE fp16 where the LayerNorm launch is the only reader (ops.ln_f16: >= 4096 rows, d = 256): 2^-11 relative, a
+    # quarter of the rounding the LayerNorm's own bf16 operand copy applies next, and 2 bytes per element less on both sides
+    tmp = empty((rows, d), (torch.float16 if ops.ln_f16(rows, d) else torch.float32) if (sp and mixed) else x_in.dtype, res)
     lo = getattr(W, "_bf16_lo", None) if (sp and mixed and rows >= 4096 and W.shape[1] >= 512 and W.shape[0] == 256) else None
     # (the long-K kernel's own admission rules, gemm_pipe.hip:gemm_pipe_try: K a multiple of 64, 16-byte aligned operands, row
     # strides of 8 / 4 elements -- anything else, e.g. dim_feedforward = 1000 or a sliced x_in, keeps the fp32-master split kernel)
@@ -284,8 +286,11 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
     else:
         q = empty(src.shape, src16.dtype, src)
         ops.add(src, pos, q)
+    # value maps in fp16 where their only readers take it (ops.v_f16: the shared-geometry gathers): 11 mantissa bits instead of 8 in
+    # the same bytes, and the forward gather multiplies the halves straight out of the packed pair (v_fma_mix_f32: no unpack)
+    v16 = (act or src16.dtype) == torch.bfloat16 and ops.v_f16(M, D, geom.L, npts, True)
     V = value_proj_fwd(src16, P_["self_attn.value_proj.weight"], P_["self_attn.value_proj.bias"], mask, N, S, M, D,
-                       act, split)
+                       torch.float16 if v16 else act, split)
     out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
                            P_["self_attn.attention_weights.weight"], P_["self_attn.attention_weights.bias"],
                            V, geom, ref, ref_bs, N, S, M, D, npts, act, split, grid_queries=True)
@@ -320,12 +325,13 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
                                 g("norm1.weight"), g("norm1.bias"))
     # grid queries + bf16 storage + D = 16: the LDS-tiled scatter can hand over the value gradient in bf16 (packed bf16x2
     # atomics; its consumer, the value projection's backward, rounds it to bf16 anyway) -- half the atomics, zero-fill and read
-    gv16 = (sv["V"].dtype == torch.bfloat16 and sv["OA"].dtype in (torch.bfloat16, torch.float16) and D == 16 and npts == 4 and geom.L * npts <= 16
+    v2b = sv["V"].dtype in (torch.bfloat16, torch.float16)             # 2-byte value maps (fp16: ops.v_f16)
+    gv16 = (v2b and sv["OA"].dtype in (torch.bfloat16, torch.float16) and D == 16 and npts == 4 and geom.L * npts <= 16
             and ops.tiled_scatter_bf16())
     dV = torch.zeros(sv["V"].shape, dtype=torch.bfloat16 if gv16 else torch.float32, device=dx2.device)
     mlp = M * geom.L * npts
     so_w = P_["self_attn.sampling_offsets.weight"]
-    tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and sv["V"].dtype == torch.bfloat16 else None
+    tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and v2b else None
     if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d or dpos is not None or (3 * mlp) % 8 != 0):
         tri = None
     G2 = None
@@ -336,7 +342,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
         G2 = torch.empty((N * S, 3 * mlp + d), dtype=torch.bfloat16, device=dx2.device)
     g_so_w = g("self_attn.sampling_offsets.weight")
     if (G2 is not None and _ENV_DW_MERGE and tri.get("gw") is not None and tri["gw"].data_ptr() == g_so_w.data_ptr() and S >= 64
-            and sv["src"].dtype == torch.bfloat16 and sv["q"].dtype == torch.bfloat16):
+            and geom.L <= 8 and sv["src"].dtype == torch.bfloat16 and sv["q"].dtype == torch.bfloat16):
         # The weight gradients of the three stacked Linears [sampling_offsets ; attention_weights ; value_proj] as ONE launch: their
         # gradient rows are the column blocks of G2 = [d(offsets | logits) | d(value) rows]; the first two pair with the query src + pos,
         # the third with src (PoetGemmDesc.B_alt).  The per-level column sums of ALL 3 M L P + d columns ride in the same pass: bias
@@ -370,13 +376,14 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
         so_w, aw_w = P_["self_attn.sampling_offsets.weight"], P_["self_attn.attention_weights.weight"]
         ops.gemm(seg, so_w, g_level, geom.L, d, 2 * mlp, lda=3 * mlp, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
         ops.gemm(seg[:, 2 * mlp:], aw_w, g_level, geom.L, d, mlp, lda=3 * mlp, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
+    vact = torch.bfloat16 if sv["V"].dtype == torch.float16 else sv["V"].dtype      # (gradient rows of an fp16 map are bf16)
     if G2 is not None:
         value_proj_bwd(dV, sv["src"], P_["self_attn.value_proj.weight"], mask, N, S, M, D,
-                       g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), None, True, sv["V"].dtype, dVr=G2[:, 3 * mlp:])
+                       g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), None, True, vact, dVr=G2[:, 3 * mlp:])
         ops.linear_dx(G2, tri["w16"], dsrc, rows=N * S, add_src=dsrc)
     else:
         value_proj_bwd(dV, sv["src"], P_["self_attn.value_proj.weight"], mask, N, S, M, D,
-                       g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), dsrc, True, sv["V"].dtype)
+                       g("self_attn.value_proj.weight"), g("self_attn.value_proj.bias"), dsrc, True, vact)
     return dsrc
 
 

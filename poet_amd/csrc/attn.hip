@@ -75,10 +75,14 @@ __global__ __launch_bounds__(NT) void mha_fwd_kernel(const MhaP p) {
 
 // OVERLAY (two waves, Q > 64): the row-phase operands (k, v) and the column-phase operands (scaled q, d(out)) SHARE their LDS --
 // 2 Q hd + 2 Q (Q + 1) floats = 148 KB at Q = 128, hd = 16 instead of 165 KB; a lane reads its own q / d(out) row from memory
-template <int HD, int NT, bool OVERLAY>
+// SWZ (Q a multiple of 64 whose padded score matrices would not fit: Q = 128 at head dim 32 needs 164 864 B with the Q + 1 pitch,
+// 163 840 = all of the CU's LDS without): pitch Q and the column index XORed with the row's low 6 bits instead of the pad -- a lane's
+// row walk (lane * Q + (j ^ lane)) and the column phase's walk down a column (i * Q + (lane ^ i)) both stay on 64 different banks.
+template <int HD, int NT, bool OVERLAY, bool SWZ = false>
 __global__ __launch_bounds__(NT) void mha_bwd_kernel(const MhaP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Q = p.Q, PQ = Q + 1;
+    const int Q = p.Q, PQ = SWZ ? Q : Q + 1;
+    auto at = [PQ](int r, int c) __attribute__((always_inline)) { return r * PQ + (SWZ ? (c ^ (r & 63)) : c); };
     constexpr int PH = HD;            // rows are read by all lanes at once (broadcast): no padding, 16-byte LDS reads
     float* sq = smem;                 // scaled q
     float* sk = OVERLAY ? smem : sq + Q * PH;
@@ -116,14 +120,14 @@ __global__ __launch_bounds__(NT) void mha_bwd_kernel(const MhaP p) {
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < HD; ++c) s += qr[c] * sk[j * PH + c];
-            spd[lane * PQ + j] = s;
+            spd[at(lane, j)] = s;
             mx = fmaxf(mx, s);
         }
         float sum = 0.f;
     #pragma unroll 4
     for (int j = 0; j < Q; ++j) {
-            const float e = __expf(spd[lane * PQ + j] - mx);
-            spd[lane * PQ + j] = e;
+            const float e = __expf(spd[at(lane, j)] - mx);
+            spd[at(lane, j)] = e;
             sum += e;
         }
         const float inv = 1.f / sum;
@@ -131,15 +135,15 @@ __global__ __launch_bounds__(NT) void mha_bwd_kernel(const MhaP p) {
         float dot = 0.f;
     #pragma unroll 4
     for (int j = 0; j < Q; ++j) {
-            const float pj = spd[lane * PQ + j] * inv;
+            const float pj = spd[at(lane, j)] * inv;
             float keep = 1.f;
             if (p.thresh) keep = drop_keep(p.seed ^ (p.seed_dev ? *p.seed_dev * 0x9E3779B1u : 0u), ibase + j, p.thresh) ? p.dscale : 0.f;
             float dpd = 0.f;
 #pragma unroll
             for (int c = 0; c < HD; ++c) dpd += dor[c] * sv[j * PH + c];
             const float dp = dpd * keep;
-            spd[lane * PQ + j] = pj * keep;
-            sds[lane * PQ + j] = dp;            // temporarily dP
+            spd[at(lane, j)] = pj * keep;
+            sds[at(lane, j)] = dp;            // temporarily dP
             dot += pj * dp;
         }
         float dqr[HD];
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(NT) void mha_bwd_kernel(const MhaP p) {
 #pragma unroll
             for (int c = 0; c < HD; ++c) s += qr[c] * sk[j * PH + c];
             const float pj = __expf(s - mx) * inv;
-            const float ds = pj * (sds[lane * PQ + j] - dot);
-            sds[lane * PQ + j] = ds;
+            const float ds = pj * (sds[at(lane, j)] - dot);
+            sds[at(lane, j)] = ds;
 #pragma unroll
             for (int c = 0; c < HD; ++c) dqr[c] += ds * sk[j * PH + c];
         }
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(NT) void mha_bwd_kernel(const MhaP p) {
         for (int c = 0; c < HD; ++c) { dkr[c] = 0.f; dvr[c] = 0.f; }
 #pragma unroll 4
         for (int i = 0; i < Q; ++i) {
-            const float ds = sds[i * PQ + lane], pd = spd[i * PQ + lane];
+            const float ds = sds[at(i, lane)], pd = spd[at(i, lane)];
 #pragma unroll
             for (int c = 0; c < HD; ++c) {
                 dkr[c] += ds * sq[i * PH + c];      // sq already carries the 1/sqrt(hd) scale
@@ -242,13 +246,21 @@ extern "C" int poet_mha_bwd(const float* q, const float* k, const float* v, int6
     POET_CHECK(q && k && v && dout && dq && dk && dv, POET_ERR_ARG, "mha_bwd: null pointer");
     p.q = q; p.k = k; p.v = v; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv; p.ld = ld; p.ld_out = ld_out; p.ld_d = ld_d;
     const bool two = Q > 64;                                            // two waves: k / v and q / d(out) share their LDS (OVERLAY)
-    const size_t lds = sizeof(float) * ((two ? 2 : 4) * Q * hd + 2 * Q * (Q + 1));
-    POET_CHECK(lds <= MHA_LDS_MAX, POET_ERR_UNSUPPORTED, "mha_bwd: Q=%d at head dim %d needs %zu bytes of LDS (> 160 KiB)", Q, hd, lds);
+    size_t lds = sizeof(float) * ((two ? 2 : 4) * Q * hd + 2 * Q * (Q + 1));
+    // swizzled score matrices (no pad column) where the padded ones do not fit: Q = 128 at head dim 32
+    const bool swz = two && lds > MHA_LDS_MAX && hd == 32 && Q % 64 == 0 && sizeof(float) * (2 * Q * hd + 2 * Q * Q) <= MHA_LDS_MAX;
+    if (swz) lds = sizeof(float) * (2 * Q * hd + 2 * Q * Q);
+    POET_CHECK(lds <= MHA_LDS_MAX, POET_ERR_UNSUPPORTED,
+               "mha_bwd: Q=%d at head dim %d needs %zu bytes of LDS (> 160 KiB; limits: Q <= 128 at head dim 16 / 32, Q <= 111 at head dim 64)", Q, hd, lds);
     dim3 grid(N * M);
     hipStream_t st = (hipStream_t)stream;
 #define POET_MHA_BWD(HD, NT, OV) do { mha_lds_attr(reinterpret_cast<const void*>(mha_bwd_kernel<HD, NT, OV>), lds);   \
                                       hipLaunchKernelGGL((mha_bwd_kernel<HD, NT, OV>), grid, dim3(NT), lds, st, p); } while (0)
     if (!two) { if (hd == 16) POET_MHA_BWD(16, 64, false); else if (hd == 32) POET_MHA_BWD(32, 64, false); else POET_MHA_BWD(64, 64, false); }
+    else if (swz) {
+        mha_lds_attr(reinterpret_cast<const void*>(mha_bwd_kernel<32, 128, true, true>), lds);
+        hipLaunchKernelGGL((mha_bwd_kernel<32, 128, true, true>), grid, dim3(128), lds, st, p);
+    }
     else { if (hd == 16) POET_MHA_BWD(16, 128, true); else if (hd == 32) POET_MHA_BWD(32, 128, true); else POET_MHA_BWD(64, 128, true); }
 #undef POET_MHA_BWD
     POET_LAUNCH_CHECK();

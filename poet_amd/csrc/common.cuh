@@ -116,6 +116,13 @@ template <> struct io<f16_t> {
     static __device__ __forceinline__ float ld(const f16_t* p) { return h_lo((uint32_t)p->v); }
     static __device__ __forceinline__ void st(f16_t* p, float v) { p->v = (uint16_t)(pack_h2(v, 0.f) & 0xffffu); }
 };
+template <> struct vec<f16_t, 4> {
+    static __device__ __forceinline__ void ld(const f16_t* p, float* o) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = h_lo(v.x); o[1] = h_hi(v.x); o[2] = h_lo(v.y); o[3] = h_hi(v.y);
+    }
+    static __device__ __forceinline__ void st(f16_t* p, const float* o) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3])); }
+};
 template <> struct vec<f16_t, 8> {
     static __device__ __forceinline__ void ld(const f16_t* p, float* o) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
@@ -168,5 +175,17 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): set it once per device a call site launches on --
+// `done` is the call site's own bitmask of device ordinals (a process-wide "already set" flag left the second GPU of a
+// single-process multi-GPU run without the attribute; idempotent, so a race between host threads is benign: ADVICE r5)
+static inline void lds_attr_once(const void* kern, int bytes, unsigned long long& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done |= bit;
+}
 
 }  // namespace poet

@@ -386,11 +386,8 @@ static void launch_one(const GemmK& p, hipStream_t st) {
     constexpr int LDS_ST = 2 * (BM + (SPLIT ? 2 : 1) * BN) * (BKB + 16), LDS_C = BM * (BN + 4) * 4;
     constexpr int LDS = LDS_ST > LDS_C ? LDS_ST : LDS_C;
     auto kern = gemm_kernel<TA, TB, TC, CT, BM, BN, BKB, AKM, BKM, SPLIT>;
-    static bool attr_set = false;          // per instantiation; idempotent, so a race between host threads is benign
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;          // per instantiation and device
+    lds_attr_once(reinterpret_cast<const void*>(kern), LDS, attr_done);
     const PoetGemmDesc& d = p.d;
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, p);

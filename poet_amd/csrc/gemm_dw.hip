@@ -353,12 +353,9 @@ bool gemm_dw_try(const GemmK& g, hipStream_t st) {
     const int nst = (p.rows + DW_RS - 1) / DW_RS;
     if (p.splits > nst) p.splits = nst;
     const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE);
-        attr_set = true;
-    }
+    static unsigned long long attr_done[2] = {0, 0};
+    lds_attr_once(reinterpret_cast<const void*>(gemm_dw_kernel<false>), 2 * DW_STAGE, attr_done[0]);
+    lds_attr_once(reinterpret_cast<const void*>(gemm_dw_kernel<true>), 2 * DW_STAGE, attr_done[1]);
     // partial tiles through the caller's workspace when it is large enough (PoetGemmDesc.workspace), else fp32 atomics
     const int64_t need = (int64_t)p.splits * p.ntiles * DW_T * DW_T * 4;
     static const int no_ws = [] { const char* e = getenv("POET_DW_NO_WORKSPACE"); return e && atoi(e) ? 1 : 0; }();

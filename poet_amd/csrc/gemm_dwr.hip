@@ -649,11 +649,8 @@ bool gemm_dwr_try(const GemmK& g, hipStream_t st) {
     p.ws = reinterpret_cast<float*>(d.workspace);
     p.wsb = sums ? p.ws + tile_bytes / 4 : nullptr;
     const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dwr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R_NST * R_STAGE);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    lds_attr_once(reinterpret_cast<const void*>(gemm_dwr_kernel), R_NST * R_STAGE, attr_done);
     hipLaunchKernelGGL(gemm_dwr_kernel, dim3(nblocks), dim3(R_NT), R_NST * R_STAGE, st, p);
     hipLaunchKernelGGL(dwr_reduce_kernel, dim3(R_TILE_F / 256, p.ntiles), dim3(256), 0, st, p);
     return true;
@@ -702,11 +699,8 @@ extern "C" int poet_linear_bwd(const void* dy, int64_t ldy, const void* x, int64
     p.ws = reinterpret_cast<float*>(workspace);
     p.wsb = db ? p.ws + tile_bytes / 4 : nullptr;
     const int nblocks = ((p.splits + 7) / 8) * p.ntiles * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dwx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    lds_attr_once(reinterpret_cast<const void*>(gemm_dwx_kernel), X_LDS, attr_done);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gemm_dwx_kernel, dim3(nblocks), dim3(R_NT), X_LDS, st, p);
     hipLaunchKernelGGL(dwr_reduce_kernel, dim3(R_TILE_F / 256, p.ntiles), dim3(256), 0, st, p);

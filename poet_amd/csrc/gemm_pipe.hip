@@ -55,7 +55,7 @@ struct PipeP {
     const bf16_t* A;
     const bf16_t* W;
     const bf16_t* Wlo;
-    float* C;
+    float* C;                        // (HOUT kernels: fp16 storage behind the same pointer)
     const float* bias;
     int64_t lda, ldb, ldc;           // elements
     int M, K;
@@ -83,8 +83,11 @@ __device__ __forceinline__ void gload16(f32x4_t& dst, uint32_t voff, const void*
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW >
+// HOUT (round 6): C is stored as IEEE fp16 (PoetGemmDesc.c_f16; plain write only) -- the LayerNorm that reads it next takes 2 bytes per
+// element instead of 4 on both sides; a lane's 4 consecutive columns leave as one 8-byte store, 32 contiguous bytes per row
+template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW, bool HOUT = false>
 __global__ __launch_bounds__(PIPE_NT, 3) void gemm_pipe_kernel(const PipeP p) {
+    static_assert(!(HOUT && ACC), "fp16 output: plain write only");
     constexpr int ROWB = BK * 2, CPR = ROWB / 16;
     constexpr int NLT = 128;                                           // threads per loader role (2 waves)
     constexpr int NA = (PIPE_MAXF * 16 * CPR + NLT - 1) / NLT;         // DMA instructions per loader thread and stage
@@ -216,8 +219,9 @@ __global__ __launch_bounds__(PIPE_NT, 3) void gemm_pipe_kernel(const PipeP p) {
             w_rd[j] = krl * 512 + (((piece ^ sw) & 7) | (piece & 8)) * 32 + (m16 & 3) * 8;
         }
     }
-    const int ldcB = (int)p.ldc * 4;
-    const uint32_t c_col = (uint32_t)((wave * NJ * 16 + kc * 4) * 4);   // + j * 64 bytes
+    constexpr int CES = HOUT ? 2 : 4;                                   // bytes per stored element
+    const int ldcB = (int)p.ldc * CES;
+    const uint32_t c_col = (uint32_t)((wave * NJ * 16 + kc * 4) * CES);   // + j * 16 * CES bytes
 
     int a_slot = 0, w_slot = 0;
     auto run_tile = [&](auto nf_tag, int ti) {
@@ -301,7 +305,12 @@ __global__ __launch_bounds__(PIPE_NT, 3) void gemm_pipe_kernel(const PipeP p) {
         for (int i = 0; i < NF; ++i)
             if (i * 16 + mo < rv) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4_t*>(cb + (uint32_t)((i * 16 + mo) * ldcB) + c_col + j * 64) = acc[i][j];
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (HOUT)
+                        *reinterpret_cast<uint2*>(cb + (uint32_t)((i * 16 + mo) * ldcB) + c_col + j * 32) =
+                            make_uint2(pack_h2(acc[i][j][0], acc[i][j][1]), pack_h2(acc[i][j][2], acc[i][j][3]));
+                    else *reinterpret_cast<f32x4_t*>(cb + (uint32_t)((i * 16 + mo) * ldcB) + c_col + j * 64) = acc[i][j];
+                }
             }
     };
 
@@ -334,17 +343,14 @@ int pipe_cus() {
     return n;
 }
 
-template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW >
+template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW, bool HOUT = false>
 void pipe_launch(const PipeP& p, int grid, hipStream_t st) {
     constexpr int NA = (PIPE_MAXF * 16 * (BK / 8) + 127) / 128;
     constexpr int LDS = NSTA * NA * 2048 + NSTW * (SPLIT ? 2 : 1) * BK * 512;
     static_assert(LDS <= 163840, "LDS rings");
-    auto kern = gemm_pipe_kernel<BK, WKM, SPLIT, ACC, NSTA, NSTW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    auto kern = gemm_pipe_kernel<BK, WKM, SPLIT, ACC, NSTA, NSTW, HOUT>;
+    static unsigned long long attr_done = 0;
+    lds_attr_once(reinterpret_cast<const void*>(kern), LDS, attr_done);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PIPE_NT), LDS, st, p);
 }
 
@@ -369,7 +375,9 @@ bool gemm_pipe_try(const GemmK& g, hipStream_t st) {
     static const int disabled = [] { const char* e = getenv("POET_GEMM_NO_PIPE"); return e && atoi(e) ? 1 : 0; }();
     if (disabled) return false;
     // plain long-K products: bf16 operands, fp32 result written (+ bias) or accumulated in place
-    if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || d.c_dtype != POET_F32 || d.compute != POET_BF16) return false;
+    // (round 6: or an fp16 result -- c_dtype POET_BF16 with c_f16 -- of the forward form, plain write)
+    const bool hout = d.c_dtype == POET_BF16 && d.c_f16 && !d.b_kmajor && !d.add_src;
+    if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || (d.c_dtype != POET_F32 && !hout) || d.compute != POET_BF16) return false;
     if (d.a_kmajor || d.batch != 1 || d.splitk != 1 || d.atomic || d.A2) return false;
     if (d.act || d.gate_ref || d.row_mask || d.drop_p != 0.f || d.out_mode != 0 || d.alpha != 1.f) return false;
     if (d.bias && d.add_src) return false;
@@ -394,6 +402,11 @@ bool gemm_pipe_try(const GemmK& g, hipStream_t st) {
     static const int cfg = [] { const char* e = getenv("POET_PIPE_CFG"); return e ? atoi(e) : 0; }();
     const bool acc = d.add_src != nullptr, split = d.b_split != 0;
     const int key = (d.b_kmajor ? 4 : 0) | (split ? 2 : 0) | (acc ? 1 : 0);
+    if (hout) {                                                         // (the default ring depths; POET_PIPE_CFG applies to the fp32 forms)
+        if (split) pipe_launch<32, false, true, false, 3, 3, true>(p, grid, st);
+        else pipe_launch<32, false, false, false, 5, 5, true>(p, grid, st);
+        return true;
+    }
     switch (key) {
         case 0: pipe_dispatch<false, false, false>(p, grid, cfg, st); break;
         case 1: pipe_dispatch<false, false, true>(p, grid, cfg, st); break;

@@ -379,12 +379,9 @@ static bool dw64_ok(const void* X, int64_t ldx, int n2, int rows) {
     return !off && n2 % 4 == 0 && n2 >= 4 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && rows <= 1024;
 }
 static void dw64_attr() {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_dw64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_dw64_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
+    static unsigned long long attr_done[2] = {0, 0};
+    lds_attr_once(reinterpret_cast<const void*>(gemm_small_dw64_kernel), 64 * 1024, attr_done[0]);
+    lds_attr_once(reinterpret_cast<const void*>(gemm_small_dw64_list_kernel), 64 * 1024, attr_done[1]);
 }
 
 bool gemm_small_dw_list(const float* const* Y, const float* const* X, float* const* C, float* const* ysum, int n, int n_out, int k_in,
@@ -436,8 +433,8 @@ bool gemm_small_try(const GemmK& p, hipStream_t st) {
             nw = nw < 4 ? 4 : (nw > 16 ? 16 : nw);
             const int kw = (((d.K + nw - 1) / nw) + 15) / 16 * 16;
             const int tiles64 = ((d.M + 15) >> 4) * ((d.N + BKM_TN - 1) / BKM_TN);
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_bkm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
+            static unsigned long long attr_done = 0;
+            lds_attr_once(reinterpret_cast<const void*>(gemm_small_bkm_kernel), 64 * 1024, attr_done);
             hipLaunchKernelGGL(gemm_small_bkm_kernel, dim3(tiles64, d.batch), dim3(64 * nw), (size_t)nw * 4096, st, p, kw);
             return true;
         }

@@ -761,11 +761,8 @@ template <typename TC, int KIND, bool WKM, bool SPLIT, int BN = 128, int NTH = 5
 bool wsk_launch(const GemmK& p, hipStream_t st) {
     constexpr int LDS = 2 * (SPLIT ? 2 : 1) * BN * (4 * 64) + BN * 4;
     auto kern = gemm_wsk_kernel<TC, KIND, WKM, SPLIT, BN, NTH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;          // per instantiation and device
+    lds_attr_once(reinterpret_cast<const void*>(kern), LDS, attr_done);
     const int NT = p.d.N / BN, RB = (p.d.M + NTH / 2 - 1) / (NTH / 2);
     const int nblocks = ((RB + 7) / 8) * NT * 8;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTH), LDS, st, p);
@@ -805,11 +802,8 @@ template <typename TC, int KIND, bool WKM, int FM, int NTH, bool SPLIT = false, 
 void ws_launch_cfg(const GemmK& p, int nblocks, hipStream_t st) {
     constexpr int LDS = (SPLIT ? 2 : 1) * BN * (8 * 64) + BN * 4;
     auto kern = gemm_ws_kernel<TC, KIND, WKM, FM, NTH, SPLIT, BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;          // per instantiation and device
+    lds_attr_once(reinterpret_cast<const void*>(kern), LDS, attr_done);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTH), LDS, st, p);
 }
 
@@ -831,11 +825,8 @@ template <typename TC, bool ACT, bool DROP>
 void wsp_launch(const GemmK& p, int nblocks, hipStream_t st) {
     constexpr int LDS = 2 * 128 * 512 + 128 * 4;
     auto kern = gemm_wsp_kernel<TC, ACT, DROP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;          // per instantiation and device
+    lds_attr_once(reinterpret_cast<const void*>(kern), LDS, attr_done);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), LDS, st, p);
 }
 
@@ -887,9 +878,14 @@ bool ws_kind(const GemmK& p, int nblocks, hipStream_t st) {
     const PoetGemmDesc& d = p.d;
     const int kind = (d.gate_ref ? WS_GATE : 0) | (d.add_src ? WS_ADD : 0) | (d.row_mask ? WS_MASK : 0);
     if constexpr (sizeof(TC) == 2) {
-        // fp16 outputs (c_f16): the split-weight forward without epilogue operands, specialised on the output type; anything else
-        // goes to the generic kernel
-        if (d.c_f16) return (d.b_split && kind == 0) ? ws_launch_split<f16_t, 0>(p, st) : false;
+        // fp16 outputs (c_f16): the forward without add_src / gate_ref, specialised on the output type; anything else goes to the
+        // generic kernel
+        // (round 6: + the row-masked head-major form = the encoder's fp16 value maps, split or single-image weights)
+        if (d.c_f16) {
+            if (d.b_split) return kind == 0 ? ws_launch_split<f16_t, 0>(p, st) : kind == WS_MASK ? ws_launch_split<f16_t, WS_MASK>(p, st) : false;
+            if (d.b_kmajor) return false;
+            return kind == 0 ? ws_launch<f16_t, 0, false>(p, nblocks, st) : kind == WS_MASK ? ws_launch<f16_t, WS_MASK, false>(p, nblocks, st) : false;
+        }
     }
     if (d.b_split) {
         switch (kind) {

@@ -44,6 +44,7 @@ struct MsdaP {
     int parts;           // backward: bit0 = d(offsets|logits)/d(loc,attn) kernel, bit1 = d(value) scatter kernel
     int gv_bf16;         // grad_value is bf16 (LDS-tiled scatter only): windows and far corners leave through packed bf16x2 atomics
     int q_f16;           // fused, encoder shape: the offsets | logits buffer q1 holds IEEE fp16 (POET_F16), its gradient g1 stays bf16
+    int v_f16;           // fused, encoder shape: the value maps hold IEEE fp16 (POET_F16; shared-geometry gathers only)
 };
 
 // a packed pair of 2-byte storage values -> two floats: bf16 (shift / mask) or fp16 (v_cvt_f32_f16); QH is a kernel template
@@ -420,6 +421,52 @@ __device__ __forceinline__ float dot8_packed(const u32x4_t& a, const u32x4_t& b)
     return d;
 }
 
+// ---- fp16 value maps (MsdaP::v_f16, round 6) ----------------------------------------------------------------------------------
+// acc += w * (fp16 half of v): v_fma_mix_f32 converts the selected half on the way into the FMA -- no unpack instruction at all
+// (a bf16 pair costs v_and + v_lshl before its two FMAs: 4 VALU per pair against 2, and the encoder gathers are VALU-issue bound)
+__device__ __forceinline__ void fmix_lo(float& acc, uint32_t v, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(v), "v"(w));
+}
+__device__ __forceinline__ void fmix_hi(float& acc, uint32_t v, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(v), "v"(w));
+}
+// sum over 8 channels of a[ch] * b[ch], both operands packed fp16 pairs (exact products, fp32 sum)
+__device__ __forceinline__ float dot8_packed_h(const u32x4_t& a, const u32x4_t& b) {
+    float d = 0.f;
+    asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(d) : "v"(a[0]), "v"(b[0]));
+    asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(d) : "v"(a[1]), "v"(b[1]));
+    asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(d) : "v"(a[2]), "v"(b[2]));
+    asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(d) : "v"(a[3]), "v"(b[3]));
+    return d;
+}
+// The backward's <grad_out, value> products want both operands in ONE 2-byte format.  grad_out arrives as bf16 with the full fp32
+// exponent range (gradients of 1e-7 are routine), so it cannot simply be re-typed: the 16 channels of a (query, head) -- the 8 of
+// this lane and the 8 of its channel-half partner, lane ^ 1 -- are rescaled by a common power of two that puts their largest
+// exponent at 2^14, in the integer domain on the packed pairs (|x| = exponent:8 | mantissa:7 -> subtract K << 7 with unsigned
+// saturation, shift left by 3 into exponent:5 | mantissa:10; what falls below 2^-28 of the largest channel becomes zero), and the
+// owner lane multiplies the inverse scale back into d(offsets) / d(logits).  bf16 -> fp16 is exact for everything kept (7 -> 10
+// mantissa bits); ~30 VALU per pass.  Returns the inverse scale.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+__device__ __forceinline__ float g_to_f16_scaled(u32x4_t& g) {
+    const uint32_t a0 = g[0] & 0x7fff7fffu, a1 = g[1] & 0x7fff7fffu, a2 = g[2] & 0x7fff7fffu, a3 = g[3] & 0x7fff7fffu;
+    uint32_t mx = pk_max_u16(pk_max_u16(a0, a1), pk_max_u16(a2, a3));
+    mx = max(mx & 0xffffu, mx >> 16);
+    mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0xB1, 0xf, 0xf, true));       // the other channel half of the head
+    const int kexp = max((int)(mx >> 7) - 29, 0);                                                   // (mx < 2^15: exponent = bits 14..7)
+    const uint32_t k1 = (uint32_t)kexp << 7, kpk = k1 | (k1 << 16);
+    const uint32_t a[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const us2_t d = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2_t, a[j]), __builtin_bit_cast(us2_t, kpk));
+        const us2_t sh = d << (unsigned short)3;
+        g[j] = (g[j] & 0x80008000u) | __builtin_bit_cast(uint32_t, sh);
+    }
+    return __uint_as_float((uint32_t)(kexp + 15) << 23);            // fp16 value = bf16 value * 2^(112 - kexp)
+}
+
 // LDS traffic between lanes of ONE wave needs no s_barrier (the LDS ops of a wave execute in order); this only stops the
 // compiler from moving accesses across
 __device__ __forceinline__ void sh_wave_sync() {
@@ -512,7 +559,7 @@ struct ShMap {
     }
 };
 
-template <int QG, bool QH>
+template <int QG, bool QH, int VH>       // VH: 0 bf16 value maps, 1 fp16 (v_fma_mix_f32), 2 fp16 with the 8 terms of a level summed in packed fp16 first
 __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const MsdaP p) {
     __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -545,13 +592,32 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
             Raw8<bf16_t> v0[4], v1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
+            uint32_t t16[4] = {0u, 0u, 0u, 0u};                     // (VH == 2) this level's 8 terms per channel, packed fp16
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float w0 = __uint_as_float(r[i].z), w1 = __uint_as_float(r[i].w);
+                if constexpr (VH == 2) {
+                    const uint32_t wp = pack_h2(w0, w1);
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[i].f(ch), acc[ch]);
+                    for (int j = 0; j < 4; ++j) {
+                        asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(t16[j]) : "v"(v0[i].v[j]), "v"(wp));
+                        asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(t16[j]) : "v"(v1[i].v[j]), "v"(wp));
+                    }
+                } else if constexpr (VH == 1) {
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
+                    for (int j = 0; j < 4; ++j) { fmix_lo(acc[2 * j], v0[i].v[j], w0); fmix_hi(acc[2 * j + 1], v0[i].v[j], w0); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { fmix_lo(acc[2 * j], v1[i].v[j], w1); fmix_hi(acc[2 * j + 1], v1[i].v[j], w1); }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w0, v0[i].f(ch), acc[ch]);
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
+                }
+            }
+            if constexpr (VH == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { fmix_lo(acc[2 * j], t16[j], 1.f); fmix_hi(acc[2 * j + 1], t16[j], 1.f); }
             }
         }
         sh_wave_sync();                                             // (the next pass overwrites the records)
@@ -564,7 +630,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
     }
 }
 
-template <int QG, bool QH>
+template <int QG, bool QH, bool VH>
 __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const MsdaP p) {
     __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -586,7 +652,9 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
         const ShRaw raw = sh_load(p, mp.row, m, o);
         sh_prepare<true, QH>(p, raw, rf, mp.n, m, lane, wlds, gk);
         // grad_out stays packed: <grad_out, value> over a lane's 8 channels is 4 v_dot2c_f32_bf16 (exact bf16 products, fp32 sum)
-        const u32x4_t g = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.grad_out) + (int64_t)mp.row * 256 + m * 16 + dsub * 8);
+        u32x4_t g = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.grad_out) + (int64_t)mp.row * 256 + m * 16 + dsub * 8);
+        float ginv = 1.f;                                          // fp16 value maps: grad_out re-typed to fp16 under a per-head power-of-two scale
+        if constexpr (VH) ginv = g_to_f16_scaled(g);
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
             char* slot = slot0 + sh_slot(pair, l);
@@ -598,7 +666,8 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
             for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
 #pragma unroll
             for (int i = 0; i < 4; ++i)     // this lane's partial <grad_out, value> of the upper / lower corner, into its half of the slot it consumed
-                *reinterpret_cast<float2*>(slot + (l * 4 + i) * 256 + dsub * 8) = make_float2(dot8_packed(g, v0[i].v), dot8_packed(g, v1[i].v));
+                *reinterpret_cast<float2*>(slot + (l * 4 + i) * 256 + dsub * 8) =
+                    VH ? make_float2(dot8_packed_h(g, v0[i].v), dot8_packed_h(g, v1[i].v)) : make_float2(dot8_packed(g, v0[i].v), dot8_packed(g, v1[i].v));
         }
         sh_wave_sync();
         // owner lane (pair, level o): d(offsets) and d(attention) of its 4 points
@@ -615,8 +684,10 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_bwd_shared_kernel(const Ms
             const float e0 = D10 - D00, e1 = D11 - D01;
             const float T0 = fmaf(fy, e0, D00), T1 = fmaf(fy, e1, D01);
             da[i] = fmaf(fx, T1 - T0, T0);                                // (1-fx) T0 + fx T1
-            dxy[2 * i] = aw * (T1 - T0);                                  // d/d(offset) = (dpx, dpy): the W,H factors cancel
-            dxy[2 * i + 1] = aw * fmaf(fx, e1 - e0, e0);                  // aw ((1-fx) e0 + fx e1)
+            if constexpr (VH) da[i] *= ginv;                              // (the dot products carry grad_out's scale: the quad shares it)
+            const float aws = VH ? aw * ginv : aw;
+            dxy[2 * i] = aws * (T1 - T0);                                 // d/d(offset) = (dpx, dpy): the W,H factors cancel
+            dxy[2 * i + 1] = aws * fmaf(fx, e1 - e0, e0);                 // aw ((1-fx) e0 + fx e1)
             dot = fmaf(aw, da[i], dot);
         }
         sh_wave_sync();                                                   // (the next pass overwrites the slots)
@@ -1154,16 +1225,15 @@ static bool launch_dv_tiled(const MsdaP& p, int P, hipStream_t st) {
     { const char* e = getenv("POET_DV_SKIP"); tp.skip = e ? atoi(e) : 0; }
 #endif
     if (!lds) return false;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_dv_tiled_kernel<TQ, L, false>), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_dv_tiled_kernel<TQ, L, true>), hipFuncAttributeMaxDynamicSharedMemorySize, POET_DV_LDS_BYTES + 2048);
-        attr_set = true;
-    }
+    const dim3 grid(tp.TX * tp.TY * p.M * p.N), blk(TILED_NT);
     static const int order = [] { const char* e = getenv("POET_DV_ORDER"); return e ? atoi(e) : 1; }();         // (A/B aid, read once: 0 = the (tiles, M, N) grid order)
     tp.order = order;
-    if (p.q_f16) hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, true>), dim3(tp.TX * tp.TY * p.M * p.N), dim3(TILED_NT), lds, st, p, tp);
-    else hipLaunchKernelGGL((msda_bwd_dv_tiled_kernel<TQ, L, false>), dim3(tp.TX * tp.TY * p.M * p.N), dim3(TILED_NT), lds, st, p, tp);
+#define POET_DV_LAUNCH(QH_) do { auto kern = msda_bwd_dv_tiled_kernel<TQ, L, QH_>;                                                          \
+        static unsigned long long attr_done = 0;                             /* per instantiation and device */                            \
+        lds_attr_once(reinterpret_cast<const void*>(kern), POET_DV_LDS_BYTES + 2048, attr_done);                                            \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, p, tp); } while (0)
+    if (p.q_f16) POET_DV_LAUNCH(true); else POET_DV_LAUNCH(false);
+#undef POET_DV_LAUNCH
     return true;
     }
 }
@@ -1365,8 +1435,8 @@ static void launch_gen(const MsdaP& p, int L, int P, hipStream_t st) {
     if constexpr (BWD) {
         const size_t lds = FUSED ? (size_t)L * P * 256 * sizeof(float) : 0;
         auto kern = msda_gen_bwd_kernel<TV, TQ, FUSED>;
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 4); attr_set = true; }
+        static unsigned long long attr_done = 0;
+        lds_attr_once(reinterpret_cast<const void*>(kern), 64 * 256 * 4, attr_done);
         hipLaunchKernelGGL(kern, grid, block, lds, st, p, L, P);
     } else {
         hipLaunchKernelGGL((msda_gen_fwd_kernel<TV, TQ, FUSED>), grid, block, 0, st, p, L, P);
@@ -1437,16 +1507,19 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
             { const char* e = getenv("POET_SH_PADLDS"); if (e) dyn = (size_t)atoi(e); }     // experiment: extra LDS per workgroup (lowers the occupancy)
 #endif
             const dim3 grid((unsigned)((rows + SH_WAVES * qg - 1) / (SH_WAVES * qg))), blk(SH_WAVES * 64);
-#define POET_SH_LAUNCH(Q, H) do { if (BWD) hipLaunchKernelGGL((msda_bwd_shared_kernel<Q, H>), grid, blk, dyn, st, p); \
-                                  else hipLaunchKernelGGL((msda_fwd_shared_kernel<Q, H>), grid, blk, dyn, st, p); } while (0)
-            if (p.q_f16) { if (qg == 1) POET_SH_LAUNCH(1, true); else POET_SH_LAUNCH(4, true); }
-            else if (qg == 1) POET_SH_LAUNCH(1, false);
-            else POET_SH_LAUNCH(4, false);
+#define POET_SH_LAUNCH(Q, H, V) do { if (BWD) hipLaunchKernelGGL((msda_bwd_shared_kernel<Q, H, V>), grid, blk, dyn, st, p); \
+                                     else hipLaunchKernelGGL((msda_fwd_shared_kernel<Q, H, V>), grid, blk, dyn, st, p); } while (0)
+            static const int f16pk = [] { const char* e = getenv("POET_SH_F16_PK"); return e ? atoi(e) : 0; }();       // (A/B aid, read once)
+            if (p.v_f16 && !BWD && f16pk && qg == 4) { hipLaunchKernelGGL((msda_fwd_shared_kernel<4, true, 2>), grid, blk, dyn, st, p); return; }
+            if (p.v_f16) { if (qg == 1) POET_SH_LAUNCH(1, true, true); else POET_SH_LAUNCH(4, true, true); }      // (fp16 maps come with fp16 offsets | logits)
+            else if (p.q_f16) { if (qg == 1) POET_SH_LAUNCH(1, true, false); else POET_SH_LAUNCH(4, true, false); }
+            else if (qg == 1) POET_SH_LAUNCH(1, false, false);
+            else POET_SH_LAUNCH(4, false, false);
 #undef POET_SH_LAUNCH
             return;
         }
     }
-    if (p.q_f16) { g_f16_refused = true; return; }
+    if (p.q_f16 || p.v_f16) { g_f16_refused = true; return; }
     if (P == 4) {
         if (BWD) hipLaunchKernelGGL((msda_bwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
         else hipLaunchKernelGGL((msda_fwd_kernel<TV, TQ, L, 4, FUSED>), gridf, block, 0, st, p);
@@ -1462,7 +1535,7 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
 template <typename TV, typename TQ, bool FUSED, bool BWD>
 static void launch_l(const MsdaP& p, int L, int P, hipStream_t st) {
     if (L > 4 || !(P == 1 || P == 2 || P == 4)) {             // outside the instantiated kernels: the generic ones
-        if (p.q_f16) { g_f16_refused = true; return; }
+        if (p.q_f16 || p.v_f16) { g_f16_refused = true; return; }
         launch_gen<TV, TQ, FUSED, BWD>(p, L, P, st);
         return;
     }
@@ -1477,16 +1550,17 @@ static void launch_l(const MsdaP& p, int L, int P, hipStream_t st) {
 template <bool FUSED, bool BWD>
 static int dispatch(const MsdaP& p, int L, int P, int v_dtype, int q_dtype, hipStream_t st) {
     {   // the gather kernels address the value maps with 32-bit byte offsets and 24-bit pixel arithmetic
-        const int64_t esz = v_dtype == POET_BF16 ? 2 : 4;
+        const int64_t esz = (v_dtype == POET_BF16 || v_dtype == POET_F16) ? 2 : 4;
         const int64_t span = ((int64_t)(p.N - 1) * p.vs_n + (int64_t)(p.M - 1) * p.vs_m + (int64_t)(p.S - 1) * p.vs_s + p.D) * esz;
         POET_CHECK(span < (1ll << 32) && p.vs_s * esz < (1 << 24) && p.S < (1 << 24) && p.vs_n >= 0 && p.vs_m >= 0 && p.vs_s > 0,
                    POET_ERR_UNSUPPORTED, "msda: value maps of %lld bytes exceed the 4 GiB (32-bit offset) limit of the gather kernels",
                    (long long)span);
     }
     g_f16_refused = false;
-    if (v_dtype == POET_BF16 && q_dtype == POET_F16 && FUSED) {
+    if ((v_dtype == POET_BF16 || v_dtype == POET_F16) && q_dtype == POET_F16 && FUSED) {
         MsdaP ph = p;
         ph.q_f16 = 1;
+        ph.v_f16 = v_dtype == POET_F16;                       // (round 6) fp16 value maps: the shared-geometry gathers' own format
         launch_l<bf16_t, bf16_t, FUSED, BWD>(ph, L, P, st);
         POET_CHECK(!g_f16_refused, POET_ERR_UNSUPPORTED,
                    "msda_fused: fp16 offsets | logits (q_dtype POET_F16) need the encoder shape (bf16 value maps, 16 heads x 16 channels, 4 levels x 4 points, "

@@ -473,7 +473,10 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
     dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16)
-    if (dtype_z == dtype_x) {
+    if (dtype_x == POET_F16) {      // (round 6) the branch stored as IEEE fp16 by the projection (PoetGemmDesc.c_f16): fp32 stream, bf16 saved sum
+        POET_CHECK(dtype_r == POET_F32 && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED, "ln_fwd: an fp16 branch comes with an fp32 stream and a bf16 saved sum (%d,%d,%d)", dtype_x, dtype_r, dtype_z);
+        ln_fwd_kernel<f16_t, float, bf16_t><<<grid, block, 0, st>>>((const f16_t*)x, (const float*)res, gamma, beta, (float*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16);
+    } else if (dtype_z == dtype_x) {
         POET_DT2(dtype_x, dtype_r, LN_FWD);
     } else {        // fp32 branch input (the GEMM's accumulators, never rounded to bf16) with the pre-norm sum saved in bf16 for backward
         POET_CHECK(dtype_x == POET_F32 && dtype_r == POET_F32 && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED, "ln_fwd: dtype triple (%d,%d,%d)", dtype_x, dtype_r, dtype_z);

@@ -397,9 +397,17 @@ def linear_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, *, rows: int,
         D.record(dy, x, dW, db, rows, ldy, ldx)
         return dW
     n_out, k_in = dW.shape
-    SIDE.run(lambda: gemm(dy, x, dW, n_out, k_in, rows, lda=ldy or n_out, ldb=ldx or k_in, ldc=k_in, a_kmajor=True,
+    if seg is not None and len(seg[1]) - 1 > 8:
+        raise ValueError("linear_dw: seg_sums carries at most 8 segments (PoetGemmDesc.seg_start[10])")
+    launch = lambda: gemm(dy, x, dW, n_out, k_in, rows, lda=ldy or n_out, ldb=ldx or k_in, ldc=k_in, a_kmajor=True,
                           b_kmajor=True, splitk=_splitk_for(n_out, k_in, rows), atomic=True, bias=db, seg=seg,
-                          b_alt=None if x_alt is None else (x_alt[0], x_alt[0].stride(0), x_alt[1])), dy, x)
+                          b_alt=None if x_alt is None else (x_alt[0], x_alt[0].stride(0), x_alt[1]))
+    if seg is not None:
+        # the per-segment sums are READ by the caller's next launches (colsum -> bias gradients, level_embed products): this launch
+        # belongs on the caller's stream even when weight gradients otherwise fork (POET_SIDE_STREAM=1) -- ADVICE r5
+        launch()
+    else:
+        SIDE.run(launch, dy, x, *(() if x_alt is None else (x_alt[0],)))
     return dW
 
 
@@ -595,6 +603,18 @@ def oa_f16(M, D, L, P, grid_queries) -> bool:
     return bool(grid_queries and M == 16 and D == 16 and L == 4 and P == 4 and env("POET_OA_BF16", "0") in ("", "0")
                 and env("POET_MSDA_NO_SHARED", "0") in ("", "0") and env("POET_NO_TILED_SCATTER", "0") in ("", "0")
                 and env("POET_WIN_GATHER", "0") in ("", "0"))
+
+
+def v_f16(M, D, L, P, grid_queries) -> bool:
+    """fp16 storage of the encoder's value maps (round 6): wherever the offsets | logits are fp16 (oa_f16: the shared-geometry
+    gathers are then the only readers of the maps) and POET_V_BF16=1 does not ask for bf16 (A/B aid)."""
+    return oa_f16(M, D, L, P, grid_queries) and os.environ.get("POET_V_BF16", "0") in ("", "0")
+
+
+def ln_f16(rows, d) -> bool:
+    """fp16 storage of the projection output that a LayerNorm launch consumes (the encoder's two per layer): POET_LN_F32=1 keeps the
+    fp32 accumulators (A/B aid)."""
+    return rows >= 4096 and d == 256 and os.environ.get("POET_LN_F32", "0") in ("", "0")
 
 
 def tiled_scatter_bf16() -> bool:

@@ -433,9 +433,11 @@ def test_groupnorm(ops, dtype):
 
 # ---------------------------------------------------------------------------------------------- MHA
 @pytest.mark.parametrize("Q,M,hd", [(20, 16, 16), (10, 4, 64), (6, 4, 16), (50, 8, 32), (64, 16, 16), (65, 4, 16), (100, 16, 16), (128, 16, 16), (100, 8, 32),
-                                    (70, 4, 64)])
+                                    (70, 4, 64), (128, 8, 32), (111, 4, 64)])
 def test_mha(ops, Q, M, hd):
-    """(Q > 64: two waves per (image, head); backward with k / v and q / d(out) sharing their LDS; `--num_queries`, main.py:98)"""
+    """(Q > 64: two waves per (image, head); backward with k / v and q / d(out) sharing their LDS; `--num_queries`, main.py:98.
+    (128, 8, 32) = the reference's default head geometry (hidden 256 / nheads 8) at the largest query count: the backward's score
+    matrices fill the CU's 160 KB exactly (swizzled, no pad column); (111, 4, 64): the largest Q the backward takes at head dim 64.)"""
     N, d = 3, M * hd
     packed = _rand(N * Q, 3 * d, seed=40)
     pk = dev(packed)
@@ -451,6 +453,23 @@ def test_mha(ops, Q, M, hd):
     dpk = torch.empty_like(pk)
     ops.mha_bwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, dev(dout), d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, hd)
     _close(dpk, p32.grad, torch.float32, msg="mha bwd")
+
+
+def test_mha_limits_are_refused_not_misrun(ops):
+    """Q > 128, head dims outside {16, 32, 64} and the backward at head dim 64 beyond 111 queries return POET_ERR_UNSUPPORTED."""
+    from poet_amd._lib import PoetHipError
+    for Q, M, hd, bwd_only in [(129, 4, 16, False), (20, 4, 24, False), (112, 4, 64, True)]:
+        N, d = 1, M * hd
+        pk = dev(_rand(N * Q, 3 * d, seed=44))
+        out = torch.empty(N * Q, d, device="cuda")
+        if not bwd_only:
+            with pytest.raises(PoetHipError):
+                ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd)
+        else:
+            ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd)        # (the forward holds one score matrix: fits)
+        dpk = torch.empty_like(pk)
+        with pytest.raises(PoetHipError):
+            ops.mha_bwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, hd)
 
 
 # ---------------------------------------------------------------------------------------------- encodings & misc
@@ -648,6 +667,33 @@ def test_layernorm_mixed(ops):
     ops.ln_bwd(dev(dy), z, mean, rstd, dev(gamma), dz, dx, dg, db, rows, d)
     _close(dz, zr.grad, torch.bfloat16, msg="mixed ln dz")
     _close(dx, zr.grad, torch.bfloat16, msg="mixed ln dx")
+
+
+@pytest.mark.parametrize("rows", [4096 + 3, 700])
+def test_layernorm_fp16_branch(ops, rows):
+    """(round 6) `x = norm(res + dropout(branch))` with the branch stored as IEEE fp16 by the projection before it (dtype_x POET_F16:
+    fp32 residual stream, bf16 saved sum, bf16 operand copy and next-layer query copy): equal to the fp32-branch launch on the
+    fp16-rounded values BIT FOR BIT (same kernel arithmetic, only the loader differs)."""
+    d = 256
+    x32 = _rand(rows, d, seed=70, scale=3.0)
+    res = _rand(rows, d, seed=71)
+    gamma, beta = 1.0 + 0.1 * _rand(d, seed=72), 0.1 * _rand(d, seed=73)
+    pos = _rand(rows, d, seed=74).to(torch.bfloat16)
+    x16 = x32.to(torch.float16)
+    for drop in (0.1, 0.0):
+        outs = []
+        for xd in (x16, x16.float()):
+            y = torch.empty(rows, d, device="cuda")
+            z = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+            y16, q16 = torch.empty_like(z), torch.empty_like(z)
+            mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+            ops.ln_fwd(dev(xd), dev(res), dev(gamma), dev(beta), y, z, mean, rstd, rows, d, 1e-5, drop, 1234, y16=y16, pos16=dev(pos), q16=q16)
+            outs.append((y, z, y16, q16, mean, rstd))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    ref = F.layer_norm(x16.float() + res, (d,), gamma, beta, 1e-5)                   # (the last pass ran without dropout)
+    assert (outs[0][0].cpu() - ref).abs().max().item() < 1e-5
+    assert torch.equal(outs[0][2].cpu(), outs[0][0].cpu().to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("shapes,m,dt", [([(12, 16), (6, 8), (3, 4)], 4, torch.float32), ([(30, 40), (15, 20), (8, 10), (4, 5)], 2, torch.bfloat16),
@@ -996,6 +1042,89 @@ def test_msda_fp16_offsets_logits_vs_explicit(ops):
     dbf = (res[torch.bfloat16] - exact).pow(2).mean().sqrt().item()
     print(f"   rms distance of the sampled output from the one of the unrounded offsets | logits: fp16 storage {d16:.2e}, bf16 storage {dbf:.2e}")
     assert d16 < 0.25 * dbf
+
+
+@pytest.mark.parametrize("gscale", ["unit", "tiny_mixed"])
+def test_msda_fp16_value_maps_vs_explicit(ops, gscale):
+    """Round 6: the encoder's value maps stored as IEEE fp16 (v_dtype POET_F16 with q_dtype POET_F16: shared-geometry forward by
+    v_fma_mix_f32 on the packed halves, d(offsets | logits) by v_dot2c_f32_f16 with grad_out re-typed bf16 -> fp16 under a per-
+    (query, head) power-of-two scale) against the float64 closed form on the SAME fp16 values.  tiny_mixed: grad_out spans 1e-9 ..
+    1e-2 across heads with one head all zero and single huge channels -- the rescaling must neither flush the small heads nor
+    overflow; what it may drop is below 2^-28 of a head's largest channel."""
+    m, d, p = 16, 16, 4
+    shapes, n = [(60, 80), (30, 40), (15, 20), (8, 10)], 2
+    L = len(shapes)
+    geom = ops.LevelGeom(shapes)
+    S = geom.S
+    rng = np.random.default_rng(31)
+    mlp = m * L * p
+    v32 = torch.from_numpy((rng.standard_normal((n, S, m, d)) * np.exp(rng.uniform(-3, 2, (n, S, m, 1)))).astype(np.float32))
+    th = np.arange(m) * (2 * np.pi / m)
+    grid = np.stack([np.cos(th), np.sin(th)], -1)
+    grid = grid / np.abs(grid).max(-1, keepdims=True)
+    base = (grid[:, None, None, :] * (np.arange(p) + 1)[None, None, :, None]).repeat(L, 1)
+    off = base[None, None] + 0.3 * rng.standard_normal((n, S, m, L, p, 2))
+    lg = rng.standard_normal((n, S, mlp))
+    oa = torch.from_numpy(np.concatenate([off.reshape(n, S, 2 * mlp), lg], -1).astype(np.float32)).to(torch.float16)
+    g = rng.standard_normal((n, S, m, d))
+    if gscale == "tiny_mixed":
+        g = g * (10.0 ** rng.uniform(-9, -2, (n, S, m, 1)))
+        g[:, :, 3] = 0.0                                         # a head without gradient
+        g[:, ::7, 5, 2] *= 3.0e4                                 # one channel 2^15 above the rest of its head
+        g[:, ::5, 9, :8] *= 1.0e-6                               # a channel HALF far below its partner half (the scale is per head, not per lane)
+    gout = torch.from_numpy(g.reshape(n, S, m * d).astype(np.float32)).to(torch.bfloat16)
+    ref = torch.empty(n, S, L, 2, device="cuda")
+    ops.enc_ref_points(dev(torch.ones(n, L, 2)), geom, ref, n)
+    vstr = (m * S * d, d, S * d)
+    errs = {}
+    for vdt in (torch.float16, torch.bfloat16):
+        value = v32.to(vdt)
+        out_ref, dv_ref, doa_ref, kink = _explicit_from_fused(shapes, value.float(), oa.float(), ref.cpu(), gout.float(), m, p)
+        vdev = dev(value.permute(0, 2, 1, 3).contiguous())
+        out = torch.empty(n, S, m * d, dtype=torch.bfloat16, device="cuda")
+        ops.msda_fused_fwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
+        gv = torch.zeros(n, m, S, d, device="cuda")
+        goa = torch.empty(n, S, 3 * mlp, dtype=torch.bfloat16, device="cuda")
+        ops.msda_fused_bwd(vdev, vstr, geom, dev(oa), 3 * mlp, 2 * mlp, ref, S * L * 2, dev(gout), gv, goa, n, m, d, p, S, grid_queries=True)
+        e_out = (out.double().cpu() - out_ref).abs().max().item() / out_ref.abs().max().item()
+        dq = goa.double().cpu()
+        ghead = gout.double().abs().reshape(n, S, m, d).amax(-1, keepdim=True)
+        # per-(query, head) scale of the reference gradient: the heads span 7 decades, a global max would hide the small ones
+        def rel(a, b, width, mask=None):
+            a, b = a.reshape(n, S, m, width), b.reshape(n, S, m, width)
+            e = (a - b).abs()
+            if mask is not None:
+                e = e * (~mask.reshape(n, S, m, width))
+            # (floor: 1e-3 of what the head's grad_out and the map's values can produce -- a head whose only in-range corner has a
+            # weight of 1e-8 carries a gradient of 1e-8 of the typical one, and fp32 sample positions round that corner away)
+            sc = torch.maximum(b.abs().amax(-1, keepdim=True), 1e-3 * ghead * float(value.float().abs().max()))
+            ok = ghead > 0
+            assert bool((a[~ok.expand_as(e)] == 0).all())       # a head without gradient gets exactly zero
+            r = torch.where(ok.expand_as(e), e / sc.clamp_min(1e-300), torch.zeros_like(e))
+            worst = int(r.argmax())
+            i0, i1, i2 = np.unravel_index(worst // width, (n, S, m))
+            rel.info = f"worst head (n {i0}, q {i1}, m {i2}): kernel {a[i0, i1, i2].tolist()} reference {b[i0, i1, i2].tolist()}"
+            return float(r.max())
+        e_off = rel(dq[..., : 2 * mlp], doa_ref[..., : 2 * mlp], 2 * L * p, kink)
+        e_lg = rel(dq[..., 2 * mlp:], doa_ref[..., 2 * mlp:], L * p)
+        info_lg = rel.info
+        e_dv = (gv.double().cpu().permute(0, 2, 1, 3) - dv_ref).abs().max().item() / dv_ref.abs().max().item()
+        print(f"value maps stored as {vdt}, grad_out {gscale}: rel max err out {e_out:.2e} d(off) {e_off:.2e} d(logit) {e_lg:.2e} (per head) dV {e_dv:.2e}")
+        assert bool(torch.isfinite(goa.float()).all()) and bool(torch.isfinite(out.float()).all())
+        errs[vdt] = (e_off, e_lg, e_out, info_lg)
+    for vdt, (e_off, e_lg, e_out, info_lg) in errs.items():
+        assert e_out < 6e-3 and e_off < 1.2e-2 and e_lg < 1.2e-2, (vdt, e_out, e_off, e_lg, info_lg)      # (bf16 rounding of the stored results, relative to the HEAD's max)
+    # the fp16 path is no worse than the bf16 one on the same problem (both are bound by the bf16 rounding of the stored gradient)
+    assert errs[torch.float16][0] < 1.5 * errs[torch.bfloat16][0] + 1e-3 and errs[torch.float16][1] < 1.5 * errs[torch.bfloat16][1] + 1e-3, errs
+    # ... and rounding fp32 maps to fp16 loses 8x less than rounding them to bf16
+    exact, _, _, _ = _explicit_from_fused(shapes, v32, oa.float(), ref.cpu(), gout.float(), m, p)
+    o16, _, _, _ = _explicit_from_fused(shapes, v32.to(torch.float16).float(), oa.float(), ref.cpu(), gout.float(), m, p)
+    obf, _, _, _ = _explicit_from_fused(shapes, v32.to(torch.bfloat16).float(), oa.float(), ref.cpu(), gout.float(), m, p)
+    d16, dbf = (o16 - exact).pow(2).mean().sqrt().item(), (obf - exact).pow(2).mean().sqrt().item()
+    print(f"   rms distance of the sampled output from the one of fp32 maps: fp16 storage {d16:.2e}, bf16 storage {dbf:.2e}")
+    assert d16 < 0.2 * dbf
+    with pytest.raises(Exception):                               # fp16 maps exist for the encoder shape only: anything else is refused, not misread
+        ops.msda_fused_fwd(vdev, vstr, geom, dev(oa.float().to(torch.bfloat16)), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
 
 
 # ------------------------------------------------------------------------- streaming (weight-stationary) GEMM
@@ -1439,6 +1568,18 @@ def test_gemm_pipe_long_k(ops, M, K):
     single = torch.empty_like(one)
     ops.linear_fwd(dev(a), dev(hi), dev(bias), single)
     assert (single.double().cpu() - exact).abs().max().item() > 20 * (two.double().cpu() - exact).abs().max().item()
+    # (round 6) the same products stored as IEEE fp16 (PoetGemmDesc.c_f16: the operand the encoder's LayerNorm reads): THE fp16
+    # rounding of the fp32 result almost everywhere (ties of the accumulation order aside), on the pipe kernel, deterministic
+    for kw, want in ((dict(W_lo=dev(lo)), two), (dict(), single)):
+        h = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        ops.linear_fwd(dev(a), dev(hi), dev(bias), h, **kw)
+        assert lib.poet_gemm_last_path() == 5
+        assert torch.isfinite(h.float()).all()
+        assert (h.cpu() == want.cpu().to(torch.float16)).float().mean().item() > 0.999
+        assert (h.double().cpu() - want.double().cpu()).abs().max().item() <= 2.0 ** -11 * sc * 1.01
+        h2 = torch.full_like(h, float("nan"))
+        ops.linear_fwd(dev(a), dev(hi), dev(bias), h2, **kw)
+        assert torch.equal(h, h2)
 
 
 def test_gemm_pipe_grid_independent(ops):
