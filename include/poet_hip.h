@@ -30,7 +30,7 @@
  *       `x = norm(x + dropout(y))`  (deformable_transformer.py:202-203,195-196,279-287,271-272).
  *   poet_mha_fwd / poet_mha_bwd
  *       nn.MultiheadAttention core over <= 128 queries, head dim 16 / 32 / 64 (deformable_transformer.py:277-278; backward at
- *       head dim 64: <= 111 queries -- the Q x Q score matrices live in the CU's 160 KB of LDS).
+ *       head dim 64: <= 114 queries -- the Q x Q score matrices live in the CU's 160 KB of LDS).
  *   poet_pos_sine / poet_bbox_sine
  *       models/position_encoding.py:40-60 and :71-84.
  *   poet_groupnorm_* / poet_im2col3x3s2 / poet_col2im3x3s2_add / poet_nchw_to_tokens / poet_tokens_to_nchw
@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define POET_ABI_VERSION 4
+#define POET_ABI_VERSION 5
 #define POET_SQNORM_SCRATCH 1024
 
 #define POET_F32 0
@@ -253,7 +253,7 @@ int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* r
  * Small multi-head self-attention core (nn.MultiheadAttention without the projections):
  * q,k,v (N,Q,M*hd) fp32 with row stride ld (so they may be column slices of one packed buffer);
  * out (N,Q,M*hd).  hd in {16, 32, 64}; Q <= 128 (one wave up to 64 queries, two waves above), except poet_mha_bwd at hd = 64:
- * Q <= 111 (2 Q hd + 2 Q (Q + 1) floats of LDS; Q = 128 at hd = 32 runs with swizzled, unpadded score matrices = exactly
+ * Q <= 114 (2 Q hd + 2 Q (Q + 1) floats of LDS; Q = 128 at hd = 32 runs with swizzled, unpadded score matrices = exactly
  * 160 KB).  Anything else returns POET_ERR_UNSUPPORTED.  softmax(q k^T / sqrt(hd)) with dropout(p) on the
  * probabilities, no key-padding mask (the reference passes none).
  * ---------------------------------------------------------------------------------------------- */
@@ -301,6 +301,9 @@ int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype_a, in
 int poet_add_rowvec(void* x, const float* vec, int batch, int64_t batch_stride_rows, int64_t row0, int64_t rows,
                     int cols, int dtype, void* stream);
 int poet_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* (ABI v5) zero-fill of `bytes` bytes (address and size multiples of 4): the value-gradient maps, the gradient arena, per-level sums --
+ * every buffer the step accumulates into, so that a captured step holds library kernels only. */
+int poet_zero(void* p, int64_t bytes, void* stream);
 /* out[seg, col] += sum over rows of segment seg.  x (batch, rows_per_batch, cols) row stride ld;
  * seg_start_host (nseg+1) row boundaries inside one batch item.  out fp32 (nseg, cols) accumulated. */
 int poet_colsum(const void* x, int64_t ld, float* out, int batch, int64_t rows_per_batch, int cols,

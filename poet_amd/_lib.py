@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpoet_hip.so")
-ABI_VERSION = 4                                # POET_ABI_VERSION of include/poet_hip.h this binding was written against
+ABI_VERSION = 5                                # POET_ABI_VERSION of include/poet_hip.h this binding was written against
 
 F32, BF16 = 0, 1
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -59,6 +59,7 @@ _PROTOS = {
     "poet_enc_ref_points": ([vp, pi64, vp, i32, i32, i32, vp], i32),
     "poet_add": ([vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "poet_cast": ([vp, vp, i64, i32, i32, vp], i32),
+    "poet_zero": ([vp, i64, vp], i32),
     "poet_colsum": ([vp, i64, vp, i32, i64, i32, pi64, i32, i32, vp], i32),
     "poet_vgrad_to_rows": ([vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_zero_masked_rows": ([vp, i64, vp, i64, i32, i32, vp], i32),

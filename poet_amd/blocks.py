@@ -328,7 +328,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
     v2b = sv["V"].dtype in (torch.bfloat16, torch.float16)             # 2-byte value maps (fp16: ops.v_f16)
     gv16 = (v2b and sv["OA"].dtype in (torch.bfloat16, torch.float16) and D == 16 and npts == 4 and geom.L * npts <= 16
             and ops.tiled_scatter_bf16())
-    dV = torch.zeros(sv["V"].shape, dtype=torch.bfloat16 if gv16 else torch.float32, device=dx2.device)
+    dV = ops.zeros(sv["V"].shape, torch.bfloat16 if gv16 else torch.float32, dx2.device)
     mlp = M * geom.L * npts
     so_w = P_["self_attn.sampling_offsets.weight"]
     tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and v2b else None
@@ -351,7 +351,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
         ops.msda_fused_bwd(sv["V"], vstrides_of(sv["V"]), geom, sv["OA"], 3 * mlp, 2 * mlp, ref, ref_bs, d_out_m, dV, G2, N, M, D, npts, S,
                            grid_queries=True, ld_grad=ldg)
         ops.vgrad_to_rows(dV, vstrides(M, S, D), mask, G2[:, 3 * mlp:], N, S, M, D, ld_out=ldg)
-        segw = torch.zeros((geom.L, 3 * mlp + d), dtype=torch.float32, device=dx2.device)
+        segw = ops.zeros((geom.L, 3 * mlp + d), torch.float32, dx2.device)
         ops.linear_dw(G2, sv["q"], tri["gw"], rows=N * S, ldy=ldg, seg=(segw, geom.c_segs, S), x_alt=(sv["src"], 3 * mlp))
         ops.colsum(segw, ldg, g("self_attn.sampling_offsets.bias"), 1, geom.L, 2 * mlp)
         ops.colsum(segw[:, 2 * mlp:], ldg, g("self_attn.attention_weights.bias"), 1, geom.L, mlp)
@@ -362,7 +362,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
             ops.gemm(segw[:, 2 * mlp:], aw_w, g_level, geom.L, d, mlp, lda=ldg, ldb=d, ldc=d, b_kmajor=True, add_src=g_level, ld_add=d)
         ops.linear_dx(G2, tri["w16"], dsrc, rows=N * S, add_src=dsrc)
         return dsrc
-    seg = torch.zeros((geom.L, 3 * mlp), dtype=torch.float32, device=dx2.device)
+    seg = ops.zeros((geom.L, 3 * mlp), torch.float32, dx2.device)
     sample_bwd(d_out_m, sv["q"], sv["OA"], so_w, P_["self_attn.attention_weights.weight"],
                sv["V"], geom, ref, ref_bs, N, S, M, D, npts, dV,
                g_so_w, g("self_attn.sampling_offsets.bias"),

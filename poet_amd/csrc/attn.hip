@@ -251,7 +251,7 @@ extern "C" int poet_mha_bwd(const float* q, const float* k, const float* v, int6
     const bool swz = two && lds > MHA_LDS_MAX && hd == 32 && Q % 64 == 0 && sizeof(float) * (2 * Q * hd + 2 * Q * Q) <= MHA_LDS_MAX;
     if (swz) lds = sizeof(float) * (2 * Q * hd + 2 * Q * Q);
     POET_CHECK(lds <= MHA_LDS_MAX, POET_ERR_UNSUPPORTED,
-               "mha_bwd: Q=%d at head dim %d needs %zu bytes of LDS (> 160 KiB; limits: Q <= 128 at head dim 16 / 32, Q <= 111 at head dim 64)", Q, hd, lds);
+               "mha_bwd: Q=%d at head dim %d needs %zu bytes of LDS (> 160 KiB; limits: Q <= 128 at head dim 16 / 32, Q <= 114 at head dim 64)", Q, hd, lds);
     dim3 grid(N * M);
     hipStream_t st = (hipStream_t)stream;
 #define POET_MHA_BWD(HD, NT, OV) do { mha_lds_attr(reinterpret_cast<const void*>(mha_bwd_kernel<HD, NT, OV>), lds);   \

@@ -32,6 +32,18 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* _
     }
 }
 
+// zero-fill of `bytes` bytes at a 4-byte aligned address: 16-byte stores (4-byte head / tail pieces), 64 bytes per lane
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, int64_t words) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && i + 16 <= words) {
+        uint4* q = reinterpret_cast<uint4*>(p + i);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+    } else {
+        for (int64_t j = i; j < words && j < i + 16; ++j) p[j] = 0u;
+    }
+}
+
 // ---- segmented column sums (bias gradients; per-level sums for level_embed) -----------------------
 constexpr int CS_MAXSEG = 8;
 struct ColsumP {
@@ -748,6 +760,16 @@ extern "C" int poet_cast(const void* src, void* dst, int64_t n, int sd, int dd, 
     else if (sd == POET_BF16 && dd == POET_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, ST, (const bf16_t*)src, (float*)dst, n);
     else if (sd == POET_F32 && dd == POET_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, ST, (const float*)src, (float*)dst, n);
     else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, ST, (const bf16_t*)src, (bf16_t*)dst, n);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_zero(void* p, int64_t bytes, void* stream) {
+    POET_CHECK(p && bytes >= 0, POET_ERR_ARG, "zero: bad args");
+    POET_CHECK((reinterpret_cast<uintptr_t>(p) & 3) == 0 && (bytes & 3) == 0, POET_ERR_ARG, "zero: address and size must be multiples of 4 bytes");
+    if (bytes == 0) return POET_OK;
+    const int64_t words = bytes / 4;
+    hipLaunchKernelGGL(zero_kernel, dim3(cdiv(words, 4096)), dim3(256), 0, ST, reinterpret_cast<uint32_t*>(p), words);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -237,7 +237,7 @@ class ParamArena:
         self.flat_bf16_lo.copy_(self.flat - self.flat_bf16.float())
 
     def zero_grad(self):
-        self.grad.zero_()
+        ops.zero_(self.grad)
 
     def step(self, max_norm: float = 0.1, step_dev=None):
         """clip_grad_norm_(max_norm) + AdamW (engine.py:77-81) on the flat arenas.  With `step_dev` (a device word) the
@@ -246,7 +246,7 @@ class ParamArena:
         gs = 1.0 / self.world
         sq = None
         if max_norm > 0:
-            self.sq.zero_()
+            ops.zero_(self.sq)
             ops.sqnorm(self.grad, self.sq)
             sq = self.sq
         for a, b, lr in self.groups:
@@ -878,6 +878,14 @@ def _stage_copy(dst: torch.Tensor, src: torch.Tensor):
         dst.copy_(src, non_blocking=True)
 
 
+class PackedBatch:
+    """One batch staged ahead of its step in a GraphedTrainer's static-input layout (GraphedTrainer.pack)."""
+    __slots__ = ("buf", "owner")
+
+    def __init__(self, buf, owner):
+        self.buf, self.owner = buf, owner
+
+
 class GraphedTrainer(Trainer):
     """Trainer whose device work is replayed from HIP graphs (the step has ~700 kernel launches; enqueuing them from
     Python costs about as much as executing them).  Three graphs, captured after `warm` eager steps:
@@ -936,16 +944,19 @@ class GraphedTrainer(Trainer):
         boxes, classes, valid, n_boxes = m.host_queries(targets)
         return features, boxes, classes, valid, n_boxes
 
-    def _stage_targets(self, targets, queries=False):
-        """Compacted target boxes / translations / rotations and the per-image offsets + query counts into the static
+    def _stage_targets(self, targets, queries=False, D=None):
+        """(D: destination views -- the static input buffers by default, a PackedBatch's views from pack())
+        Compacted target boxes / translations / rotations and the per-image offsets + query counts into the static
         buffers the captured matcher reads (device-resident targets: device-side cat + copy; host targets: H2D).
         queries=True (targets on the device): the padded query boxes / classes / valid flags of PoET.host_queries are
         scattered into their static buffers on the device as well -- the host reads shapes only, never tensor contents, so it
         does not wait for the GPU and can run ahead of it."""
-        N, Q = self.s_boxes.shape[:2]
+        D = self.S if D is None else D
+        s_boxes, s_cls, s_valid, s_tb, s_tpos, s_trot, s_meta = (D[k] for k in ("boxes", "cls", "valid", "tb", "tpos", "trot", "meta"))
+        N, Q = s_boxes.shape[:2]
         counts = [int(t["boxes"].shape[0]) for t in targets]
         n = sum(counts)
-        if len(counts) != N or n > self.s_tb.shape[0] or max(counts, default=0) > Q:
+        if len(counts) != N or n > s_tb.shape[0] or max(counts, default=0) > Q:
             raise ValueError(f"GraphedTrainer: {n} targets in {len(counts)} images (max {max(counts, default=0)}) exceed the captured "
                              f"capacity ({N} images x {Q} queries; the reference assumes n <= num_queries in gt mode)")
         meta = np.zeros(2 * N + 1 + (n if queries else 0), np.int64)
@@ -955,9 +966,9 @@ class GraphedTrainer(Trainer):
             meta[2 * N + 1:] = np.concatenate([i * Q + np.arange(c, dtype=np.int64) for i, c in enumerate(counts)])
         if not hasattr(self, "_meta_ring"):
             self._meta_ring = _PinnedRing()
-        meta_d = self._meta_ring.stage(meta, self.s_meta.device)
-        self.s_meta.copy_(meta_d[: 2 * N + 1], non_blocking=True)
-        dev = self.s_tb.device
+        meta_d = self._meta_ring.stage(meta, s_meta.device)
+        s_meta.copy_(meta_d[: 2 * N + 1], non_blocking=True)
+        dev = s_tb.device
         tb = None
         if n:
             def gather(key, dst, shape):                        # device-resident fp32 fields: concatenated straight into the static buffer
@@ -967,18 +978,18 @@ class GraphedTrainer(Trainer):
                 else:
                     dst[:n].copy_(torch.cat(parts, 0).to(dev, non_blocking=True), non_blocking=True)
                 return dst[:n]
-            tb = gather("boxes", self.s_tb, (-1, 4))
-            gather("relative_position", self.s_tpos, (-1, 3))
-            gather("relative_rotation", self.s_trot, (-1, 3, 3))
+            tb = gather("boxes", s_tb, (-1, 4))
+            gather("relative_position", s_tpos, (-1, 3))
+            gather("relative_rotation", s_trot, (-1, 3, 3))
         if queries:
-            self.s_boxes.fill_(-1.0)
-            self.s_cls.fill_(-1)
-            self.s_valid.zero_()
+            s_boxes.fill_(-1.0)
+            s_cls.fill_(-1)
+            s_valid.zero_()
             if n:
                 idx = meta_d[2 * N + 1:]
-                self.s_boxes.view(-1, 4).index_copy_(0, idx, tb)
-                self.s_cls.view(-1).index_copy_(0, idx, torch.cat([t["labels"].reshape(-1) for t in targets], 0).to(dev, non_blocking=True).to(self.s_cls.dtype))
-                self.s_valid.view(-1).index_fill_(0, idx, 1)
+                s_boxes.view(-1, 4).index_copy_(0, idx, tb)
+                s_cls.view(-1).index_copy_(0, idx, torch.cat([t["labels"].reshape(-1) for t in targets], 0).to(dev, non_blocking=True).to(s_cls.dtype))
+                s_valid.view(-1).index_fill_(0, idx, 1)
         return counts
 
     def _capture(self, samples, targets):
@@ -1028,6 +1039,8 @@ class GraphedTrainer(Trainer):
                 crit._lsa_status = torch.zeros(1, dtype=torch.int32, device=dev)
             n_dec = len(m.transformer.decoder.layers)
             crit.total(_vec_dict(torch.zeros((n_dec, 2), device=dev)))      # builds crit._w, the (L, 2) weight table, outside the capture
+        self._build_pack()
+        if self.graph_loss:
             self._stage_targets(targets)
         self.g_fwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fwd, **_CAPTURE):
@@ -1122,43 +1135,116 @@ class GraphedTrainer(Trainer):
         torch.cuda.synchronize()
         self.ready = True
 
-    def step(self, samples, targets):
-        self.calls += 1
-        if not self.ready:
-            if self.calls <= self.warm:
-                return super().step(samples, targets)        # eager warm-up (also fills every lazy cache)
-            self._capture(samples, targets)
+    def _build_pack(self):
+        """Re-home every static INPUT of the graphs -- feature maps, masks, image mask, padded query boxes / classes / valid flags and
+        (captured loss) the compacted targets + per-image offsets -- in ONE allocation, 256-byte aligned fields: a batch that was
+        staged ahead of time in the same layout (pack()) then reaches the graphs by a single streaming copy instead of ~20 small
+        launches at the head of the step.  Called once, before the capture; the attribute names keep pointing
+        at the (moved) tensors.  persistent_inputs=True: the caller's feature / mask buffers stay where they are (no pack)."""
+        fields = [("boxes", self.s_boxes), ("cls", self.s_cls), ("valid", self.s_valid)]
+        if not self.persistent_inputs:
+            fields += [(f"feat{i}", t) for i, t in enumerate(self.s_feats)] + [(f"fmask{i}", t) for i, t in enumerate(self.s_fmasks)] + [("imask", self.s_imask)]
+        if self.graph_loss:
+            fields += [("tb", self.s_tb), ("tpos", self.s_tpos), ("trot", self.s_trot), ("meta", self.s_meta)]
+        off, self._pack_fields = 0, []
+        for name, t in fields:
+            nb = t.numel() * t.element_size()
+            self._pack_fields.append((name, off, nb, t.dtype, tuple(t.shape)))
+            off = (off + nb + 255) // 256 * 256
+        self.s_pack = torch.zeros(max(off, 256), dtype=torch.uint8, device=self.s_boxes.device)
+        self.S = self._pack_views(self.s_pack)
+        for name, t in fields:
+            self.S[name].copy_(t)
+        if self.persistent_inputs:
+            for i, (f, mk) in enumerate(zip(self.s_feats, self.s_fmasks)):
+                self.S[f"feat{i}"], self.S[f"fmask{i}"] = f, mk
+            self.S["imask"] = self.s_imask
+        else:
+            self.s_feats = [self.S[f"feat{i}"] for i in range(len(self.s_feats))]
+            self.s_fmasks = [self.S[f"fmask{i}"] for i in range(len(self.s_fmasks))]
+            self.s_imask = self.S["imask"]
+        self.s_boxes, self.s_cls, self.s_valid = self.S["boxes"], self.S["cls"], self.S["valid"]
+        if self.graph_loss:
+            self.s_tb, self.s_tpos, self.s_trot, self.s_meta = self.S["tb"], self.S["tpos"], self.S["trot"], self.S["meta"]
+        self._pack_slots, self._pack_pos = [], 0
+
+    def _pack_views(self, buf):
+        return {name: buf[off:off + nb].view(dt).view(shape) for name, off, nb, dt, shape in self._pack_fields}
+
+    def _stage(self, D, samples, targets):
+        """One batch into the destination views D (the static inputs, or a PackedBatch's): feature maps and masks as handed over by
+        the backbone, the padded query boxes / classes / valid flags, and (captured loss) the compacted targets.  Returns
+        (boxes, n_boxes) of PoET.host_queries on the host path, None when the targets live on the device."""
         m = self.model
         on_device = self.graph_loss and all(t["boxes"].is_cuda and t["labels"].is_cuda for t in targets)
         if on_device:
             features = m.backbone(samples)[0]
         else:
             features, boxes, classes, valid, n_boxes = self._static_inputs(samples, targets)
-        for f, sf, sm in zip(features, self.s_feats, self.s_fmasks):
+        for i, f in enumerate(features):
+            sf, sm = D[f"feat{i}"], D[f"fmask{i}"]
             if f.tensors.data_ptr() != sf.data_ptr():
                 _stage_copy(sf, f.tensors)
             if f.mask.data_ptr() != sm.data_ptr():
                 sm.copy_(f.mask.view(torch.uint8) if f.mask.dtype == torch.bool else f.mask, non_blocking=True)
         im = samples.mask                                   # the extra levels' masks / valid ratios / sine encodings derive from it
-        if im.data_ptr() != self.s_imask.data_ptr():
-            self.s_imask.copy_(im.view(torch.uint8) if im.dtype == torch.bool else im, non_blocking=True)
+        if im.data_ptr() != D["imask"].data_ptr():
+            D["imask"].copy_(im.view(torch.uint8) if im.dtype == torch.bool else im, non_blocking=True)
         if on_device:
-            self._stage_targets(targets, queries=True)
-            self.g_fwd.replay()
-            _Replay.replay_backward(self)
-            return self.s_total.clone(), _vec_dict(self.s_lossvec.clone())      # (the static buffers are overwritten by the next replay)
+            self._stage_targets(targets, queries=True, D=D)
+            return None
         slot = self.ring[self.ring_pos]
         self.ring_pos = (self.ring_pos + 1) % len(self.ring)
         if slot["ev"] is not None:
             slot["ev"].synchronize()
         slot["boxes"].copy_(torch.from_numpy(boxes)); slot["cls"].copy_(torch.from_numpy(classes)); slot["valid"].copy_(torch.from_numpy(valid))
-        self.s_boxes.copy_(slot["boxes"], non_blocking=True)
-        self.s_cls.copy_(slot["cls"], non_blocking=True)
-        self.s_valid.copy_(slot["valid"], non_blocking=True)
+        D["boxes"].copy_(slot["boxes"], non_blocking=True)
+        D["cls"].copy_(slot["cls"], non_blocking=True)
+        D["valid"].copy_(slot["valid"], non_blocking=True)
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
         if self.graph_loss:
-            self._stage_targets(targets)
+            self._stage_targets(targets, D=D)
+        return boxes, n_boxes
+
+    def pack(self, samples, targets):
+        """Stage one batch AHEAD of its step: into a device buffer laid out like the graphs' static input area (a ring of two, so
+        batch i + 1 can be packed -- by a prefetcher, on its own stream, under the step of batch i -- while batch i is consumed).
+        `step(packed)` then costs one streaming copy.  The captured-loss mode only ('gt' queries, device matcher): the eager
+        loss needs the host-side query assembly of its own batch.  Returns a PackedBatch; valid until two more pack() calls."""
+        if not self.ready:
+            raise RuntimeError("GraphedTrainer.pack: call step(samples, targets) until the graphs are captured (warm + 1 steps) first")
+        if not self.graph_loss or self.persistent_inputs:
+            raise NotImplementedError("GraphedTrainer.pack: needs the captured loss ('gt' queries, device matcher) and private static inputs")
+        if len(self._pack_slots) < 2:
+            self._pack_slots.append(torch.empty_like(self.s_pack))
+        buf = self._pack_slots[self._pack_pos]
+        self._pack_pos = (self._pack_pos + 1) % 2
+        self._stage(self._pack_views(buf), samples, targets)
+        return PackedBatch(buf, self)
+
+    def step(self, samples, targets=None):
+        self.calls += 1
+        if isinstance(samples, PackedBatch):
+            if samples.owner is not self or not self.ready:
+                raise ValueError("GraphedTrainer.step: a PackedBatch belongs to the trainer that packed it")
+            n4 = self.s_pack.numel() // 4
+            ops.cast(samples.buf[: n4 * 4].view(torch.float32), self.s_pack[: n4 * 4].view(torch.float32))      # ONE streaming copy (fields are 256-B aligned)
+            self.g_fwd.replay()
+            _Replay.replay_backward(self)
+            return self.s_total.clone(), _vec_dict(self.s_lossvec.clone())
+        if not self.ready:
+            if self.calls <= self.warm:
+                return super().step(samples, targets)        # eager warm-up (also fills every lazy cache)
+            self._capture(samples, targets)
+        m = self.model
+        staged = self._stage(self.S, samples, targets)
+        if staged is None:                                   # targets on the device (captured loss)
+            self.g_fwd.replay()
+            _Replay.replay_backward(self)
+            return self.s_total.clone(), _vec_dict(self.s_lossvec.clone())      # (the static buffers are overwritten by the next replay)
+        boxes, n_boxes = staged
+        if self.graph_loss:
             self.g_fwd.replay()
             _Replay.replay_backward(self)
             vec = self.s_lossvec.clone()                         # the static buffers are overwritten by the next replay

@@ -272,11 +272,11 @@ class DecoderFn(torch.autograd.Function):
         # bf16 policy with stacked value projections: the scatters of all layers write bf16 token-major rows (N*S, nl*M*D) in place --
         # what the stacked weight / input-gradient GEMMs read; no fp32 head-major staging map (522 MB zero-fill + transposing pass)
         rows16 = vs is not None and ctx.mem2.dtype == torch.bfloat16 and os.environ.get("POET_DEC_DV_F32", "0") in ("", "0")
-        dVr_all = torch.zeros((N * S, nl * M * D), dtype=torch.bfloat16, device=dhs.device) if rows16 else None
-        dV_all = torch.zeros((N, M * nl, S, D), dtype=torch.float32, device=dhs.device) if (vs is not None and not rows16) else None
-        dqp = torch.zeros((N * Q, d), dtype=torch.float32, device=dhs.device) if ctx.need_qpos else None
+        dVr_all = ops.zeros((N * S, nl * M * D), torch.bfloat16, dhs.device) if rows16 else None
+        dV_all = ops.zeros((N, M * nl, S, D), torch.float32, dhs.device) if (vs is not None and not rows16) else None
+        dqp = ops.zeros((N * Q, d), torch.float32, dhs.device) if ctx.need_qpos else None
         mlp = M * geom.L * cfg["P"]
-        dref = torch.zeros((N, Q, geom.L, 2), dtype=torch.float32, device=dhs.device) if ctx.need_ref else None
+        dref = ops.zeros((N, Q, geom.L, 2), torch.float32, dhs.device) if ctx.need_ref else None
         if ctx.need_ref:
             wh = _level_wh(geom, dhs.device)                                                                   # (L, 2): x scales with W, y with H
         with ops.defer_small_dw() as deferred:           # the 320-row dW + db of all layers: one launch per Linear, at the end
@@ -292,7 +292,7 @@ class DecoderFn(torch.autograd.Function):
                 if rows16:
                     dV = dVr_all.view(N, S, nl, M, D)[:, :, i].permute(0, 2, 1, 3)      # (N, M, S, D) view of this layer's column block
                 else:
-                    dV = dV_all[:, i * M:(i + 1) * M] if vs is not None else torch.zeros((N, M, S, D), dtype=torch.float32, device=dhs.device)
+                    dV = dV_all[:, i * M:(i + 1) * M] if vs is not None else ops.zeros((N, M, S, D), torch.float32, dhs.device)
                 # (a fresh buffer per layer: the deferred weight-gradient launches read it after the loop)
                 dOA = torch.empty((N * Q, 3 * mlp), dtype=torch.float32, device=dhs.device) if ctx.need_ref else None
                 dx = B.dec_layer_bwd(dx, ctx.saved[i], P_, G, pre, ctx.ref_in, geom, N, Q, M, cfg["P"], dV, dqp=dqp, dOA_out=dOA)
@@ -669,7 +669,7 @@ class MSDeformAttnFn(torch.autograd.Function):
         ops.linear_dw(dy, out_m, G("output_proj.weight"), rows=rows, db=G("output_proj.bias"))
         d_out_m = torch.empty_like(out_m)
         ops.linear_dx(dy, P_["output_proj.weight"], d_out_m, rows=rows)
-        dV = torch.zeros(V.shape, dtype=torch.float32, device=dy.device)
+        dV = ops.zeros(V.shape, torch.float32, dy.device)
         dq = torch.empty_like(q2) if ctx.need[0] else None
         B.sample_bwd(d_out_m, q2, OA, P_["sampling_offsets.weight"], P_["attention_weights.weight"], V, geom, refc,
                      Lq * geom.L * 2, N, Lq, M, D, npts, dV, G("sampling_offsets.weight"), G("sampling_offsets.bias"),

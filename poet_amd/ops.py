@@ -583,6 +583,23 @@ def cast(src, dst):
     return dst
 
 
+def zero_(t: torch.Tensor):
+    """t[...] = 0 through the library's own fill (poet_zero): contiguous tensors whose byte size is a multiple of 4."""
+    nb = t.numel() * t.element_size()
+    if not t.is_cuda:
+        raise _lib.PoetHipError("poet_amd: zero_ needs a GPU tensor (no CPU path exists)")
+    if not t.is_contiguous() or nb % 4 or t.data_ptr() % 4:
+        return t.zero_()
+    if nb:
+        _lib.check(_lib.load().poet_zero(t.data_ptr(), nb, _stream()), "poet_zero")
+    return t
+
+
+def zeros(shape, dtype, device):
+    """torch.zeros through poet_zero (the step's accumulators: value-gradient maps, per-level sums)."""
+    return zero_(torch.empty(shape, dtype=dtype, device=device))
+
+
 def colsum(x, ld, out, batch, rows_per_batch, cols, segs=None, nseg=1):
     lib = _lib.load()
     _lib.check(lib.poet_colsum(_req(x, "x").data_ptr(), ld, out.data_ptr(), batch, rows_per_batch, cols, segs, nseg, dcode(x),

@@ -8,7 +8,7 @@ from oracle.formula import CONFIGS, formula_fill, make_inputs
 
 def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, feat_dtype=None, default_init=False,
                   bbox_mode="gt", predictions=None, class_mode="specific", rotation_mode="6d", aleatoric=False,
-                  ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine", replicate=None):
+                  ref_points_mode="bbox", query_embedding_mode="bbox", position_embedding="sine", replicate=None, perturb=0):
     """replicate=B: the batch is B copies of image 0 of the (batch, pad) inputs -- features, size and targets alike.  Images of
     a batch are independent and every loss term is a sum over matched objects divided by the batch's object count, so every
     per-image output, every loss value and every parameter gradient equals the single-image run's: a golden of the real
@@ -17,6 +17,12 @@ def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, f
         precision = "fp32" if precision == torch.float32 else "bf16"
     cfg = CONFIGS[name]
     feats, sizes, targets = make_inputs(cfg, seed=seed, batch=batch, pad=pad)
+    if perturb:
+        # member `perturb` of a NOISE ENSEMBLE of the same problem (tests/test_model_gpu.py, the bf16 gradient gate): every feature
+        # value moved by a random-sign 2^-10 relative step -- a quarter of a bf16 ulp: it re-rolls the rounding decisions of a 16-bit
+        # policy from the first operand on while the exact gradient moves by ~1e-3 of itself
+        gen = torch.Generator().manual_seed(9000 + int(perturb))
+        feats = [f * (1.0 + (2.0 ** -10) * (torch.randint(0, 2, f.shape, generator=gen).to(f.dtype) * 2.0 - 1.0)) for f in feats]
     if replicate:
         feats = [f[:1].repeat(replicate, 1, 1, 1).contiguous() for f in feats]
         sizes = [sizes[0]] * replicate

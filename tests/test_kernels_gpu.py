@@ -433,11 +433,11 @@ def test_groupnorm(ops, dtype):
 
 # ---------------------------------------------------------------------------------------------- MHA
 @pytest.mark.parametrize("Q,M,hd", [(20, 16, 16), (10, 4, 64), (6, 4, 16), (50, 8, 32), (64, 16, 16), (65, 4, 16), (100, 16, 16), (128, 16, 16), (100, 8, 32),
-                                    (70, 4, 64), (128, 8, 32), (111, 4, 64)])
+                                    (70, 4, 64), (128, 8, 32), (114, 4, 64)])
 def test_mha(ops, Q, M, hd):
     """(Q > 64: two waves per (image, head); backward with k / v and q / d(out) sharing their LDS; `--num_queries`, main.py:98.
     (128, 8, 32) = the reference's default head geometry (hidden 256 / nheads 8) at the largest query count: the backward's score
-    matrices fill the CU's 160 KB exactly (swizzled, no pad column); (111, 4, 64): the largest Q the backward takes at head dim 64.)"""
+    matrices fill the CU's 160 KB exactly (swizzled, no pad column); (114, 4, 64): the largest Q the backward takes at head dim 64.)"""
     N, d = 3, M * hd
     packed = _rand(N * Q, 3 * d, seed=40)
     pk = dev(packed)
@@ -456,9 +456,9 @@ def test_mha(ops, Q, M, hd):
 
 
 def test_mha_limits_are_refused_not_misrun(ops):
-    """Q > 128, head dims outside {16, 32, 64} and the backward at head dim 64 beyond 111 queries return POET_ERR_UNSUPPORTED."""
+    """Q > 128, head dims outside {16, 32, 64} and the backward at head dim 64 beyond 114 queries return POET_ERR_UNSUPPORTED."""
     from poet_amd._lib import PoetHipError
-    for Q, M, hd, bwd_only in [(129, 4, 16, False), (20, 4, 24, False), (112, 4, 64, True)]:
+    for Q, M, hd, bwd_only in [(129, 4, 16, False), (20, 4, 24, False), (115, 4, 64, True)]:
         N, d = 1, M * hd
         pk = dev(_rand(N * Q, 3 * d, seed=44))
         out = torch.empty(N * Q, d, device="cuda")
@@ -1123,8 +1123,9 @@ def test_msda_fp16_value_maps_vs_explicit(ops, gscale):
     d16, dbf = (o16 - exact).pow(2).mean().sqrt().item(), (obf - exact).pow(2).mean().sqrt().item()
     print(f"   rms distance of the sampled output from the one of fp32 maps: fp16 storage {d16:.2e}, bf16 storage {dbf:.2e}")
     assert d16 < 0.2 * dbf
-    with pytest.raises(Exception):                               # fp16 maps exist for the encoder shape only: anything else is refused, not misread
-        ops.msda_fused_fwd(vdev, vstr, geom, dev(oa.float().to(torch.bfloat16)), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
+    with pytest.raises(Exception):                               # fp16 maps come with fp16 offsets | logits: anything else is refused, not misread
+        v16 = dev(v32.to(torch.float16).permute(0, 2, 1, 3).contiguous())
+        ops.msda_fused_fwd(v16, vstr, geom, dev(oa.float().to(torch.bfloat16)), 3 * mlp, 2 * mlp, ref, S * L * 2, out, n, m, d, p, S, grid_queries=True)
 
 
 # ------------------------------------------------------------------------- streaming (weight-stationary) GEMM

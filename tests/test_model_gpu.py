@@ -365,13 +365,115 @@ FULL_SIZE = [("ycbv", 1, False, False), ("ycbv", 1, False, True),          # BAS
 # decoder.layers.1.self_attn.in_proj_weight; 5.3e-2 at YCB-V); as relative L2 over ALL gradients the bf16 policy sits 4.8-5.8 %
 # from the fp32 policy (test_arena_paths_match_plain_model_at_full_size).
 GRAD_TOL_F32, GRAD_TOL_BF16 = 2e-3, 8e-2        # fp32: worst measured over all full-size goldens 3.5e-4 (round 5; was 1e-2)
-# Round 5: the bf16 bound per golden = worst checksum entry measured on that golden (plain and arena pass; round-5 runs on three
-# boxes agree to the digit: the two passes are deterministic up to the decoder's bf16 atomics) x 1.3, not one flat 8e-2.  The worst
-# entry is every time the NORM of a small decoder tensor (self_attn.in_proj of layers 0 / 1, a norm1 weight): gradients that are sums
-# over a few dozen queries of terms that cancel, fed by the memory's bf16 rounding noise; the encoder tensors (sums over 6380+ token
-# rows) sit at 1.0-1.7e-2.  Other tests keep GRAD_TOL_BF16 as the ceiling.
-GRAD_TOL_BF16_AT = {("ycbv", 1, False): 4.8e-2, ("ycbv", 1, True): 7.7e-2, ("lmo", 1, False): 2.5e-2, ("lmo", 2, False): 6.4e-2,
-                    ("lmo", 1, True): 2.5e-2, ("lmo", 3, False): 3.0e-2, ("hires", 1, False): 3.0e-2, ("hires", 1, True): 5.9e-2}
+# ---- the bf16 gradient gate (round 6; replaces the per-golden bound on the worst checksum entry) -------------------------------
+# Rounds 3-5 gated the bf16 policy on the worst per-tensor checksum entry against the golden, bound = measured x 1.3 per golden
+# (2.5e-2 .. 7.7e-2).  That statistic was loose AND brittle: the worst entry was every time the norm of a small decoder tensor --
+# a sum over a few dozen queries of cancelling terms fed by the memory's rounding noise -- which a numerically neutral reordering
+# inside one forward kernel moved 5x without any change of an error level, while a 5 % wrong gradient passed.  What a single
+# realisation of a 16-bit policy can be held to depends on what the tensor sums over:
+#   (i)   ALL gradients together: relative L2 distance to the fp32 policy of the same model (whose gradients the golden pins to
+#         2e-3 in the same test): dominated by the big tensors -- one flat ceiling (measured 2.3-5.3e-2 over the eight goldens)
+#         and, relative to the policy's own noise ensemble (below), mean + 4 sigma;
+#   (ii)  tensors whose gradient sums over the token rows (encoder, input_proj, level_embed, the decoder's value projections):
+#         per-tensor checksums against the GOLDEN at one flat 3e-2 (measured worst per golden 0.8-2.6e-2): a 3 % scale error fails;
+#   (iii) the small decoder / head tensors, where a single realisation is noise-limited: judged against the policy's OWN NOISE
+#         ENSEMBLE -- ENS_K further problems, the inputs moved by a quarter of a bf16 ulp (product_runner.perturb: re-rolls every
+#         rounding decision), each solved by the bf16 policy AND by the fp32 policy (the exact gradient of an ill-conditioned head
+#         tensor moves by percents under such a step: every member is compared with ITS OWN fp32 solution):
+#           a. as a group: the relative L2 over all small tensors of THIS realisation <= ensemble mean + 4 sigma (+ 10 %);
+#           b. per tensor, BIAS: the ensemble-MEAN error (noise averaged down by ~sqrt(K)) within max(ENS_BIAS x the members'
+#              mean error, ENS_BIAS_FLOOR): a systematic error (a wrong scale, a missing term) does not average out and fails
+#              here even where one realisation is 5-10 % noise;
+#           c. per tensor, gross: this realisation within max(ENS_GROSS x the worst member, ENS_GROSS_FLOOR) -- the floor is wide
+#              because the reference's own random init produces heavy tails (a query whose 6D rotation output is nearly degenerate
+#              amplifies the memory's noise 100x: one realisation in six sat at 10-13 % on a head tensor whose other five sat at 0.3 %).
+# test_bf16_gradient_gate_rejects_wrong_gradients feeds the gate a 3 %-scaled encoder gradient, a decoder tensor off by 8 % in
+# every realisation and one off by 60 % in this one.
+BIG_SUM_PREFIX = ("transformer.encoder.", "input_proj.", "transformer.level_embed")
+GRAD_TOL_BF16_BIG = 3e-2
+GRAD_L2_BF16_CEIL = 7e-2
+ENS_K, ENS_SIGMA = 5, 4.0
+ENS_BIAS, ENS_BIAS_FLOOR = 0.75, 2.5e-2
+ENS_GROSS, ENS_GROSS_FLOOR = 3.0, 0.25
+
+
+def _big_sum(n):
+    return n.startswith(BIG_SUM_PREFIX) or ".cross_attn.value_proj." in n
+
+
+def _collect_grads(model):
+    gof = lambda p: getattr(p, "_grad_view", None) if getattr(p, "_grad_view", None) is not None else p.grad
+    return {n: gof(p).detach().float().cpu().clone() for n, p in model.named_parameters() if gof(p) is not None}
+
+
+def _rel_l2(a, ref, names):
+    num = sum(float(((a[n] - ref[n]).double() ** 2).sum()) for n in names)
+    den = sum(float((ref[n].double() ** 2).sum()) for n in names)
+    return (num / max(den, 1e-60)) ** 0.5
+
+
+def _bf16_ensemble(gpu, name, batch, pad, init, replicate=None):
+    """ENS_K members of the bf16 policy's noise ensemble on this problem: [(bf16 gradients, fp32 gradients)] of the plain program on
+    ENS_K perturbed inputs."""
+    members = []
+    for k in range(1, ENS_K + 1):
+        pair = []
+        for dtype in (torch.bfloat16, torch.float32):
+            r = gpu(name, batch, pad, dtype, default_init=init, replicate=replicate, perturb=k)
+            model, crit = r["model"], r["crit"]
+            model.eval()
+            out, n_boxes = model(r["samples"], r["targets"])
+            losses = crit(out, r["targets"], n_boxes)
+            model.zero_grad()
+            sum(losses[k_] * crit.weight_dict[k_] for k_ in losses if k_ in crit.weight_dict).backward()
+            torch.cuda.synchronize()
+            pair.append(_collect_grads(model))
+            del r, model, crit, out, losses
+            torch.cuda.empty_cache()
+        members.append(tuple(pair))
+    return members
+
+
+def _gate_bf16(tag, g, grads, g32, ens, init, grad_of):
+    """The bf16 gradient gate (comment above): asserts (i), (ii), (iii a-c); returns the printed summary."""
+    names = sorted(n for n in g32 if n in grads and float(g32[n].double().pow(2).sum()) > 1e-24)
+    big, small = [n for n in names if _big_sum(n)], [n for n in names if not _big_sum(n)]
+    # (i) all gradients
+    e_all = _rel_l2(grads, g32, names)
+    ens_all = np.array([_rel_l2(a, b, names) for a, b in ens])
+    # (ii) big-sum tensors against the golden's checksums
+    errs_big = _grad_errors(g, grad_of, GRAD_TOL_BF16_BIG, init, select=_big_sum)
+    _norm_worst()
+    # (iii) small tensors against the noise ensemble
+    e_small = _rel_l2(grads, g32, small)
+    ens_small = np.array([_rel_l2(a, b, small) for a, b in ens])
+    mu, sd = float(ens_small.mean()), float(ens_small.std(ddof=1))
+    rows = []
+    for n in small:
+        dk = np.array([_rel_l2(a, b, [n]) for a, b in ens])
+        err_mean = sum((a[n] - b[n]).double() for a, b in ens) / len(ens)
+        ref_mean = sum(b[n].double() for a, b in ens) / len(ens)
+        bias = float(err_mean.pow(2).sum().sqrt() / ref_mean.pow(2).sum().sqrt().clamp_min(1e-30))
+        rows.append((n, _rel_l2(grads, g32, [n]), float(dk.mean()), float(dk.max()), bias))
+    worst_bias = sorted(rows, key=lambda r: r[4] / max(ENS_BIAS * r[2], ENS_BIAS_FLOOR), reverse=True)[:3]
+    worst_gross = sorted(rows, key=lambda r: r[1] / max(ENS_GROSS * r[3], ENS_GROSS_FLOOR), reverse=True)[:3]
+    msg = (f"{tag}: bf16 gradient gate: (i) rel. L2 over all {len(names)} tensors {e_all:.4f} (ceiling {GRAD_L2_BF16_CEIL}; ensemble "
+           f"{[round(float(x), 4) for x in ens_all]}); (ii) worst big-sum checksum {[(n, round(float(e), 4)) for _, e, n in errs_big[:2]]} (bound {GRAD_TOL_BF16_BIG}); "
+           f"(iii a) {len(small)} small tensors together {e_small:.4f}, ensemble {mu:.4f} +- {sd:.4f} (members {[round(float(x), 4) for x in ens_small]}); "
+           f"(iii b) worst bias (name, this, members' mean, members' max, error of the ensemble mean) "
+           f"{[(n, round(a, 4), round(b, 4), round(c, 4), round(d, 4)) for n, a, b, c, d in worst_bias]}; (iii c) worst single (name, this, members' max) "
+           f"{[(n, round(a, 4), round(c, 4)) for n, a, b, c, d in worst_gross]}")
+    print(msg)
+    assert e_all <= GRAD_L2_BF16_CEIL, (tag, "all-gradient L2 ceiling", e_all)
+    assert e_all <= 1.1 * (float(ens_all.mean()) + ENS_SIGMA * float(ens_all.std(ddof=1))), (tag, "all-gradient L2 vs ensemble", e_all, ens_all)
+    assert errs_big and errs_big[0][0] <= 1.0, (tag, "big-sum checksums", errs_big[:6])
+    assert e_small <= 1.1 * (mu + ENS_SIGMA * sd), (tag, "small tensors vs ensemble", e_small, mu, sd)
+    for n, d_this, d_mean, d_max, bias in rows:
+        assert bias <= max(ENS_BIAS * d_mean, ENS_BIAS_FLOOR), (tag, "biased gradient", n, bias, d_mean)
+        assert d_this <= max(ENS_GROSS * d_max, ENS_GROSS_FLOOR), (tag, "gross error", n, d_this, d_max)
+    return msg
+
+
 # d(sampling offset) is a ONE-SIDED derivative wherever a sampling point sits exactly on a pixel centre (bilinear
 # interpolation has a kink there).  With the reference's default init every offset is bias only, and the biases of the
 # axis / diagonal heads are exact integers (k * (1,0), k * (1,1), ...), so at init=True which side the reference itself takes
@@ -413,7 +515,7 @@ def _rotation_amplification(name, batch, pad, init):
     return torch.stack(amps).view(hs.shape[0], hs.shape[1], hs.shape[2])
 
 
-def _grad_errors(g, grad_of, gtol, init):
+def _grad_errors(g, grad_of, gtol, init, select=None):
     """[(error / tolerance, error, name)] of every parameter gradient against the golden's checksums, as fractions of the tensor's
     gradient norm.  Encoder sampling_offsets at the reference's own init: the no-kink channels against their own checksums at
     the plain tolerance, the kink channels finite and norm-bounded."""
@@ -421,6 +523,8 @@ def _grad_errors(g, grad_of, gtol, init):
     nokink = {str(n): (c, int(k)) for n, c, k in zip(g["nokink_names"], g["nokink_checksums"], g["kink_channels"])} if (init and "nokink_names" in g.files) else {}
     for n, ref in zip(g["grad_names"], g["grad_checksums"]):
         n = str(n)
+        if select is not None and not select(n):
+            continue
         gr = grad_of(n)
         if np.isnan(ref).all():
             assert gr is None, n
@@ -474,9 +578,9 @@ def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, b
         layer of the `_init` goldens only.
     The printed line says for each run what the plain bound would have given."""
     g = np.load(os.path.join(golden_dir, f"poet_{name}_b{batch}{'_pad' if pad else ''}{'_init' if init else ''}.npz"))
-    gtol16 = GRAD_TOL_BF16_AT[(name, batch, init)]
-    passes = [(torch.float32, TOL_F32, GRAD_TOL_F32, False), (torch.bfloat16, TOL_BF16, gtol16, False), (torch.bfloat16, TOL_BF16, gtol16, True)]
+    passes = [(torch.float32, TOL_F32, GRAD_TOL_F32, False), (torch.bfloat16, TOL_BF16, None, False), (torch.bfloat16, TOL_BF16, None, True)]
     amp = None
+    g32 = ens = None                # the fp32 policy's gradients (pinned to the golden in the first pass) and the bf16 noise ensemble
     for dtype, tol, gtol, arena in passes:
         r = gpu(name, batch, pad, dtype, default_init=init)
         model, crit = r["model"], r["crit"]
@@ -520,16 +624,24 @@ def test_full_size_forward_backward_vs_reference_golden(gpu, golden_dir, name, b
         gof = lambda p: getattr(p, "_grad_view", None) if getattr(p, "_grad_view", None) is not None else p.grad
         grad_of = lambda n: gof(params[n])
         grad_of.param = lambda n: params[n]
-        errs = _grad_errors(g, grad_of, gtol, init)
-        nw = _norm_worst()
-        print(f"{name} b{batch} init={init} {dtype}{' arena' if arena else ''}: worst gradient-NORM error {nw[0]:.2e} ({nw[1]})")
-        print(f"{name} b{batch} init={init} {dtype}{' arena' if arena else ''}: max|dt| {dt:.2e}; max|dR| final layer {dR[-1].max():.2e} all layers {dR.max():.2e} "
-              f"(rms {dR.pow(2).mean().sqrt():.2e}){rule}; max loss err {lerr:.2e}; worst grad checksums {[(n, round(e, 4)) for _, e, n in errs[:3]]}")
+        tag = f"{name} b{batch} init={init} {dtype}{' arena' if arena else ''}"
+        if dtype == torch.float32:
+            errs = _grad_errors(g, grad_of, gtol, init)
+            nw = _norm_worst()
+            print(f"{tag}: worst gradient-NORM error {nw[0]:.2e} ({nw[1]})")
+            g32 = _collect_grads(model)
+        print(f"{tag}: max|dt| {dt:.2e}; max|dR| final layer {dR[-1].max():.2e} all layers {dR.max():.2e} "
+              f"(rms {dR.pow(2).mean().sqrt():.2e}){rule}; max loss err {lerr:.2e}" + (f"; worst grad checksums {[(n, round(e, 4)) for _, e, n in errs[:3]]}" if dtype == torch.float32 else ""))
         assert dt < tol, (dtype, dt)
         assert (dR / allow).max().item() < tol, (dtype, dR.max().item(), (dR / allow).max().item())
         assert (dR[-1] / allow[-1]).max().item() < tol, (dtype, dR[-1].max().item())     # the model outputs
         assert lerr < (2e-4 if dtype == torch.float32 else 2e-2) * max(1.0, float(np.abs(g["loss_values"]).max())), lerr
-        assert errs[0][0] <= 1.0, errs[:8]
+        if dtype == torch.float32:
+            assert errs[0][0] <= 1.0, errs[:8]
+        else:
+            if ens is None:
+                ens = _bf16_ensemble(gpu, name, batch, pad, init)
+            _gate_bf16(tag, g, _collect_grads(model), g32, ens, init, grad_of)
 
 
 BENCHED = [("ycbv", 16), ("lmo", 32), ("hires", 8)]      # BASELINE.json configs[1] / [3] / [4]: the batch sizes bench.py quotes numbers on
@@ -553,25 +665,32 @@ def test_benched_batch_sizes_vs_reference_golden_by_replication(gpu, golden_dir,
     gr_all = torch.from_numpy(np.concatenate([g["aux_rotation"], g["pred_rotation"][None]]))
     names = [str(x) for x in g["loss_names"]]
 
-    def check(tag, trans, rot, lv, grad_of, tol, gtol, ltol):
+    state = dict(g32=None, ens=None)
+
+    def check(tag, trans, rot, lv, grad_of, tol, gtol, ltol, model):
         assert trans.shape[1] == B and rot.shape[1] == B
         dt = (trans - gt_all).abs()                                # broadcast over the B copies
         dR = (rot - gr_all).abs()
         spread = max((trans - trans[:, :1]).abs().max().item(), (rot - rot[:, :1]).abs().max().item())
         lerr = float(np.abs(lv - g["loss_values"]).max())
-        errs = _grad_errors(g, grad_of, gtol, False)
-        nw = _norm_worst()
-        print(f"{name} x{B} {tag}: worst gradient-NORM error {nw[0]:.2e} ({nw[1]})")
         print(f"{name} x{B} {tag}: max|dt| {dt.max():.2e}; max|dR| final layer {dR[-1].max():.2e} all layers {dR.max():.2e}; spread over the copies "
-              f"{spread:.2e}; max loss err {lerr:.2e}; worst grad checksums {[(n, round(e, 4)) for _, e, n in errs[:3]]}")
+              f"{spread:.2e}; max loss err {lerr:.2e}")
         assert dt.max().item() < tol and dR.max().item() < tol, (tag, dt.max().item(), dR.max().item())
         assert lerr < ltol * max(1.0, float(np.abs(g["loss_values"]).max())), (tag, lerr)
-        assert errs[0][0] <= 1.0, (tag, errs[:8])
+        if gtol is not None:                                       # the fp32 pass: checksums against the golden
+            errs = _grad_errors(g, grad_of, gtol, False)
+            nw = _norm_worst()
+            print(f"{name} x{B} {tag}: worst gradient-NORM error {nw[0]:.2e} ({nw[1]}); worst grad checksums {[(n, round(e, 4)) for _, e, n in errs[:3]]}")
+            assert errs[0][0] <= 1.0, (tag, errs[:8])
+            state["g32"] = _collect_grads(model)
+        else:                                                      # the bf16 gradient gate (the bs-1 golden's all-gradient bound: B copies average the same realisation)
+            if state["ens"] is None:
+                state["ens"] = _bf16_ensemble(gpu, name, 1, False, False, replicate=B)
+            _gate_bf16(f"{name} x{B} {tag}", g, _collect_grads(model), state["g32"], state["ens"], False, grad_of)
 
     gof = lambda p: getattr(p, "_grad_view", None) if getattr(p, "_grad_view", None) is not None else p.grad
-    gtol16 = GRAD_TOL_BF16_AT[(name, 1, False)]                 # the bs-1 golden's own bound: B copies average the same realisation
-    for dtype, tol, gtol, ltol, arena in [(torch.float32, TOL_F32, GRAD_TOL_F32, 2e-4, False), (torch.bfloat16, TOL_BF16, gtol16, 2e-2, False),
-                                          (torch.bfloat16, TOL_BF16, gtol16, 2e-2, True)]:
+    for dtype, tol, gtol, ltol, arena in [(torch.float32, TOL_F32, GRAD_TOL_F32, 2e-4, False), (torch.bfloat16, TOL_BF16, None, 2e-2, False),
+                                          (torch.bfloat16, TOL_BF16, None, 2e-2, True)]:
         r = gpu(name, 1, False, dtype, replicate=B)
         model, crit = r["model"], r["crit"]
         model.eval()                                            # dropout off, as in the golden run
@@ -593,7 +712,7 @@ def test_benched_batch_sizes_vs_reference_golden_by_replication(gpu, golden_dir,
         params = dict(model.named_parameters())
         grad_of = lambda n: gof(params[n])
         grad_of.param = lambda n: params[n]
-        check(f"{dtype}{' arena' if arena else ''}", trans, rot, lv, grad_of, tol, gtol, ltol)
+        check(f"{dtype}{' arena' if arena else ''}", trans, rot, lv, grad_of, tol, gtol, ltol, model)
         del r, model, crit, out, losses, total, params
         torch.cuda.empty_cache()
     # the replayed graphs (bench.py's launch mode): train() with dropout 0 == eval(); lr = 0 and no weight decay: parameters frozen
@@ -609,7 +728,45 @@ def test_benched_batch_sizes_vs_reference_golden_by_replication(gpu, golden_dir,
     params = dict(r["model"].named_parameters())
     grad_of = lambda n: gof(params[n])
     grad_of.param = lambda n: params[n]
-    check("bf16 graph replay", tr.s_trans.detach().float().cpu(), tr.s_rot.detach().float().cpu(), lv, grad_of, TOL_BF16, gtol16, 2e-2)
+    check("bf16 graph replay", tr.s_trans.detach().float().cpu(), tr.s_rot.detach().float().cpu(), lv, grad_of, TOL_BF16, None, 2e-2, r["model"])
+
+
+def test_bf16_gradient_gate_rejects_wrong_gradients(gpu, golden_dir):
+    """The gate must FAIL on gradients that are wrong by a few percent (round 5's statistic admitted 5 %): (1) every encoder gradient
+    scaled by 1.03 -- caught by the big-sum checksums against the golden (2.5e-2); (2) one decoder tensor wrong by 8 % in EVERY
+    realisation (a systematic error: the single run and all ensemble members alike) -- caught by the bias test on the ensemble
+    mean, although 8 % is inside what ONE realisation of a noisier tensor may show; (3) one decoder tensor of THIS realisation
+    off by 60 % -- the gross test.  The unmodified gradients pass."""
+    name, batch, pad, init = "lmo", 1, False, False
+    g = np.load(os.path.join(golden_dir, f"poet_{name}_b{batch}.npz"))
+    runs = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        r = gpu(name, batch, pad, dtype)
+        model, crit = r["model"], r["crit"]
+        model.eval()
+        out, n_boxes = model(r["samples"], r["targets"])
+        losses = crit(out, r["targets"], n_boxes)
+        model.zero_grad()
+        sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict).backward()
+        torch.cuda.synchronize()
+        runs[dtype] = _collect_grads(model)
+    g32, grads = runs[torch.float32], runs[torch.bfloat16]
+    ens = _bf16_ensemble(gpu, name, batch, pad, init)
+
+    def gate(tag, gr, members):
+        return _gate_bf16(tag, g, gr, g32, members, init, lambda n: gr.get(n))
+    gate("unmodified", grads, ens)
+    enc = {n: (v * 1.03 if n.startswith("transformer.encoder.") else v) for n, v in grads.items()}
+    with pytest.raises(AssertionError, match="big-sum checksums"):
+        gate("encoder x 1.03", enc, ens)
+    small = [n for n in grads if not _big_sum(n) and n in g32 and float(g32[n].double().pow(2).sum()) > 1e-24]
+    quiet = min(small, key=lambda n: np.mean([_rel_l2(a, b, [n]) for a, b in ens]))        # the best-conditioned small tensor
+    sys_ = dict(grads); sys_[quiet] = grads[quiet] * 1.08
+    with pytest.raises(AssertionError, match="biased gradient"):
+        gate(f"{quiet} x 1.08 in every realisation", sys_, [(dict(a, **{quiet: a[quiet] * 1.08}), b) for a, b in ens])
+    one = dict(grads); one[quiet] = grads[quiet] * 1.6
+    with pytest.raises(AssertionError, match="gross error"):
+        gate(f"{quiet} x 1.6 in this realisation", one, ens)
 
 
 def test_arena_trainer_matches_oracle_step(gpu):
@@ -1439,6 +1596,48 @@ def test_prefetcher_feeds_the_trainer(gpu):
     assert n == 4 and pf.next() == (None, None)
 
 
+@pytest.mark.parametrize("on_device", [True, False])
+def test_packed_batches_equal_per_field_staging(gpu, on_device):
+    """GraphedTrainer.pack / step(PackedBatch) (round 6: one streaming copy per step instead of ~20 staging launches): two trainers
+    of the same model and seed, one fed (samples, targets) per step, one fed batches packed one step AHEAD (the prefetcher's
+    order: pack(i + 1) is issued before step(i) -- the two-slot ring must keep batch i intact), on four DIFFERENT batches
+    (targets on the device and on the host): same losses, bit-identical parameters."""
+    import poet_amd
+    from oracle.formula import CONFIGS, make_inputs
+    cfg = CONFIGS["tiny"]
+    batches = []
+    r0 = gpu("tiny", 2, True, "bf16", dropout=0.0)
+    for i in range(4):
+        feats, _, targets = make_inputs(cfg, seed=700 + i, batch=2, pad=True)
+        tg = [{k: (v.cuda() if on_device else v) for k, v in t.items()} for t in targets]
+        batches.append((r0["samples"], tg))
+    results = []
+    for mode in ("fields", "packed"):
+        r = gpu("tiny", 2, True, "bf16", dropout=0.0)
+        r["model"].train()
+        crit = poet_amd.SetCriterion(poet_amd.PoseMatcher(device_assign=True), poet_amd.build_weight_dict(r["cfg"]["dec_layers"]))
+        tr = poet_amd.GraphedTrainer(r["model"], crit, lr=2e-4, weight_decay=1e-4, max_norm=0.1, warm=1)
+        for _ in range(2):                                  # eager warm-up + capture, on batch 0
+            tr.step(*batches[0])
+        assert tr.ready and tr.graph_loss
+        losses = []
+        if mode == "fields":
+            for b in batches:
+                losses.append(float(tr.step(*b)[0]))
+        else:
+            nxt = tr.pack(*batches[0])
+            for i in range(len(batches)):
+                cur = nxt
+                if i + 1 < len(batches):
+                    nxt = tr.pack(*batches[i + 1])           # staged under step i
+                losses.append(float(tr.step(cur)[0]))
+        torch.cuda.synchronize()
+        results.append((losses, tr.arena.flat.clone()))
+    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
+    assert len(set(results[0][0])) == len(batches)          # the four batches really differ
+
+
 def test_images_without_objects(gpu):
     """Ragged and empty targets (the reference pads the query set per image and clamps the box count to >= 1,
     pose_estimation_transformer.py:604-606): one image without objects == the oracle's loss; a batch with no objects at all
@@ -1532,7 +1731,7 @@ def test_bench_self_launch_runs_the_dp_path_with_one_rank(gpu):
     import json, subprocess, sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "POET_DP_SINGLE_COLLECTIVE")}
-    env.update(POET_BENCH_SELF_LAUNCH="1", POET_FORCE_COLLECTIVES="1")
+    env.update(POET_BENCH_SELF_LAUNCH="1", POET_FORCE_COLLECTIVES="1", POET_BENCH_STRONG="1")      # (+ the strong-scaling leg, forced at one rank)
     p = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "cfg0", "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
@@ -1541,8 +1740,13 @@ def test_bench_self_launch_runs_the_dp_path_with_one_rank(gpu):
     out = json.loads(lines[0])
     c = out["config"]
     assert out["n_gpus"] == 1 and out["value"] > 0 and np.isfinite(c["final_loss"])
-    assert c["dp_mode_trial"]["chosen"] in ("single", "buckets") and c["dp_mode_trial"]["single_ms_per_step"] > 0 and c["dp_mode_trial"]["buckets_ms_per_step"] > 0
+    assert c["dp_mode_trial"]["chosen"] in ("single", "buckets", "single_bf16") and c["dp_mode_trial"]["single_ms_per_step"] > 0 and c["dp_mode_trial"]["buckets_ms_per_step"] > 0
+    assert c["dp_mode_trial"]["single_bf16_ms_per_step"] > 0                       # (round 6: bf16 gradient transport is a candidate of the trial)
+    assert ("bf16" in c["dp_mode"]) == (c["dp_mode_trial"]["chosen"] == "single_bf16")
     assert "allreduce_exposed_ms" in c and c["with_collectives_ms"] > 0 and c["without_collectives_ms"] > 0
+    st = out["strong_scaling"]                                                      # SURVEY 8(d)'s secondary line rides in the same JSON line
+    assert "error" not in st, st
+    assert st["scaling"] == "strong" and st["per_gpu_batch"] == 1 and st["global_batch"] == 1 and st["ms_per_step"] > 0 and st["images_per_s"] > 0
     # a launcher that cannot place its ranks says so instead of hanging
     p2 = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1)], env=env, capture_output=True, text=True, timeout=300)
     assert p2.returncode != 0 and "GPU(s)" in (p2.stderr + p2.stdout)
