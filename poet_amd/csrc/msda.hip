@@ -559,7 +559,7 @@ struct ShMap {
     }
 };
 
-template <int QG, bool QH, int VH>       // VH: 0 bf16 value maps, 1 fp16 (v_fma_mix_f32), 2 fp16 with the 8 terms of a level summed in packed fp16 first
+template <int QG, bool QH, bool VH>      // VH: fp16 value maps (v_fma_mix_f32 on the packed halves)
 __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const MsdaP p) {
     __shared__ __attribute__((aligned(16))) char lds[SH_WAVES * SH_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -592,18 +592,10 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
             Raw8<bf16_t> v0[4], v1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { v0[i].load(p.value, r[i].x + lane_off); v1[i].load(p.value, r[i].y + lane_off); }
-            uint32_t t16[4] = {0u, 0u, 0u, 0u};                     // (VH == 2) this level's 8 terms per channel, packed fp16
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float w0 = __uint_as_float(r[i].z), w1 = __uint_as_float(r[i].w);
-                if constexpr (VH == 2) {
-                    const uint32_t wp = pack_h2(w0, w1);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(t16[j]) : "v"(v0[i].v[j]), "v"(wp));
-                        asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(t16[j]) : "v"(v1[i].v[j]), "v"(wp));
-                    }
-                } else if constexpr (VH == 1) {
+                if constexpr (VH) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { fmix_lo(acc[2 * j], v0[i].v[j], w0); fmix_hi(acc[2 * j + 1], v0[i].v[j], w0); }
 #pragma unroll
@@ -614,10 +606,6 @@ __global__ __launch_bounds__(SH_WAVES * 64) void msda_fwd_shared_kernel(const Ms
 #pragma unroll
                     for (int ch = 0; ch < 8; ++ch) acc[ch] = fmaf(w1, v1[i].f(ch), acc[ch]);
                 }
-            }
-            if constexpr (VH == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { fmix_lo(acc[2 * j], t16[j], 1.f); fmix_hi(acc[2 * j + 1], t16[j], 1.f); }
             }
         }
         sh_wave_sync();                                             // (the next pass overwrites the records)
@@ -1509,8 +1497,6 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
             const dim3 grid((unsigned)((rows + SH_WAVES * qg - 1) / (SH_WAVES * qg))), blk(SH_WAVES * 64);
 #define POET_SH_LAUNCH(Q, H, V) do { if (BWD) hipLaunchKernelGGL((msda_bwd_shared_kernel<Q, H, V>), grid, blk, dyn, st, p); \
                                      else hipLaunchKernelGGL((msda_fwd_shared_kernel<Q, H, V>), grid, blk, dyn, st, p); } while (0)
-            static const int f16pk = [] { const char* e = getenv("POET_SH_F16_PK"); return e ? atoi(e) : 0; }();       // (A/B aid, read once)
-            if (p.v_f16 && !BWD && f16pk && qg == 4) { hipLaunchKernelGGL((msda_fwd_shared_kernel<4, true, 2>), grid, blk, dyn, st, p); return; }
             if (p.v_f16) { if (qg == 1) POET_SH_LAUNCH(1, true, true); else POET_SH_LAUNCH(4, true, true); }      // (fp16 maps come with fp16 offsets | logits)
             else if (p.q_f16) { if (qg == 1) POET_SH_LAUNCH(1, true, false); else POET_SH_LAUNCH(4, true, false); }
             else if (qg == 1) POET_SH_LAUNCH(1, false, false);
