@@ -186,10 +186,14 @@ def _run_model(name, batch, pad, full, default_init=False, bbox_mode="gt", class
             if "encoder" in n and "sampling_offsets" in n and p.grad is not None:
                 b = params[n.rsplit(".", 1)[0] + ".bias"].detach()
                 kink = (b - b.round()).abs() < 1e-3
+                if not 0 < int(kink.sum()) < b.numel():
+                    continue              # (`tiny`: 4 heads = the four axis directions, EVERY channel of the bias is an integer -- there is
+                                          # no kink-free restriction to pin: that fixture carries the whole-tensor checksums only)
                 kn.append(n)
                 ks.append(checksum(p.grad[~kink]))
                 kc.append(int(kink.sum()))
-        rec["nokink_names"], rec["nokink_checksums"], rec["kink_channels"] = np.asarray(kn), np.stack(ks), np.asarray(kc)
+        if kn:
+            rec["nokink_names"], rec["nokink_checksums"], rec["kink_channels"] = np.asarray(kn), np.stack(ks), np.asarray(kc)
     tag = f"{name}_b{batch}{'_pad' if pad else ''}{'_init' if default_init else ''}"
     if (bbox_mode, class_mode) != ("gt", "specific"):
         tag += f"_{bbox_mode}_{class_mode}"

@@ -237,7 +237,8 @@ class ParamArena:
         self.flat_bf16_lo.copy_(self.flat - self.flat_bf16.float())
 
     def zero_grad(self):
-        ops.zero_(self.grad)
+        # (a CPU arena exists for the reducer's bookkeeping tests over gloo only -- no kernel ever runs on it)
+        ops.zero_(self.grad) if self.grad.is_cuda else self.grad.zero_()
 
     def step(self, max_norm: float = 0.1, step_dev=None):
         """clip_grad_norm_(max_norm) + AdamW (engine.py:77-81) on the flat arenas.  With `step_dev` (a device word) the
@@ -246,7 +247,7 @@ class ParamArena:
         gs = 1.0 / self.world
         sq = None
         if max_norm > 0:
-            ops.zero_(self.sq)
+            ops.zero_(self.sq) if self.sq.is_cuda else self.sq.zero_()
             ops.sqnorm(self.grad, self.sq)
             sq = self.sq
         for a, b, lr in self.groups:
