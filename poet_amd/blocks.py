@@ -189,16 +189,20 @@ def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=Non
     rows, d = res.shape[0], W.shape[0]
     mixed = x_in.dtype == torch.bfloat16 and res.dtype == torch.float32
     Wt, sp = Wf(W, x_in, split)
-    # (round 6) ... as IEEE fp16 where the LayerNorm launch is the only reader (ops.ln_f16: >= 4096 rows, d = 256): 2^-11 relative, a
-    # quarter of the rounding the LayerNorm's own bf16 operand copy applies next, and 2 bytes per element less on both sides
-    tmp = empty((rows, d), (torch.float16 if ops.ln_f16(rows, d) else torch.float32) if (sp and mixed) else x_in.dtype, res)
     lo = getattr(W, "_bf16_lo", None) if (sp and mixed and rows >= 4096 and W.shape[1] >= 512 and W.shape[0] == 256) else None
     # (the long-K kernel's own admission rules, gemm_pipe.hip:gemm_pipe_try: K a multiple of 64, 16-byte aligned operands, row
     # strides of 8 / 4 elements -- anything else, e.g. dim_feedforward = 1000 or a sliced x_in, keeps the fp32-master split kernel)
     if lo is not None and not (getattr(W, "_bf16", None) is not None and W.shape[1] % 64 == 0 and x_in.stride(-1) == 1 and x_in.stride(0) % 8 == 0 and x_in.data_ptr() % 16 == 0
-                               and tmp.data_ptr() % 16 == 0 and tmp.stride(0) % 4 == 0 and lo.data_ptr() % 16 == 0 and W._bf16.data_ptr() % 16 == 0):
+                               and lo.data_ptr() % 16 == 0 and W._bf16.data_ptr() % 16 == 0):
         lo = None
-    if lo is not None and getattr(W, "_bf16", None) is not None and ops.pipe_split():
+    use_pipe = lo is not None and getattr(W, "_bf16", None) is not None and ops.pipe_split()
+    # (round 6) ... as IEEE fp16 where the LayerNorm launch is the only reader (ops.ln_f16: >= 4096 rows, d = 256): 2^-11 relative, a
+    # quarter of the rounding the LayerNorm's own bf16 operand copy applies next, and 2 bytes per element less on both sides -- on the
+    # kernels that store it: the K = 256 streaming kernel and the long-K pipeline (a K >= 512 product WITHOUT the arena's two weight
+    # images -- plain modules, GraphedInference -- runs the K-chunked fp32-master kernel, which writes fp32)
+    f16_ok = ops.ln_f16(rows, d) and (W.shape[1] == 256 or use_pipe)
+    tmp = empty((rows, d), (torch.float16 if f16_ok else torch.float32) if (sp and mixed) else x_in.dtype, res)
+    if use_pipe:
         # long-K split product on the arena's two bf16 images, tmp = x (hi + lo)^T + b in ONE pass over x (gemm_pipe.hip):
         # every activation fragment staged in LDS meets both weight images
         ops.linear_fwd(x_in, W._bf16, b, tmp, W_lo=lo)
