@@ -370,10 +370,12 @@ int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, const float* 
  * the predictions, fully written) = d losses[l][0] / d trans[l] and d losses[l][1] / d rot[l].
  * n_obj_dev (optional, device int32): the pair count is read from device memory instead of n_obj -- the count
  * poet_match_gather leaves behind, so that matcher + loss can sit inside a captured HIP graph (the match arrays then
- * have capacity NQ). */
+ * have capacity NQ).  weights (ABI v5, optional, device (L, 2)): grad_trans[l] / grad_rot[l] leave multiplied by weights[l][0] /
+ * weights[l][1] (the loss weights of pose_estimation_transformer.py:657-674's weight_dict), and with `total` (optional, one device
+ * float) *total = sum_l weights[l] . losses[l] -- the scalar engine.py:66 calls backward on. */
 int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_idx, const float* tgt_trans,
                    const float* tgt_rot, int n_obj, int L, int NQ, float* losses, float* grad_trans, float* grad_rot,
-                   const int32_t* n_obj_dev, void* stream);
+                   const int32_t* n_obj_dev, const float* weights, float* total, void* stream);
 
 /* Batched on-device assignment, models/matcher.py:158-229 in 'gt' mode: per image the L1 cost between the first n_pred[i]
  * query boxes (pred_boxes (N,Q,4) fp32) and the image's targets (tgt_boxes rows [tgt_off[i], tgt_off[i+1]), fp32 (T,4)),

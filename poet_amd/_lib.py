@@ -73,7 +73,7 @@ _PROTOS = {
     "poet_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, vp, i64, vp], i32),
     "poet_pose_finish_fwd": ([vp, vp, vp, vp, vp, i32, i32, vp], i32),
     "poet_pose_finish_bwd": ([vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
-    "poet_pose_loss": ([vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], i32),
+    "poet_pose_loss": ([vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp], i32),
     "poet_lsa_boxes": ([vp, vp, vp, vp, f32, i32, i32, vp, vp, vp], i32),
     "poet_match_gather": ([vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
     "poet_sqnorm": ([vp, i64, vp, vp], i32),

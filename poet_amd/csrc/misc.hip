@@ -415,9 +415,17 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict_
                                                         const int64_t* __restrict__ qi, const float* __restrict__ tt,
                                                         const float* __restrict__ tr, int n_obj, int NQ,
                                                         float* __restrict__ losses, float* __restrict__ gt, float* __restrict__ gr,
-                                                        const int32_t* __restrict__ n_obj_dev) {
-    const int l = blockIdx.x, tid = threadIdx.x;
+                                                        const int32_t* __restrict__ n_obj_dev, int L, const float* __restrict__ weights,
+                                                        float* __restrict__ total) {
+    // (ABI v5) weights (L, 2): the gradients leave already multiplied by their loss weight and *total = sum_l w . losses[l] -- then ONE
+    // workgroup walks the layers (the weighted sum needs them all; the work is a few hundred pairs per layer), so that the captured
+    // step holds no framework elementwise / reduction kernels behind the loss
+    const int tid = threadIdx.x;
     if (n_obj_dev) n_obj = min(max(*n_obj_dev, 0), NQ);
+    __shared__ float red[2][4];
+    float tot = 0.f;
+    for (int l = blockIdx.x; l < L; l += gridDim.x) {
+    const float w0 = weights ? weights[l * 2] : 1.f, w1 = weights ? weights[l * 2 + 1] : 1.f;
     const float* T = trans + (int64_t)l * NQ * 3;
     const float* Rm = rot + (int64_t)l * NQ * 9;
     float* GT = gt + (int64_t)l * NQ * 3;
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict_
         for (int k = 0; k < 3; ++k) { d[k] = T[q * 3 + k] - tt[i * 3 + k]; s2 += d[k] * d[k]; }
         const float nrm = sqrtf(s2);
         lt += nrm;
-        const float sc = nrm > 0.f ? inv_n / nrm : 0.f;            // d||d||/dd = d/||d|| (0 at d = 0, where torch gives NaN)
+        const float sc = nrm > 0.f ? w0 * inv_n / nrm : 0.f;       // d||d||/dd = d/||d|| (0 at d = 0, where torch gives NaN)
 #pragma unroll
         for (int k = 0; k < 3; ++k) GT[q * 3 + k] = d[k] * sc;
         float tg[9], trc = 0.f;
@@ -443,18 +451,22 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict_
         const float x = 0.5f * (trc - 1.f);
         const float xc = fminf(fmaxf(x, -1.f + 1e-6f), 1.f - 1e-6f);
         lr += acosf(xc);
-        const float dac = (x == xc) ? -0.5f * inv_n * rsqrtf(1.f - xc * xc) : 0.f;   // clamp passes the gradient only inside
+        const float dac = (x == xc) ? -0.5f * w1 * inv_n * rsqrtf(1.f - xc * xc) : 0.f;   // clamp passes the gradient only inside
 #pragma unroll
         for (int k = 0; k < 9; ++k) GR[q * 9 + k] = dac * tg[k];
     }
     lt = wave_sum(lt); lr = wave_sum(lr);
-    __shared__ float red[2][4];
     if ((tid & 63) == 0) { red[0][tid >> 6] = lt; red[1][tid >> 6] = lr; }
     __syncthreads();
     if (tid == 0) {
-        losses[l * 2 + 0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_n;
-        losses[l * 2 + 1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_n;
+        const float a = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_n, b = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_n;
+        losses[l * 2 + 0] = a;
+        losses[l * 2 + 1] = b;
+        tot += w0 * a + w1 * b;
     }
+    __syncthreads();                                              // (red is reused by the next layer)
+    }
+    if (total && tid == 0) *total = tot;
 }
 
 __global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__ rot_all, const int32_t* __restrict__ cls,
@@ -961,11 +973,12 @@ extern "C" int poet_pose_finish_bwd(const float* rot_all, const int32_t* cls, co
 
 extern "C" int poet_pose_loss(const float* trans, const float* rot, const int64_t* query_idx, const float* tgt_trans,
                               const float* tgt_rot, int n_obj, int L, int NQ, float* losses, float* grad_trans, float* grad_rot,
-                              const int32_t* n_obj_dev, void* stream) {
+                              const int32_t* n_obj_dev, const float* weights, float* total, void* stream) {
     POET_CHECK(trans && rot && losses && grad_trans && grad_rot && L > 0 && NQ > 0 && n_obj >= 0, POET_ERR_ARG, "pose_loss: bad args");
     POET_CHECK((n_obj == 0 && !n_obj_dev) || (query_idx && tgt_trans && tgt_rot), POET_ERR_ARG, "pose_loss: null match arrays");
-    hipLaunchKernelGGL(pose_loss_kernel, dim3(L), dim3(256), 0, ST, trans, rot, query_idx, tgt_trans, tgt_rot, n_obj, NQ, losses,
-                       grad_trans, grad_rot, n_obj_dev);
+    POET_CHECK(!total || weights, POET_ERR_ARG, "pose_loss: total needs weights");
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(total ? 1 : L), dim3(256), 0, ST, trans, rot, query_idx, tgt_trans, tgt_rot, n_obj, NQ, losses,
+                       grad_trans, grad_rot, n_obj_dev, L, weights, total);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

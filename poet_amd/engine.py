@@ -1057,13 +1057,14 @@ class GraphedTrainer(Trainer):
                                      n_out=self.s_nobj)
                     self.s_lossvec = torch.empty((L, 2), dtype=torch.float32, device=dev)
                     gt_, gr_ = torch.empty_like(trans), torch.empty_like(rot)
-                    ops.pose_loss(trans.detach(), rot.detach(), self.s_qi, self.s_tt, self.s_tr, 0, self.s_lossvec, gt_, gr_,
-                                  n_obj_dev=self.s_nobj)
                     w = crit._w
-                    assert w.shape[0] == L, (w.shape, L)
-                    self.s_total = (self.s_lossvec * w).sum()
-                    self.s_dtrans = gt_ * w[:, 0].reshape(L, *([1] * (gt_.dim() - 1)))
-                    self.s_drot = gr_ * w[:, 1].reshape(L, *([1] * (gr_.dim() - 1)))
+                    assert tuple(w.shape) == (L, 2), (w.shape, L)
+                    # the loss weights ride in the kernel: weighted gradients and the weighted total leave it directly (no framework
+                    # multiply / reduce kernels behind the loss inside the captured step)
+                    self.s_total = torch.empty((), dtype=torch.float32, device=dev)
+                    ops.pose_loss(trans.detach(), rot.detach(), self.s_qi, self.s_tt, self.s_tr, 0, self.s_lossvec, gt_, gr_,
+                                  n_obj_dev=self.s_nobj, weights=w.contiguous().float(), total=self.s_total)
+                    self.s_dtrans, self.s_drot = gt_, gr_
         self.s_rot, self.s_trans = rot, trans
         # the aleatoric heads' log-variances (pose_estimation_transformer.py:402-411) are two more static outputs of the forward graph
         al = getattr(m, "_last_aleatoric", None)

@@ -705,13 +705,16 @@ def pose_finish_fwd(rot_all, trans_all, cls, rot, trans, R, ncls):
                                         trans.data_ptr(), R, ncls, _stream()), "poet_pose_finish_fwd")
 
 
-def pose_loss(trans, rot, qi, tt, tr, n_obj, losses, gt, gr, n_obj_dev=None):
+def pose_loss(trans, rot, qi, tt, tr, n_obj, losses, gt, gr, n_obj_dev=None, weights=None, total=None):
     """trans (L,NQ,3), rot (L,NQ,3,3) fp32 contiguous; qi int64 (n_obj), tt (n_obj,3), tr (n_obj,3,3) fp32.  n_obj_dev (int32
-    device word): the count is read on the device (graph capture; qi / tt / tr then have capacity NQ)."""
+    device word): the count is read on the device (graph capture; qi / tt / tr then have capacity NQ).  weights (L,2) fp32: the
+    gradients leave multiplied by their loss weights; total (1,) fp32: the weighted sum of the losses."""
+    if weights is not None and (weights.dtype != torch.float32 or not weights.is_contiguous() or tuple(weights.shape) != (trans.shape[0], 2)):
+        raise ValueError("pose_loss: weights must be a contiguous fp32 (L, 2) tensor")
     lib = _lib.load()
     L, NQ = trans.shape[0], trans.numel() // (trans.shape[0] * 3)
     _lib.check(lib.poet_pose_loss(_req(trans, "trans").data_ptr(), rot.data_ptr(), _ptr(qi) or 0, _ptr(tt) or 0, _ptr(tr) or 0, n_obj, L, NQ,
-                                  losses.data_ptr(), gt.data_ptr(), gr.data_ptr(), _ptr(n_obj_dev), _stream()), "poet_pose_loss")
+                                  losses.data_ptr(), gt.data_ptr(), gr.data_ptr(), _ptr(n_obj_dev), _ptr(weights), _ptr(total), _stream()), "poet_pose_loss")
     return losses
 
 

@@ -1319,6 +1319,14 @@ def test_pose_loss_fused_matches_torch(ops):
     assert torch.allclose(t1.grad.cpu(), t0.grad, atol=1e-6, rtol=1e-4)
     # the layer-2 pair with an identical target sits exactly on the clamp: torch passes no gradient there either
     assert torch.allclose(r1.grad.cpu(), r0.grad, atol=2e-5, rtol=2e-3), (r1.grad.cpu() - r0.grad).abs().max()
+    # (ABI v5) the loss weights inside the kernel: weighted gradients + the weighted total in ONE launch, count read on the device
+    # (what GraphedTrainer captures: no framework multiply / reduce kernels behind the loss)
+    lv = torch.empty(L, 2, device="cuda"); gt = torch.empty_like(dev(trans)); gr = torch.empty_like(dev(rot)); tot = torch.empty((), device="cuda")
+    ops.pose_loss(dev(trans), dev(rot), dev(qi), dev(tt), dev(tr), 0, lv, gt, gr, n_obj_dev=torch.tensor([n_obj], dtype=torch.int32, device="cuda"),
+                  weights=dev(w), total=tot)
+    assert torch.allclose(lv.cpu(), ref.detach(), atol=2e-5, rtol=1e-5)
+    assert abs(float(tot) - float((ref.detach() * w).sum())) < 2e-5 * max(1.0, float((ref.detach() * w).sum()))
+    assert torch.allclose(gt.cpu(), t0.grad, atol=1e-6, rtol=1e-4) and torch.allclose(gr.cpu(), r0.grad, atol=2e-5, rtol=2e-3)
 
 
 # ------------------------------------------------------------------ latency-oriented fp32 kernels (gemm_small.hip)
