@@ -602,7 +602,10 @@ def main():
                                        "pmc": pmc_mfma_summary(args.config)}
             if out["roofline"]["kernel"].startswith("msda_bwd_dvalue_scatter"):
                 # the contract's two bounds do not name this kernel's real limiter; say so next to the HBM fraction
-                out["roofline"]["limiter"] = "VALU issue, not HBM: ~310 instructions per 4 queries x 64 corners x 16 channels, 160 of them half-rate DPP / convert (2.5 per ds_add_u32 wave-instruction, 26 M of those per launch); with the LDS atomics compiled out the accumulate phase is only 7 % faster: DESIGN.md section 5/9"
+                out["roofline"]["limiter"] = ("two on-chip pipes, not HBM: VALU issue (~310 instructions per 4 queries x 64 corners x 16 channels = ~258 us) AND the LDS "
+                                              "atomic pipe (1.67 G lane-atomics per launch at its measured 6.8 T/s = 246 us) at ~70 % each, + ~65 us of max pass and flush; "
+                                              "round 6 moved the 64 x 16 weight x gradient products per query-head to the matrix pipe (v_mfma_f32_4x4x1 outer products: "
+                                              "VALU per iteration 277 -> 126 ns, parity-exact) and the kernel got 5 % SLOWER: DESIGN.md sections 0 and 8b")
             out["kernel_breakdown_ms_per_step"] = {k: round(v["total_ms"] / prof_steps, 3)
                                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
             bsum = sum(v["total_ms"] for v in prof.values()) / prof_steps
