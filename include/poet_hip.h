@@ -29,8 +29,8 @@
  *   poet_ln_fwd / poet_ln_bwd
  *       `x = norm(x + dropout(y))`  (deformable_transformer.py:202-203,195-196,279-287,271-272).
  *   poet_mha_fwd / poet_mha_bwd
- *       nn.MultiheadAttention core over <= 128 queries, head dim 16 / 32 / 64 (deformable_transformer.py:277-278; backward at
- *       head dim 64: <= 114 queries -- the Q x Q score matrices live in the CU's 160 KB of LDS).
+ *       nn.MultiheadAttention core (deformable_transformer.py:277-278): LDS-resident Q x Q scores up to 128 queries at head dim
+ *       16 / 32 / 64 (backward at head dim 64: 114), a generic wave-per-row form for any head dim and up to 2048 queries.
  *   poet_pos_sine / poet_bbox_sine
  *       models/position_encoding.py:40-60 and :71-84.
  *   poet_groupnorm_* / poet_im2col3x3s2 / poet_col2im3x3s2_add / poet_nchw_to_tokens / poet_tokens_to_nchw
@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define POET_ABI_VERSION 5
+#define POET_ABI_VERSION 6
 #define POET_SQNORM_SCRATCH 1024
 
 #define POET_F32 0
@@ -247,15 +247,19 @@ int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float*
 int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                 void* dz_out, void* dx_out, float* dgamma, float* dbeta,
                 int64_t rows, int d, float drop_p, uint32_t seed, int dtype_x, int dtype_r,
+                int dtype_dz /* (ABI v6) storage of dz_out: = dtype_r, or POET_BF16 with bf16 z and fp32 dy -- the point where the
+                                encoder's bf16 gradient stream starts */,
                 const uint32_t* seed_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small multi-head self-attention core (nn.MultiheadAttention without the projections):
  * q,k,v (N,Q,M*hd) fp32 with row stride ld (so they may be column slices of one packed buffer);
- * out (N,Q,M*hd).  hd in {16, 32, 64}; Q <= 128 (one wave up to 64 queries, two waves above), except poet_mha_bwd at hd = 64:
- * Q <= 114 (2 Q hd + 2 Q (Q + 1) floats of LDS; Q = 128 at hd = 32 runs with swizzled, unpadded score matrices = exactly
- * 160 KB).  Anything else returns POET_ERR_UNSUPPORTED.  softmax(q k^T / sqrt(hd)) with dropout(p) on the
- * probabilities, no key-padding mask (the reference passes none).
+ * out (N,Q,M*hd).  Fast form: hd in {16, 32, 64} and Q <= 128 (one wave up to 64 queries, two waves above; poet_mha_bwd at
+ * hd = 64: Q <= 114 -- 2 Q hd + 2 Q (Q + 1) floats of LDS; Q = 128 at hd = 32 runs with swizzled, unpadded score matrices =
+ * exactly 160 KB).  Every other shape (any hd >= 1, Q <= 2048: `--num_queries`, `--hidden_dim`, `--nheads`, main.py:94-98)
+ * runs the generic form: one wave per query row / key column, probabilities recomputed in the column phase, no Q x Q matrix
+ * and no scratch; Q > 2048 returns POET_ERR_UNSUPPORTED.  softmax(q k^T / sqrt(hd)) with dropout(p) on the probabilities
+ * (one counter for all forms), no key-padding mask (the reference passes none).
  * ---------------------------------------------------------------------------------------------- */
 int poet_mha_fwd(const float* q, const float* k, const float* v, int64_t ld, float* out, int64_t ld_out,
                  int N, int Q, int M, int hd, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
@@ -301,6 +305,12 @@ int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype_a, in
 int poet_add_rowvec(void* x, const float* vec, int batch, int64_t batch_stride_rows, int64_t row0, int64_t rows,
                     int cols, int dtype, void* stream);
 int poet_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* (ABI v6) y = dropout(gelu(x)) and dx = dy * mask / (1 - p) * gelu'(x), element-wise, erf form (F.gelu): the FFN with
+ * `activation="gelu"` (deformable_transformer.py:347-355,193-197,269-273).  dtype POET_F32 or POET_BF16 for all operands; the dropout
+ * mask is a counter function of (seed, element index), redrawn by the backward. */
+int poet_gelu_fwd(const void* x, void* y, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+int poet_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                  void* stream);
 /* (ABI v5) zero-fill of `bytes` bytes (address and size multiples of 4): the value-gradient maps, the gradient arena, per-level sums --
  * every buffer the step accumulates into, so that a captured step holds library kernels only. */
 int poet_zero(void* p, int64_t bytes, void* stream);

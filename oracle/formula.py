@@ -33,6 +33,12 @@ CONFIGS = {
     "tiny100": dict(d_model=64, nheads=4, enc_layers=2, dec_layers=2, d_ffn=128, n_levels=3, n_points=4,
                     num_queries=100, n_classes=5, dropout=0.1, strides=[8, 16], num_channels=[32, 48],
                     image_hw=(96, 128), level_hw=[(12, 16), (6, 8), (3, 4)], batch=2),
+    # free parameters again: `activation="gelu"` (deformable_transformer.py:347-355; the constructor takes it, the builder passes
+    # "relu"), 8 heads of dim 8 and 130 queries (main.py:94-98) -- the generic self-attention kernels (any head dim, Q > 128), the
+    # un-fused GELU + dropout form of the FFN and the head-dim-8 MSDA
+    "tinyg": dict(d_model=64, nheads=8, enc_layers=2, dec_layers=2, d_ffn=128, n_levels=3, n_points=4,
+                  num_queries=130, n_classes=5, dropout=0.1, strides=[8, 16], num_channels=[32, 48],
+                  image_hw=(96, 128), level_hw=[(12, 16), (6, 8), (3, 4)], batch=2, activation="gelu"),
     # BASELINE.json configs[1]/[2]: YCB-V
     "ycbv": dict(d_model=256, nheads=16, enc_layers=5, dec_layers=5, d_ffn=1024, n_levels=4, n_points=4,
                  num_queries=20, n_classes=21, dropout=0.1, strides=[8, 16, 32], num_channels=[256, 256, 256],

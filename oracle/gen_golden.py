@@ -98,7 +98,7 @@ def _ref_model(cfg, feats, bbox_mode="gt", predictions=None, class_mode="specifi
 
     tr = DeformableTransformer(d_model=cfg["d_model"], nhead=cfg["nheads"], num_encoder_layers=cfg["enc_layers"],
                                num_decoder_layers=cfg["dec_layers"], dim_feedforward=cfg["d_ffn"],
-                               dropout=cfg["dropout"], activation="relu", return_intermediate_dec=True,
+                               dropout=cfg["dropout"], activation=cfg.get("activation", "relu"), return_intermediate_dec=True,
                                num_feature_levels=cfg["n_levels"], dec_n_points=cfg["n_points"],
                                enc_n_points=cfg["n_points"])
     model = PoET(Joinerish(), tr, num_queries=cfg["num_queries"], num_feature_levels=cfg["n_levels"],
@@ -369,6 +369,9 @@ def main():
     if "--queries" in sys.argv:               # --num_queries 100 (main.py:98): more object queries than one wave holds
         _run_model("tiny100", 2, True, True)
         return
+    if "--gelu" in sys.argv:                  # activation="gelu", 8 heads of dim 8, 130 queries (the generic self-attention kernels)
+        _run_model("tinyg", 2, True, True)
+        return
     if "--levels" in sys.argv:                # 5 feature levels (two chained extra levels) x 3 sampling points
         _run_model("tiny5", 2, True, True)
         return
@@ -395,6 +398,7 @@ def main():
     _run_model("tiny", 2, True, True, position_embedding="learned")
     _run_model("tiny5", 2, True, True)
     _run_model("tiny100", 2, True, True)
+    _run_model("tinyg", 2, True, True)
     _run_inference("tiny")
     _run_inference("cfg0")
     _run_matcher()

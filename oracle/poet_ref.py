@@ -158,9 +158,22 @@ class BoundingBoxEmbeddingSine(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # models/deformable_transformer.py:169-238 encoder, :241-340 decoder, :27-166 wrapper
 # ----------------------------------------------------------------------------------------------
+def activation_fn(name):
+    """deformable_transformer.py:347-355 (`_get_activation_fn`): relu / gelu / glu, anything else raises.  (The reference's own
+    builder passes "relu", :358-372; `glu` halves the hidden width and fails in linear2 there as well.)"""
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    if name == "glu":
+        return F.glu
+    raise RuntimeError(f"activation should be relu/gelu, not {name}.")
+
+
 class EncoderLayer(nn.Module):
-    def __init__(self, d_model, d_ffn, dropout, n_levels, n_heads, n_points):
+    def __init__(self, d_model, d_ffn, dropout, n_levels, n_heads, n_points, activation="relu"):
         super().__init__()
+        self.activation = activation_fn(activation)
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
@@ -173,7 +186,7 @@ class EncoderLayer(nn.Module):
     def forward(self, src, pos, ref, shapes, lsi, padding_mask=None):
         a = self.self_attn(src + pos, ref, src, shapes, lsi, padding_mask)
         src = self.norm1(src + self.dropout1(a))
-        f = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        f = self.linear2(self.dropout2(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout3(f))
 
 
@@ -206,8 +219,9 @@ class Encoder(nn.Module):
 
 
 class DecoderLayer(nn.Module):
-    def __init__(self, d_model, d_ffn, dropout, n_levels, n_heads, n_points):
+    def __init__(self, d_model, d_ffn, dropout, n_levels, n_heads, n_points, activation="relu"):
         super().__init__()
+        self.activation = activation_fn(activation)
         self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
@@ -226,7 +240,7 @@ class DecoderLayer(nn.Module):
         tgt = self.norm2(tgt + self.dropout2(a))
         c = self.cross_attn(tgt + query_pos, ref, src, shapes, lsi, padding_mask)
         tgt = self.norm1(tgt + self.dropout1(c))
-        f = self.linear2(self.dropout3(F.relu(self.linear1(tgt))))
+        f = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
         return self.norm3(tgt + self.dropout4(f))
 
 
@@ -254,13 +268,13 @@ class Decoder(nn.Module):
 class DeformableTransformer(nn.Module):
     def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
                  dim_feedforward=1024, dropout=0.1, return_intermediate_dec=True,
-                 num_feature_levels=4, dec_n_points=4, enc_n_points=4):
+                 num_feature_levels=4, dec_n_points=4, enc_n_points=4, activation="relu"):
         super().__init__()
         self.d_model, self.nhead = d_model, nhead
         self.encoder = Encoder(EncoderLayer(d_model, dim_feedforward, dropout, num_feature_levels,
-                                            nhead, enc_n_points), num_encoder_layers)
+                                            nhead, enc_n_points, activation), num_encoder_layers)
         self.decoder = Decoder(DecoderLayer(d_model, dim_feedforward, dropout, num_feature_levels,
-                                            nhead, dec_n_points), num_decoder_layers,
+                                            nhead, dec_n_points, activation), num_decoder_layers,
                                return_intermediate_dec)
         self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
         self.reference_points = nn.Linear(d_model, 2)
@@ -710,7 +724,8 @@ def build_poet(cfg, features, bbox_mode="gt", predictions=None, class_mode="spec
     bb = SyntheticBackbone(features, cfg["strides"], cfg["num_channels"], cfg["d_model"] // 2, predictions=predictions,
                            position_embedding=position_embedding)
     tr = DeformableTransformer(cfg["d_model"], cfg["nheads"], cfg["enc_layers"], cfg["dec_layers"],
-                               cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"])
+                               cfg["d_ffn"], cfg["dropout"], True, cfg["n_levels"], cfg["n_points"], cfg["n_points"],
+                               activation=cfg.get("activation", "relu"))
     model = PoET(bb, tr, cfg["num_queries"], cfg["n_levels"], cfg["n_classes"], bbox_mode, class_mode, True,
                  rotation_mode=rotation_mode, aleatoric=aleatoric, ref_points_mode=ref_points_mode, query_embedding_mode=query_embedding_mode)
     crit = SetCriterion(PoseMatcher(bbox_mode="jitter" if bbox_mode == "jitter" else "gt"), build_weight_dict(cfg["dec_layers"]),

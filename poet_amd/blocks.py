@@ -29,6 +29,7 @@ def next_seed() -> int:
 _ENV_HEAD_LOOP = __import__("os").environ.get("POET_HEAD_DX_LOOP", "0") not in ("", "0")      # (A/B aid, read at import)
 _ENV_SEG_FUSE = __import__("os").environ.get("POET_NO_SEG_FUSE", "0") in ("", "0")      # (A/B aid, read at import)
 _ENV_DW_MERGE = __import__("os").environ.get("POET_NO_DW_MERGE", "0") in ("", "0")
+_ENV_GSTREAM = __import__("os").environ.get("POET_GSTREAM_F32", "0") in ("", "0")       # (POET_GSTREAM_F32=1: fp32 gradient stream, rounds 1-5)
 
 
 def empty(shape, dtype, like):
@@ -223,13 +224,15 @@ def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=Non
     return y, (y16 if y16 is not None else y), (z, mean, rstd)
 
 
-def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_ref=None, gate_scale=1.0):
+def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_ref=None, gate_scale=1.0, stream_dtype=None):
+    """stream_dtype: storage of the returned stream gradient dz (default: dy's; torch.bfloat16 = the encoder's bf16 gradient
+    stream, see enc_layer_bwd)."""
     z, mean, rstd = saved
     rows, d = z.shape
-    dz = torch.empty_like(dy)
+    dz = torch.empty(dy.shape, dtype=stream_dtype or dy.dtype, device=dy.device)
     # (a deferred weight gradient reads dxo after this function returned: it must not alias dz, which the callers go on
     # accumulating into)
-    separate = p > 0 or z.dtype != dy.dtype or ops.defer_small_dw.active is not None
+    separate = p > 0 or z.dtype != dy.dtype or dz.dtype != dy.dtype or ops.defer_small_dw.active is not None
     dxo = torch.empty_like(z) if separate else dz
     ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dxo if separate else None, ggamma, gbeta, rows, d, p, seed)
     dx_in = empty((rows, W.shape[1]), x_in.dtype, x_in)
@@ -245,24 +248,41 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
 
 
 # ---- (d) FFN block -------------------------------------------------------------------------------
-def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False, pos_next=None, y_out=None):
-    """x: residual stream; x16: the GEMM operand copy of it (== x in the pure modes)."""
+def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False, pos_next=None, y_out=None, fn="relu"):
+    """x: residual stream; x16: the GEMM operand copy of it (== x in the pure modes).  fn: the FFN's activation
+    (deformable_transformer.py:347-355): "relu" rides in the Linear's epilogue together with the dropout; "gelu" keeps the
+    pre-activation (its derivative needs it) and runs activation + dropout as one element-wise pass (poet_gelu_fwd)."""
     rows = x.shape[0]
     Hd = empty((rows, W1.shape[0]), act or x.dtype, x)
     Wt, sp = Wf(W1, x16, split)
-    ops.linear_fwd(x16, Wt, b1, Hd, act=1, drop_p=p_h, seed=seed_h, split=sp)
+    extra = ()
+    if fn == "relu":
+        ops.linear_fwd(x16, Wt, b1, Hd, act=1, drop_p=p_h, seed=seed_h, split=sp)
+    elif fn == "gelu":
+        pre = torch.empty_like(Hd)
+        ops.linear_fwd(x16, Wt, b1, pre, split=sp)
+        ops.gelu_fwd(pre, Hd, p_h, seed_h)
+        extra = (pre, seed_h)
+    else:
+        # ("glu": F.glu halves the hidden width and the reference's linear2 then fails on the shape, deformable_transformer.py:193-197)
+        raise RuntimeError(f"activation {fn!r}: the FFN's second Linear takes d_ffn columns, glu leaves d_ffn / 2 (the reference fails here too)")
     if pos_next is not None:
         y, y16, ln_saved, q_next = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, pos_next=pos_next)
-        return y, y16, (Hd, ln_saved), q_next
+        return y, y16, (Hd, ln_saved) + extra, q_next
     y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, y_out=y_out)
-    return y, y16, (Hd, ln_saved)
+    return y, y16, (Hd, ln_saved) + extra
 
 
-def ffn_bwd(dy, x, W1, W2, gamma, saved, p_h, p_o, seed_o, gW1, gb1, gW2, gb2, ggamma, gbeta):
-    Hd, ln_saved = saved
+def ffn_bwd(dy, x, W1, W2, gamma, saved, p_h, p_o, seed_o, gW1, gb1, gW2, gb2, ggamma, gbeta, stream_dtype=None):
+    Hd, ln_saved = saved[:2]
     rows, f = Hd.shape
-    dz, dh = proj_ln_bwd(dy, Hd, W2, gamma, ln_saved, p_o, seed_o, gW2, gb2, ggamma, gbeta,
-                         gate_ref=Hd, gate_scale=1.0 / (1.0 - p_h) if p_h > 0 else 1.0)
+    if len(saved) > 2:                        # GELU: d(hidden) ungated, then the element-wise backward on the kept pre-activation
+        pre, seed_h = saved[2:]
+        dz, dh = proj_ln_bwd(dy, Hd, W2, gamma, ln_saved, p_o, seed_o, gW2, gb2, ggamma, gbeta, stream_dtype=stream_dtype)
+        ops.gelu_bwd(dh, pre, dh, p_h, seed_h)
+    else:
+        dz, dh = proj_ln_bwd(dy, Hd, W2, gamma, ln_saved, p_o, seed_o, gW2, gb2, ggamma, gbeta,
+                             gate_ref=Hd, gate_scale=1.0 / (1.0 - p_h) if p_h > 0 else 1.0, stream_dtype=stream_dtype)
     ops.linear_dw(dh, x, gW1, rows=rows, db=gb1)
     ops.linear_dx(dh, Wb(W1, dh), dz, rows=rows, add_src=dz)
     return dz
@@ -277,7 +297,8 @@ ENC_PARAMS = ("self_attn.sampling_offsets.weight", "self_attn.sampling_offsets.b
               "linear2.weight", "linear2.bias", "norm2.weight", "norm2.bias")
 
 
-def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None, split=False, q_in=None, emit_q=False):
+def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None, split=False, q_in=None, emit_q=False,
+                  ffn_act="relu"):
     """src (N*S,d): residual stream; src16: its GEMM-operand copy (== src in the pure modes); pos (N*S,d).
     q_in: `src + pos` when the previous layer's LayerNorm already produced it; emit_q: have this layer's last LayerNorm
     produce it for the next layer.  Returns (out, out16, saved[, q_next])."""
@@ -303,10 +324,10 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
     q_next = None
     if emit_q:
         x2, x2_16, ffn, q_next = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                                         P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, pos_next=pos)
+                                         P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, pos_next=pos, fn=ffn_act)
     else:
         x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                                 P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split)
+                                 P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, fn=ffn_act)
     saved = dict(src=src16, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1_16, ffn=ffn, seeds=seeds, pd=pd)
     if emit_q:
         return x2, x2_16, saved, q_next
@@ -321,23 +342,36 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
     D = d // M
     pd, seeds = sv["pd"], sv["seeds"]
     g = lambda n: G(pre + n)
-    dx1 = ffn_bwd(dx2, sv["x1"], P_["linear1.weight"], P_["linear2.weight"], P_["norm2.weight"], sv["ffn"], pd, pd,
-                  seeds[2], g("linear1.weight"), g("linear1.bias"), g("linear2.weight"), g("linear2.bias"),
-                  g("norm2.weight"), g("norm2.bias"))
-    dsrc, d_out_m = proj_ln_bwd(dx1, sv["out_m"], P_["self_attn.output_proj.weight"], P_["norm1.weight"], sv["ln1"], pd,
-                                seeds[0], g("self_attn.output_proj.weight"), g("self_attn.output_proj.bias"),
-                                g("norm1.weight"), g("norm1.bias"))
-    # grid queries + bf16 storage + D = 16: the LDS-tiled scatter can hand over the value gradient in bf16 (packed bf16x2
-    # atomics; its consumer, the value projection's backward, rounds it to bf16 anyway) -- half the atomics, zero-fill and read
     v2b = sv["V"].dtype in (torch.bfloat16, torch.float16)             # 2-byte value maps (fp16: ops.v_f16)
-    gv16 = (v2b and sv["OA"].dtype in (torch.bfloat16, torch.float16) and D == 16 and npts == 4 and geom.L * npts <= 16
-            and ops.tiled_scatter_bf16())
-    dV = ops.zeros(sv["V"].shape, torch.bfloat16 if gv16 else torch.float32, dx2.device)
     mlp = M * geom.L * npts
     so_w = P_["self_attn.sampling_offsets.weight"]
     tri = getattr(so_w, "_triple", None) if sv["OA"].dtype in (torch.bfloat16, torch.float16) and v2b else None
     if tri is not None and (tri["n_oa"] != 3 * mlp or tri["w16"].shape[0] != 3 * mlp + d or dpos is not None or (3 * mlp) % 8 != 0):
         tri = None
+    # The bf16 GRADIENT STREAM (bf16 policy, the arena's stacked weights): d(src) travels through the layer -- and on to the layer
+    # below -- as bf16 rows instead of fp32.  Its writers / read-modify-writers are the two LayerNorm backwards and the two long-K
+    # input-gradient products (gemm_pipe, bf16 C accumulated in place); every one of them is HBM-bound, and the stream is 2 x 104 MB
+    # of each one's ~310-420 MB.  All arithmetic stays fp32 (LayerNorm statistics, MFMA accumulators); what changes is the rounding
+    # of the stored sum, 2^-9 relative per hand-over, against gradient OPERANDS (d(hidden), d(offsets | logits), d(value) rows, the
+    # LayerNorm branch gradients) that are bf16 already.  Conditions = what gemm_pipe takes (256 columns, >= 4096 rows, K % 64 == 0).
+    d_ffn = P_["linear1.weight"].shape[0]
+    stream = None
+    if (_ENV_GSTREAM and tri is not None and d == 256 and N * S >= 4096 and d_ffn >= 512 and d_ffn % 64 == 0
+            and (3 * mlp + d) >= 512 and (3 * mlp + d) % 64 == 0 and sv["x1"].dtype == torch.bfloat16 and len(sv["ffn"]) == 2):
+        stream = torch.bfloat16
+    elif dx2.dtype != torch.float32:                                   # (a bf16 hand-over into a layer that cannot continue it)
+        dx2 = dx2.float()
+    dx1 = ffn_bwd(dx2, sv["x1"], P_["linear1.weight"], P_["linear2.weight"], P_["norm2.weight"], sv["ffn"], pd, pd,
+                  seeds[2], g("linear1.weight"), g("linear1.bias"), g("linear2.weight"), g("linear2.bias"),
+                  g("norm2.weight"), g("norm2.bias"), stream_dtype=stream)
+    dsrc, d_out_m = proj_ln_bwd(dx1, sv["out_m"], P_["self_attn.output_proj.weight"], P_["norm1.weight"], sv["ln1"], pd,
+                                seeds[0], g("self_attn.output_proj.weight"), g("self_attn.output_proj.bias"),
+                                g("norm1.weight"), g("norm1.bias"), stream_dtype=stream)
+    # grid queries + bf16 storage + D = 16: the LDS-tiled scatter can hand over the value gradient in bf16 (packed bf16x2
+    # atomics; its consumer, the value projection's backward, rounds it to bf16 anyway) -- half the atomics, zero-fill and read
+    gv16 = (v2b and sv["OA"].dtype in (torch.bfloat16, torch.float16) and D == 16 and npts == 4 and geom.L * npts <= 16
+            and ops.tiled_scatter_bf16())
+    dV = ops.zeros(sv["V"].shape, torch.bfloat16 if gv16 else torch.float32, dx2.device)
     G2 = None
     if tri is not None:
         # d(src) += [d(offsets|logits) | d(value) rows] [W_so ; W_aw ; W_v]: both gradient blocks are written into ONE
@@ -402,7 +436,7 @@ DEC_PARAMS = ("cross_attn.sampling_offsets.weight", "cross_attn.sampling_offsets
               "norm3.weight", "norm3.bias")
 
 
-def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training, y_out=None):
+def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training, y_out=None, ffn_act="relu"):
     """tgt,qpos (N*Q,d) fp32; V head-major value map of the encoder memory for this layer."""
     d = tgt.shape[1]
     D, rows = d // M, N * Q
@@ -426,7 +460,7 @@ def dec_layer_fwd(tgt, qpos, V, P_, ref_in, geom, N, Q, M, npts, p, training, y_
     t2, _, ln1 = proj_ln_fwd(out_m, P_["cross_attn.output_proj.weight"], P_["cross_attn.output_proj.bias"], t1,
                              P_["norm1.weight"], P_["norm1.bias"], pd, seeds[2])
     t3, _, ffn = ffn_fwd(t2, t2, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                         P_["norm3.weight"], P_["norm3.bias"], pd, pd, seeds[3], seeds[4], y_out=y_out)
+                         P_["norm3.weight"], P_["norm3.bias"], pd, pd, seeds[3], seeds[4], y_out=y_out, fn=ffn_act)
     saved = dict(tgt=tgt, qk=qk, packed=packed, att=att, ln2=ln2, t1=t1, q2=q2, OA=OA, out_m=out_m, ln1=ln1, t2=t2,
                  ffn=ffn, seeds=seeds, pd=pd, V=V)
     return t3, saved

@@ -83,10 +83,14 @@ __device__ __forceinline__ void gload16(f32x4_t& dst, uint32_t voff, const void*
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// HOUT (round 6): C is stored as IEEE fp16 (PoetGemmDesc.c_f16; plain write only) -- the LayerNorm that reads it next takes 2 bytes per
-// element instead of 4 on both sides; a lane's 4 consecutive columns leave as one 8-byte store, 32 contiguous bytes per row
-template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW, bool HOUT = false>
+// OUT = 1 (round 6): C is stored as IEEE fp16 (PoetGemmDesc.c_f16; plain write only) -- the LayerNorm that reads it next takes 2 bytes per
+// element instead of 4 on both sides; a lane's 4 consecutive columns leave as one 8-byte store, 32 contiguous bytes per row.
+// OUT = 2: C is bfloat16, written or ACCUMULATED in place (the accumulators start as the unpacked bf16 C and leave rounded to nearest
+// even): the encoder's bf16 gradient stream -- d(src) += d(hidden) W1 and d(src) += [d(offsets|logits) | d(value)] W at 2 + 2 instead
+// of 4 + 4 bytes per element of the read-modify-write.
+template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW, int OUT = 0>
 __global__ __launch_bounds__(PIPE_NT, 3) void gemm_pipe_kernel(const PipeP p) {
+    constexpr bool HOUT = OUT == 1, BOUT = OUT == 2;
     static_assert(!(HOUT && ACC), "fp16 output: plain write only");
     constexpr int ROWB = BK * 2, CPR = ROWB / 16;
     constexpr int NLT = 128;                                           // threads per loader role (2 waves)
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(PIPE_NT, 3) void gemm_pipe_kernel(const PipeP p) {
             w_rd[j] = krl * 512 + (((piece ^ sw) & 7) | (piece & 8)) * 32 + (m16 & 3) * 8;
         }
     }
-    constexpr int CES = HOUT ? 2 : 4;                                   // bytes per stored element
+    constexpr int CES = OUT ? 2 : 4;                                    // bytes per stored element
     const int ldcB = (int)p.ldc * CES;
     const uint32_t c_col = (uint32_t)((wave * NJ * 16 + kc * 4) * CES);   // + j * 16 * CES bytes
 
@@ -241,7 +245,12 @@ __global__ __launch_bounds__(PIPE_NT, 3) void gemm_pipe_kernel(const PipeP p) {
             for (int i = 0; i < NF; ++i) {
                 const char* cr = cb + (uint32_t)(min(i * 16 + mo, rv - 1) * ldcB) + c_col;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = *reinterpret_cast<const f32x4_t*>(cr + j * 64);
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (BOUT) {
+                        const uint2 u = *reinterpret_cast<const uint2*>(cr + j * 32);
+                        acc[i][j] = f32x4_t{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+                    } else acc[i][j] = *reinterpret_cast<const f32x4_t*>(cr + j * 64);
+                }
             }
         } else {
             f32x4_t b4[NJ];
@@ -309,6 +318,9 @@ __global__ __launch_bounds__(PIPE_NT, 3) void gemm_pipe_kernel(const PipeP p) {
                     if constexpr (HOUT)
                         *reinterpret_cast<uint2*>(cb + (uint32_t)((i * 16 + mo) * ldcB) + c_col + j * 32) =
                             make_uint2(pack_h2(acc[i][j][0], acc[i][j][1]), pack_h2(acc[i][j][2], acc[i][j][3]));
+                    else if constexpr (BOUT)
+                        *reinterpret_cast<uint2*>(cb + (uint32_t)((i * 16 + mo) * ldcB) + c_col + j * 32) =
+                            make_uint2(pack_bf2(acc[i][j][0], acc[i][j][1]), pack_bf2(acc[i][j][2], acc[i][j][3]));
                     else *reinterpret_cast<f32x4_t*>(cb + (uint32_t)((i * 16 + mo) * ldcB) + c_col + j * 64) = acc[i][j];
                 }
             }
@@ -343,12 +355,12 @@ int pipe_cus() {
     return n;
 }
 
-template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW, bool HOUT = false>
+template <int BK, bool WKM, bool SPLIT, bool ACC, int NSTA, int NSTW, int OUT = 0>
 void pipe_launch(const PipeP& p, int grid, hipStream_t st) {
     constexpr int NA = (PIPE_MAXF * 16 * (BK / 8) + 127) / 128;
     constexpr int LDS = NSTA * NA * 2048 + NSTW * (SPLIT ? 2 : 1) * BK * 512;
     static_assert(LDS <= 163840, "LDS rings");
-    auto kern = gemm_pipe_kernel<BK, WKM, SPLIT, ACC, NSTA, NSTW, HOUT>;
+    auto kern = gemm_pipe_kernel<BK, WKM, SPLIT, ACC, NSTA, NSTW, OUT>;
     static unsigned long long attr_done = 0;
     lds_attr_once(reinterpret_cast<const void*>(kern), LDS, attr_done);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PIPE_NT), LDS, st, p);
@@ -377,7 +389,9 @@ bool gemm_pipe_try(const GemmK& g, hipStream_t st) {
     // plain long-K products: bf16 operands, fp32 result written (+ bias) or accumulated in place
     // (round 6: or an fp16 result -- c_dtype POET_BF16 with c_f16 -- of the forward form, plain write)
     const bool hout = d.c_dtype == POET_BF16 && d.c_f16 && !d.b_kmajor && !d.add_src;
-    if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || (d.c_dtype != POET_F32 && !hout) || d.compute != POET_BF16) return false;
+    // (or a bf16 result of the input-gradient form, written or accumulated in place: the encoder's bf16 gradient stream)
+    const bool bout = d.c_dtype == POET_BF16 && !d.c_f16 && d.b_kmajor && !d.b_split && !d.bias;
+    if (d.a_dtype != POET_BF16 || d.b_dtype != POET_BF16 || (d.c_dtype != POET_F32 && !hout && !bout) || d.compute != POET_BF16) return false;
     if (d.a_kmajor || d.batch != 1 || d.splitk != 1 || d.atomic || d.A2) return false;
     if (d.act || d.gate_ref || d.row_mask || d.drop_p != 0.f || d.out_mode != 0 || d.alpha != 1.f) return false;
     if (d.bias && d.add_src) return false;
@@ -386,6 +400,7 @@ bool gemm_pipe_try(const GemmK& g, hipStream_t st) {
     if (d.N != PIPE_BN || d.M < 4096 || d.K < 512 || d.K % 64 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B) | reinterpret_cast<uintptr_t>(d.C) | reinterpret_cast<uintptr_t>(d.B_lo)) & 15) return false;
     if ((d.lda & 7) || (d.ldb & 7) || (d.ldc & 3)) return false;
+    if (bout && (reinterpret_cast<uintptr_t>(d.C) & 7)) return false;
     if (d.lda * 2 * 128 >= (1LL << 31) || d.ldc * 4 * 128 >= (1LL << 31) || (int64_t)d.K * d.ldb * 2 >= (1LL << 31)) return false;   // 32-bit lane offsets
     PipeP p;
     p.A = reinterpret_cast<const bf16_t*>(d.A);
@@ -403,8 +418,13 @@ bool gemm_pipe_try(const GemmK& g, hipStream_t st) {
     const bool acc = d.add_src != nullptr, split = d.b_split != 0;
     const int key = (d.b_kmajor ? 4 : 0) | (split ? 2 : 0) | (acc ? 1 : 0);
     if (hout) {                                                         // (the default ring depths; POET_PIPE_CFG applies to the fp32 forms)
-        if (split) pipe_launch<32, false, true, false, 3, 3, true>(p, grid, st);
-        else pipe_launch<32, false, false, false, 5, 5, true>(p, grid, st);
+        if (split) pipe_launch<32, false, true, false, 3, 3, 1>(p, grid, st);
+        else pipe_launch<32, false, false, false, 5, 5, 1>(p, grid, st);
+        return true;
+    }
+    if (bout) {
+        if (acc) pipe_launch<32, true, false, true, 5, 5, 2>(p, grid, st);
+        else pipe_launch<32, true, false, false, 5, 5, 2>(p, grid, st);
         return true;
     }
     switch (key) {

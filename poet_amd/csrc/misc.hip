@@ -20,6 +20,39 @@ __global__ __launch_bounds__(256) void add_kernel(const TA* __restrict__ a, cons
     }
 }
 
+// ---- GELU (+ dropout) of the FFN: `activation="gelu"` (deformable_transformer.py:347-355; F.gelu = the erf form) --------------------
+// The ReLU FFN has its activation and dropout in the Linear's epilogue and its backward gate in the next product's loader (the sign of
+// the stored output decides both).  GELU's derivative needs the PRE-activation, so this form keeps it: y = dropout(gelu(x)) and
+// d(x) = d(y) * mask / (1 - p) * gelu'(x) are their own element-wise passes.  One dropout counter per element index, redrawn in backward.
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.39894228040143268f;
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ o, int64_t n,
+                                                   uint32_t thresh, float dscale, uint32_t seed, const uint32_t* __restrict__ seed_dev) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const uint32_t sd = seed ^ (seed_dev ? *seed_dev * 0x9E3779B1u : 0u);
+    if (i + 8 <= n) {
+        float a[8], g[8];
+        vec<T, 8>::ld(x + i, a);
+        if constexpr (BWD) vec<T, 8>::ld(dy + i, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float keep = thresh ? (drop_keep(sd, (uint32_t)(i + e), thresh) ? dscale : 0.f) : 1.f;
+            a[e] = BWD ? g[e] * keep * gelu_df(a[e]) : gelu_f(a[e]) * keep;
+        }
+        vec<T, 8>::st(o + i, a);
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            const float keep = thresh ? (drop_keep(sd, (uint32_t)j, thresh) ? dscale : 0.f) : 1.f;
+            const float a = io<T>::ld(x + j);
+            io<T>::st(o + j, BWD ? io<T>::ld(dy + j) * keep * gelu_df(a) : gelu_f(a) * keep);
+        }
+    }
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
@@ -761,6 +794,33 @@ extern "C" int poet_add(const void* a, const void* b, void* out, int64_t n, int 
     else if (key == 3) hipLaunchKernelGGL((add_kernel<float, bf16_t, bf16_t>), grid, block, 0, ST, (const float*)a, (const bf16_t*)b, (bf16_t*)out, n);
     else if (key == 1) hipLaunchKernelGGL((add_kernel<float, float, bf16_t>), grid, block, 0, ST, (const float*)a, (const float*)b, (bf16_t*)out, n);
     else { set_error("add: unsupported dtype triple %d %d %d", da, db, dout); return POET_ERR_UNSUPPORTED; }
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_gelu_fwd(const void* x, void* y, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    POET_CHECK(x && y && n > 0, POET_ERR_ARG, "gelu_fwd: bad args");
+    POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "gelu_fwd: drop_p");
+    POET_CHECK(dtype == POET_F32 || dtype == POET_BF16, POET_ERR_UNSUPPORTED, "gelu_fwd: dtype %d", dtype);
+    const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+    const float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    dim3 grid(cdiv(n, 2048)), block(256);
+    if (dtype == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, false>), grid, block, 0, ST, (const float*)x, (const float*)nullptr, (float*)y, n, th, ds, seed, seed_dev);
+    else hipLaunchKernelGGL((gelu_kernel<bf16_t, false>), grid, block, 0, ST, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, th, ds, seed, seed_dev);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                             void* stream) {
+    POET_CHECK(dy && x && dx && n > 0, POET_ERR_ARG, "gelu_bwd: bad args");
+    POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "gelu_bwd: drop_p");
+    POET_CHECK(dtype == POET_F32 || dtype == POET_BF16, POET_ERR_UNSUPPORTED, "gelu_bwd: dtype %d", dtype);
+    const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+    const float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    dim3 grid(cdiv(n, 2048)), block(256);
+    if (dtype == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, true>), grid, block, 0, ST, (const float*)x, (const float*)dy, (float*)dx, n, th, ds, seed, seed_dev);
+    else hipLaunchKernelGGL((gelu_kernel<bf16_t, true>), grid, block, 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, th, ds, seed, seed_dev);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     }
 }
 
-template <typename TX, typename TR>
+// TRO: storage type of the stream gradient dz (= TR unless the encoder's bf16 gradient stream starts here: fp32 in, bf16 out)
+template <typename TX, typename TR, typename TRO = TR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, const TX* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, TR* __restrict__ dz,
+                                                     const float* __restrict__ gamma, TRO* __restrict__ dz,
                                                      TX* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int d,
                                                      uint32_t thresh, float dscale, uint32_t seed,
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, 
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
-                vec<TR, 4>::st(dz + row * d + c, o);
+                vec<TRO, 4>::st(dz + row * d + c, o);
                 if (dx && ((const void*)dx != (const void*)dz || thresh)) {
                     if (thresh) {
 #pragma unroll
@@ -489,11 +490,13 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
 
 extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                            void* dz_out, void* dx_out, float* dgamma, float* dbeta, int64_t rows, int d, float drop_p,
-                           uint32_t seed, int dtype_x, int dtype_r, const uint32_t* seed_dev, void* stream) {
+                           uint32_t seed, int dtype_x, int dtype_r, int dtype_dz, const uint32_t* seed_dev, void* stream) {
     POET_CHECK(dy && z && mean && rstd && gamma && dz_out && dgamma && dbeta, POET_ERR_ARG, "ln_bwd: null pointer");
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_bwd: d=%d unsupported", d);
     POET_CHECK(!(drop_p > 0.f && dx_out == dz_out), POET_ERR_ARG, "ln_bwd: dx_out must not alias dz_out when drop_p>0");
-    POET_CHECK(!(dtype_x != dtype_r && (dx_out == nullptr || dx_out == dz_out)), POET_ERR_ARG, "ln_bwd: mixed dtypes need a separate dx_out");
+    POET_CHECK(!(dtype_x != dtype_dz && (dx_out == nullptr || dx_out == dz_out)), POET_ERR_ARG, "ln_bwd: mixed dtypes need a separate dx_out");
+    POET_CHECK(dtype_dz == dtype_r || (dtype_dz == POET_BF16 && dtype_x == POET_BF16), POET_ERR_UNSUPPORTED,
+               "ln_bwd: dz dtype %d with (x, dy) dtypes (%d, %d)", dtype_dz, dtype_x, dtype_r);
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     int nb = cdiv(rows, 4);
@@ -506,7 +509,9 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     dim3 grid(nb), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev)
-    POET_DT2(dtype_x, dtype_r, LN_BWD);
+    if (dtype_dz != dtype_r)        // the bf16 gradient stream starts here: fp32 d(y) in, bf16 d(z) out (bf16 saved sum)
+        ln_bwd_kernel<bf16_t, float, bf16_t><<<grid, block, 0, st>>>((const float*)dy, (const bf16_t*)z, mean, rstd, gamma, (bf16_t*)dz_out, (bf16_t*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev);
+    else POET_DT2(dtype_x, dtype_r, LN_BWD);
 #undef LN_BWD
     POET_LAUNCH_CHECK();
     return POET_OK;

@@ -68,6 +68,9 @@ def enc_bucket_tag(n_layers: int, i: int) -> str:
     return f"2_encoder_{n_layers - 1 - i:02d}"
 
 
+_GSTREAM = {}        # (id(cfg), layer index) -> bf16 d(output) of that encoder layer, left by the backward of the layer above
+
+
 class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x16, q_in, pos2, level_embed, ref, mask, geom, cfg, idx, names, *params):
@@ -80,7 +83,7 @@ class EncoderLayerFn(torch.autograd.Function):
         P_ = _pdict(names, params, "")
         emit = idx + 1 < cfg["n_layers"]
         out = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
-                              cfg["training"], cfg.get("act"), cfg.get("split", False), q_in=q_in, emit_q=emit)
+                              cfg["training"], cfg.get("act"), cfg.get("split", False), q_in=q_in, emit_q=emit, ffn_act=cfg.get("ffn_act", "relu"))
         y, y16, sv = out[:3]
         q_next = out[3] if emit and out[3] is not None else x.new_empty(0)
         ctx.saved, ctx.geom, ctx.cfg, ctx.idx, ctx.names, ctx.params = sv, geom, cfg, idx, names, params
@@ -101,8 +104,22 @@ class EncoderLayerFn(torch.autograd.Function):
         G = B.GradSink(list(names) + ["level_embed"], list(params) + [ctx.level_embed])
         g_level = G("level_embed") if ctx.level_embed.requires_grad else None
         dpos = torch.empty((N * S, dy.shape[1]), dtype=torch.float32, device=dy.device) if ctx.need_pos else None
-        dx = B.enc_layer_bwd(dy.contiguous(), ctx.saved, _pdict(names, params, ""), G, "", ctx.ref, S * geom.L * 2, ctx.mask, geom,
+        # The bf16 gradient stream (blocks.enc_layer_bwd) is handed from layer to layer beside autograd: the layer above left its
+        # d(input) here and gave autograd an unwritten fp32 placeholder of the same shape (autograd would cast a bf16 gradient of an
+        # fp32 tensor back to fp32: a 156 MB pass per layer).  Layer 0 converts once for the input projection.
+        dy_real = _GSTREAM.pop((id(cfg), i), None)
+        if dy_real is None:
+            dy_real = dy.contiguous()
+        dx = B.enc_layer_bwd(dy_real, ctx.saved, _pdict(names, params, ""), G, "", ctx.ref, S * geom.L * 2, ctx.mask, geom,
                              N, cfg["M"], cfg["P"], g_level, dpos=dpos)
+        if dx.dtype != torch.float32:
+            if i > 0 and ctx.need_x:
+                _GSTREAM[(id(cfg), i - 1)] = dx
+                dx = torch.empty(dx.shape, dtype=torch.float32, device=dx.device)        # placeholder: never written, never read
+            else:
+                dx32 = torch.empty(dx.shape, dtype=torch.float32, device=dx.device)
+                ops.cast(dx, dx32)
+                dx = dx32
         ctx.saved = None
         ops.SIDE.join()
         announce(enc_bucket_tag(cfg["n_layers"], i))
@@ -246,7 +263,8 @@ class DecoderFn(torch.autograd.Function):
                 V = B.value_proj_fwd(mem2, P_["cross_attn.value_proj.weight"], P_["cross_attn.value_proj.bias"], mask, N, S, M, D,
                                      cfg.get("act"), cfg.get("split", False))
             # the layer's last LayerNorm writes its row of hs directly (hs[i] is also the next layer's input)
-            x, sv = B.dec_layer_fwd(x, qp, V, P_, ref_in, geom, N, Q, M, cfg["P"], cfg["p"], cfg["training"], y_out=hs[i].view(N * Q, d))
+            x, sv = B.dec_layer_fwd(x, qp, V, P_, ref_in, geom, N, Q, M, cfg["P"], cfg["p"], cfg["training"], y_out=hs[i].view(N * Q, d),
+                                    ffn_act=cfg.get("ffn_act", "relu"))
             saved.append(sv)
         ctx.vstack = vs if V_all is not None else None
         ctx.saved, ctx.geom, ctx.cfg, ctx.names, ctx.params = saved, geom, cfg, names, params

@@ -166,12 +166,20 @@ class BoundingBoxEmbeddingSine(nn.Module):
         return out
 
 
+def _check_activation(name):
+    """deformable_transformer.py:347-355 (`_get_activation_fn`): "relu" / "gelu" / "glu", anything else raises RuntimeError at
+    construction.  "glu" halves the hidden width, so the reference's own forward fails in linear2 (d_ffn / 2 columns against a
+    d_ffn-wide weight): here it constructs and raises RuntimeError on the first forward as well (blocks.ffn_fwd)."""
+    if name not in ("relu", "gelu", "glu"):
+        raise RuntimeError(f"activation should be relu/gelu, not {name}.")
+    return name
+
+
 # ====================================================================================================
 class DeformableTransformerEncoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
         super().__init__()
-        if activation != "relu":
-            raise NotImplementedError("the reference builds with activation='relu' only")
+        self.activation = _check_activation(activation)
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
@@ -191,7 +199,7 @@ class DeformableTransformerEncoder(nn.Module):
     def run(self, src, pos, level_embed, ref, mask_u8, geom: LevelGeom, act=None, split=False):
         l0 = self.layers[0]
         cfg = dict(M=l0.self_attn.n_heads, P=l0.self_attn.n_points, p=l0.dropout1.p, training=self.training,
-                   n_layers=self.num_layers, act=act, split=split)
+                   n_layers=self.num_layers, act=act, split=split, ffn_act=l0.activation)
         memory, memory16, self._layer_outs = Fn.encoder_forward(src, pos, level_embed, ref, mask_u8, geom, cfg,
                                                                 [_named(l) for l in self.layers])
         return memory, memory16
@@ -200,8 +208,7 @@ class DeformableTransformerEncoder(nn.Module):
 class DeformableTransformerDecoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
         super().__init__()
-        if activation != "relu":
-            raise NotImplementedError("the reference builds with activation='relu' only")
+        self.activation = _check_activation(activation)
         self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
@@ -227,7 +234,7 @@ class DeformableTransformerDecoder(nn.Module):
     def run(self, memory, memory16, tgt, qpos, ref_in, mask_u8, geom: LevelGeom, act=None, split=False):
         l0 = self.layers[0]
         cfg = dict(M=l0.cross_attn.n_heads, P=l0.cross_attn.n_points, p=l0.dropout1.p, training=self.training,
-                   n_layers=self.num_layers, act=act, split=split)
+                   n_layers=self.num_layers, act=act, split=split, ffn_act=l0.activation)
         names, params = _named(self.layers, "layers.")
         return Fn.DecoderFn.apply(memory, memory16, tgt, qpos, ref_in, mask_u8, geom, cfg, names, *params)
 

@@ -480,7 +480,7 @@ def ln_bwd(dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, rows, d, drop_p=0.0,
     lib = _lib.load()
     _lib.check(lib.poet_ln_bwd(_req(dy, "dy").data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                dz.data_ptr(), _ptr(dx), dgamma.data_ptr(), dbeta.data_ptr(), rows, d, drop_p,
-                               seed & 0xFFFFFFFF, dcode(z), dcode(dy), _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_bwd")
+                               seed & 0xFFFFFFFF, dcode(z), dcode(dy), dcode(dz), _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_bwd")
 
 
 def groupnorm_fwd(x, gamma, beta, y, stats, N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps=1e-5):
@@ -575,6 +575,22 @@ def add(a, b, out):
     _lib.check(lib.poet_add(_req(a, "a").data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), dcode(a), dcode(b), dcode(out), _stream()),
                "poet_add")
     return out
+
+
+def gelu_fwd(x, y, drop_p=0.0, seed=0):
+    """y = dropout(gelu(x)) (erf form), same dtype."""
+    lib = _lib.load()
+    _lib.check(lib.poet_gelu_fwd(_req(x, "x").data_ptr(), y.data_ptr(), x.numel(), dcode(x), drop_p, seed & 0xFFFFFFFF,
+                                 _seed_dev() if drop_p > 0 else None, _stream()), "poet_gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, x, dx, drop_p=0.0, seed=0):
+    """dx = dy * mask / (1 - p) * gelu'(x): the mask is redrawn from (seed, element index)."""
+    lib = _lib.load()
+    _lib.check(lib.poet_gelu_bwd(_req(dy, "dy").data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), dcode(x), drop_p, seed & 0xFFFFFFFF,
+                                 _seed_dev() if drop_p > 0 else None, _stream()), "poet_gelu_bwd")
+    return dx
 
 
 def cast(src, dst):

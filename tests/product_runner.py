@@ -36,7 +36,7 @@ def build_product(name, batch, pad, precision="fp32", seed=1234, dropout=None, f
         torch.manual_seed(4321)          # oracle/gen_golden.py INIT_SEED: the reference's own init order
     tr = poet_amd.DeformableTransformer(d_model=cfg["d_model"], nhead=cfg["nheads"], num_encoder_layers=cfg["enc_layers"],
                                         num_decoder_layers=cfg["dec_layers"], dim_feedforward=cfg["d_ffn"], dropout=p,
-                                        activation="relu", return_intermediate_dec=True,
+                                        activation=cfg.get("activation", "relu"), return_intermediate_dec=True,
                                         num_feature_levels=cfg["n_levels"], dec_n_points=cfg["n_points"],
                                         enc_n_points=cfg["n_points"])
     tr.set_precision(precision)

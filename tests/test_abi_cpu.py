@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/poet_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "ctypes prototype table and header drifted apart"
-    assert lib.poet_hip_version() == _lib.ABI_VERSION == 5
+    assert lib.poet_hip_version() == _lib.ABI_VERSION == 6
 
 
 def test_gemm_descriptor_layout_matches_header():

@@ -456,20 +456,69 @@ def test_mha(ops, Q, M, hd):
 
 
 def test_mha_limits_are_refused_not_misrun(ops):
-    """Q > 128, head dims outside {16, 32, 64} and the backward at head dim 64 beyond 114 queries return POET_ERR_UNSUPPORTED."""
+    """Beyond the generic form's row buffers (Q > 2048) the call returns POET_ERR_UNSUPPORTED instead of misrunning."""
     from poet_amd._lib import PoetHipError
-    for Q, M, hd, bwd_only in [(129, 4, 16, False), (20, 4, 24, False), (115, 4, 64, True)]:
-        N, d = 1, M * hd
-        pk = dev(_rand(N * Q, 3 * d, seed=44))
-        out = torch.empty(N * Q, d, device="cuda")
-        if not bwd_only:
-            with pytest.raises(PoetHipError):
-                ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd)
-        else:
-            ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd)        # (the forward holds one score matrix: fits)
-        dpk = torch.empty_like(pk)
-        with pytest.raises(PoetHipError):
-            ops.mha_bwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, hd)
+    Q, M, hd = 2049, 1, 16
+    N, d = 1, M * hd
+    pk = dev(_rand(N * Q, 3 * d, seed=44))
+    out = torch.empty(N * Q, d, device="cuda")
+    with pytest.raises(PoetHipError):
+        ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd)
+    dpk = torch.empty_like(pk)
+    with pytest.raises(PoetHipError):
+        ops.mha_bwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, hd)
+
+
+@pytest.mark.parametrize("Q,M,hd", [(129, 4, 16), (300, 8, 32), (20, 4, 24), (115, 4, 64), (40, 2, 128), (7, 3, 5), (1, 2, 16), (600, 2, 48)])
+def test_mha_generic_any_query_count_and_head_dim(ops, Q, M, hd):
+    """`--num_queries`, `--hidden_dim` and `--nheads` are free parameters of the reference (main.py:94-98; nn.MultiheadAttention at
+    deformable_transformer.py:253 has no limit): what the LDS-resident kernels do not take (Q > 128, head dims outside {16, 32, 64},
+    the backward beyond 114 queries at head dim 64) runs the generic kernels -- against torch fp32."""
+    N, d = 2, M * hd
+    packed = _rand(N * Q, 3 * d, seed=46)
+    pk = dev(packed)
+    out = torch.empty(N * Q, d, device="cuda")
+    ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd)
+    p32 = packed.clone().requires_grad_()
+    q, k, v = (p32[:, i * d:(i + 1) * d].view(N, Q, M, hd).transpose(1, 2) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1)
+    ref = (att @ v).transpose(1, 2).reshape(N * Q, d)
+    _close(out, ref.detach(), torch.float32, msg="mha generic fwd")
+    dout = _rand(N * Q, d, seed=47)
+    ref.backward(dout)
+    dpk = torch.empty_like(pk)
+    ops.mha_bwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, dev(dout), d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, hd)
+    _close(dpk, p32.grad, torch.float32, msg="mha generic bwd")
+
+
+@pytest.mark.parametrize("Q,M,hd", [(24, 2, 24), (130, 2, 130), (20, 4, 32)])
+def test_mha_dropout_forward_and_backward_share_one_mask(ops, Q, M, hd):
+    """Dropout on the attention probabilities (nn.MultiheadAttention(dropout=...), deformable_transformer.py:253): nothing is stored,
+    forward and backward redraw the mask from the same counter.  With v = identity (hd >= Q) the forward output IS the dropped
+    probability row, so the mask can be read off it; the backward must then equal autograd through softmax * mask / (1 - p).
+    Generic kernels (head dim 24 / 130) and the LDS-resident ones (head dim 32) alike."""
+    N, d, pdrop, seed = 2, M * hd, 0.25, 1234
+    packed = _rand(N * Q, 3 * d, seed=48)
+    assert hd >= Q
+    eye = torch.zeros(Q, hd); eye[:, :Q] = torch.eye(Q)
+    packed.view(N, Q, 3, M, hd)[:, :, 2] = eye[None, :, None, :]
+    pk = dev(packed)
+    out = torch.empty(N * Q, d, device="cuda")
+    ops.mha_fwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, out, d, N, Q, M, hd, pdrop, seed)
+    p32 = packed.clone().requires_grad_()
+    q, k, v = (p32[:, i * d:(i + 1) * d].view(N, Q, M, hd).transpose(1, 2) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1)                  # (N, M, Q, Q)
+    dropped = out.cpu().view(N, Q, M, hd).transpose(1, 2)[..., :Q]
+    mask = (dropped != 0).float()
+    frac = 1.0 - mask.mean().item()
+    assert abs(frac - pdrop) < 0.05, frac
+    _close(dev(dropped), (att * mask / (1 - pdrop)).detach(), torch.float32, msg="dropped probabilities")
+    ref = ((att * mask / (1 - pdrop)) @ v).transpose(1, 2).reshape(N * Q, d)
+    dout = _rand(N * Q, d, seed=49)
+    ref.backward(dout)
+    dpk = torch.empty_like(pk)
+    ops.mha_bwd(pk, pk[:, d:], pk[:, 2 * d:], 3 * d, dev(dout), d, dpk, dpk[:, d:], dpk[:, 2 * d:], 3 * d, N, Q, M, hd, pdrop, seed)
+    _close(dpk, p32.grad, torch.float32, msg="mha dropout bwd")
 
 
 # ---------------------------------------------------------------------------------------------- encodings & misc
@@ -667,6 +716,81 @@ def test_layernorm_mixed(ops):
     ops.ln_bwd(dev(dy), z, mean, rstd, dev(gamma), dz, dx, dg, db, rows, d)
     _close(dz, zr.grad, torch.bfloat16, msg="mixed ln dz")
     _close(dx, zr.grad, torch.bfloat16, msg="mixed ln dx")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gelu_dropout_forward_backward(ops, dtype):
+    """poet_gelu_fwd / poet_gelu_bwd (the FFN with activation="gelu", deformable_transformer.py:347-355): F.gelu (erf form) and its
+    derivative on the kept pre-activation; the backward redraws the forward's dropout mask."""
+    n = 5 * 2048 + 13
+    x = _rand(n, seed=180, scale=2.5).to(dtype)
+    y = torch.empty(n, dtype=dtype, device="cuda")
+    ops.gelu_fwd(dev(x), y)
+    xr = x.float().requires_grad_()
+    yr = F.gelu(xr)
+    _close(y, yr.detach(), dtype, msg="gelu fwd")
+    dy = _rand(n, seed=181).to(dtype)
+    yr.backward(dy.float())
+    dx = torch.empty_like(y)
+    ops.gelu_bwd(dev(dy), dev(x), dx)
+    _close(dx, xr.grad, dtype, msg="gelu bwd")
+    yd = torch.empty_like(y)
+    ops.gelu_fwd(dev(x), yd, 0.25, 77)
+    keep = (yd != 0) | (y == 0)
+    assert abs(keep.float().mean().item() - 0.75) < 0.02
+    _close(yd[keep], y[keep].float() / 0.75, dtype, msg="gelu dropout scale")
+    dxd = torch.empty_like(y)
+    ops.gelu_bwd(dev(dy), dev(x), dxd, 0.25, 77)
+    assert bool((dxd[~keep] == 0).all())
+    _close(dxd[keep], dx[keep].float() / 0.75, dtype, msg="gelu dropout bwd")
+
+
+@pytest.mark.parametrize("dy_bf16", [False, True])
+def test_layernorm_backward_bf16_stream(ops, dy_bf16):
+    """The encoder's bf16 gradient stream (blocks.enc_layer_bwd): LayerNorm backward that stores d(z) -- the gradient of the residual
+    stream -- as bf16, from an fp32 d(y) (where the stream starts: the top layer, fed by the decoder) or a bf16 one (below).  Equal to
+    the fp32-stream launch on the same operands rounded once; branch gradient (with dropout) and parameter gradients unchanged."""
+    rows, d = 4099, 256
+    z = _rand(rows, d, seed=190, scale=2.0).bfloat16()
+    gamma = 1 + 0.1 * _rand(d, seed=191)
+    dy = _rand(rows, d, seed=192)
+    if dy_bf16:
+        dy = dy.bfloat16()
+    zf = z.float()
+    mean = zf.mean(1)
+    rstd = (zf.var(1, unbiased=False) + 1e-5).rsqrt()
+    outs = []
+    for stream in (torch.float32, torch.bfloat16):
+        dyd = dev(dy.float()) if stream == torch.float32 else dev(dy)
+        dz = torch.empty(rows, d, dtype=stream, device="cuda")
+        dx = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+        dg = torch.zeros(d, device="cuda"); db = torch.zeros(d, device="cuda")
+        ops.ln_bwd(dyd, dev(z), dev(mean), dev(rstd), dev(gamma), dz, dx, dg, db, rows, d, drop_p=0.1, seed=5)
+        outs.append((dz, dx, dg, db))
+    assert torch.equal(outs[1][0].cpu(), outs[0][0].cpu().bfloat16())
+    assert torch.equal(outs[1][1], outs[0][1])
+    assert torch.allclose(outs[1][2], outs[0][2], rtol=1e-4, atol=1e-3) and torch.allclose(outs[1][3], outs[0][3], rtol=1e-4, atol=1e-3)
+    zr = zf.clone().requires_grad_()
+    F.layer_norm(zr, (d,), gamma, torch.zeros(d), 1e-5).backward(dy.float())
+    _close(outs[1][0], zr.grad, torch.bfloat16, msg="bf16-stream ln dz")
+
+
+@pytest.mark.parametrize("rows,K,acc", [(8192 + 40, 1024, True), (4096, 1280, True), (5000, 512, False)])
+def test_gemm_input_gradient_bf16_stream(ops, rows, K, acc):
+    """d(src) (+)= d(y) W with the stream stored as bf16 (gemm_pipe OUT = 2: the accumulators start as the unpacked bf16 C and leave
+    rounded to nearest even): against fp64 on the same bf16 operands, within one bf16 rounding of the result; rows past the end untouched."""
+    dyv = _rand(rows, K, seed=195).bfloat16()
+    w = _rand(K, 256, seed=196, scale=1 / math.sqrt(K)).bfloat16()
+    c0 = _rand(rows, 256, seed=197).bfloat16()
+    buf = torch.full((rows + 2, 256), 3.0, dtype=torch.bfloat16, device="cuda")
+    buf[:rows] = dev(c0)
+    out = buf[:rows]
+    ops.linear_dx(dev(dyv), dev(w), out, rows=rows, add_src=out if acc else None)
+    ref = dyv.double() @ w.double() + (c0.double() if acc else 0.0)
+    err = (out.double().cpu() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 1e-3
+    assert bool((err <= bound).all()), float((err - bound).max())
+    assert bool((buf[rows:] == 3.0).all())
 
 
 @pytest.mark.parametrize("rows", [4096 + 3, 700])

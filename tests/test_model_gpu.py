@@ -34,7 +34,8 @@ def _real_query_mask(n_boxes, Q):
     return m
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("tiny", 2, False), ("cfg0", 2, False), ("cfg0", 2, True), ("tiny5", 2, True), ("tiny100", 2, True)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("tiny", 2, False), ("cfg0", 2, False), ("cfg0", 2, True), ("tiny5", 2, True), ("tiny100", 2, True),
+                                            ("tinyg", 2, True)])
 def test_forward_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.float32)
@@ -65,7 +66,7 @@ def test_forward_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
         assert diff[valid].max().item() < TOL_F32
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True), ("tiny100", 2, True)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True), ("tiny100", 2, True), ("tinyg", 2, True)])
 def test_forward_bf16_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.bfloat16)
@@ -79,7 +80,7 @@ def test_forward_bf16_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     assert dt.max().item() < TOL_BF16 and dr.max().item() < TOL_BF16
 
 
-@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True), ("tiny100", 2, True)])
+@pytest.mark.parametrize("name,batch,pad", [("tiny", 2, True), ("cfg0", 2, False), ("tiny5", 2, True), ("tiny100", 2, True), ("tinyg", 2, True)])
 def test_loss_and_grads_fp32_vs_reference_golden(gpu, golden_dir, name, batch, pad):
     g = _golden(golden_dir, name, batch, pad)
     r = gpu(name, batch, pad, torch.float32)

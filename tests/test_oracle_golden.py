@@ -64,6 +64,8 @@ def test_msda_core_vs_hf(golden_dir):
                                                       # 5 feature levels (two chained 3x3-s2 extra levels) x 3 sampling points
                                                       ("tiny5", 2, True, True, False),
                                                       ("tiny100", 2, True, True, False),
+                                                      # activation="gelu", 8 heads of dim 8, 130 queries
+                                                      ("tinyg", 2, True, True, False),
                                                       # BASELINE.json configs[3] (LM-O geometry) and configs[4] (1280x960, 6/6, Q=50)
                                                       ("lmo", 1, False, False, False), ("lmo", 2, True, False, False),
                                                       ("hires", 1, False, False, False),
