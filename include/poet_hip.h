@@ -237,7 +237,10 @@ int poet_msda_fused_bwd(const void* value, int64_t vs_n, int64_t vs_s, int64_t v
  * ---------------------------------------------------------------------------------------------- */
 int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                 void* y, void* z_out, float* mean, float* rstd,
-                int64_t rows, int d, float eps, float drop_p, uint32_t seed, int dtype_x, int dtype_r,
+                int64_t rows, int d, float eps, float drop_p, uint32_t seed, int dtype_x, int dtype_r /* of res */,
+                int dtype_y /* (ABI v6) of y; -1 = dtype_r.  Behind an fp16 branch (dtype_x = POET_F16) res and y may each be POET_F32 or
+                               POET_F16: the encoder's residual stream stored as IEEE fp16 between its LayerNorms (2^-12 relative at O(1)
+                               values, a quarter of the rounding of the bf16 operand copy y_bf16 written beside it) */,
                 int dtype_z /* dtype of z_out; -1 = dtype_x.  (f32 x, f32 stream, bf16 z): the branch arrives as the GEMM's
                                fp32 accumulators, only the copy saved for backward is bf16 */,
                 void* y_bf16 /* optional: bf16 copy of y, the MFMA operand of the next GEMM */,
@@ -306,11 +309,13 @@ int poet_add_rowvec(void* x, const float* vec, int batch, int64_t batch_stride_r
                     int cols, int dtype, void* stream);
 int poet_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 /* (ABI v6) y = dropout(gelu(x)) and dx = dy * mask / (1 - p) * gelu'(x), element-wise, erf form (F.gelu): the FFN with
- * `activation="gelu"` (deformable_transformer.py:347-355,193-197,269-273).  dtype POET_F32 or POET_BF16 for all operands; the dropout
- * mask is a counter function of (seed, element index), redrawn by the backward. */
-int poet_gelu_fwd(const void* x, void* y, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
-int poet_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+ * `activation="gelu"` (deformable_transformer.py:347-355,193-197,269-273).  dtype (y, dy, dx): POET_F32 or POET_BF16; dtype_x (the
+ * kept pre-activation): = dtype, or POET_F32 under bf16 storage (the Linear's accumulators handed over unrounded).  The dropout mask
+ * is a counter function of (seed, element index), redrawn by the backward. */
+int poet_gelu_fwd(const void* x, void* y, int64_t n, int dtype_x, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev,
                   void* stream);
+int poet_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype_x, int dtype, float drop_p, uint32_t seed,
+                  const uint32_t* seed_dev, void* stream);
 /* (ABI v5) zero-fill of `bytes` bytes (address and size multiples of 4): the value-gradient maps, the gradient arena, per-level sums --
  * every buffer the step accumulates into, so that a captured step holds library kernels only. */
 int poet_zero(void* p, int64_t bytes, void* stream);

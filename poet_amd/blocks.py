@@ -29,6 +29,7 @@ def next_seed() -> int:
 _ENV_HEAD_LOOP = __import__("os").environ.get("POET_HEAD_DX_LOOP", "0") not in ("", "0")      # (A/B aid, read at import)
 _ENV_SEG_FUSE = __import__("os").environ.get("POET_NO_SEG_FUSE", "0") in ("", "0")      # (A/B aid, read at import)
 _ENV_DW_MERGE = __import__("os").environ.get("POET_NO_DW_MERGE", "0") in ("", "0")
+_ENV_FSTREAM = __import__("os").environ.get("POET_FSTREAM_F32", "0") in ("", "0")       # (POET_FSTREAM_F32=1: fp32 residual stream between the encoder's LayerNorms)
 _ENV_GSTREAM = __import__("os").environ.get("POET_GSTREAM_F32", "0") in ("", "0")       # (POET_GSTREAM_F32=1: fp32 gradient stream, rounds 1-5)
 
 
@@ -183,12 +184,13 @@ def sample_bwd(d_out, q2d, OA, so_w, aw_w, V, geom, ref, ref_bs, N, Lq, M, D, P,
 
 
 # ---- (c) projection + residual + dropout + LayerNorm ----------------------------------------------
-def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=None, y_out=None):
+def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=None, y_out=None, stream16=False):
     """Returns (y, y16, saved): y in the residual-stream dtype; y16 = bf16 copy for the next GEMM when the stream is
     fp32 but the branch is bf16 (else y itself).  With split weights the projection hands its fp32 accumulators to the
-    LayerNorm unrounded (the branch is never stored in bf16); only the pre-norm sum saved for backward is bf16."""
+    LayerNorm unrounded (the branch is never stored in bf16); only the pre-norm sum saved for backward is bf16.
+    stream16: store y as IEEE fp16 where this launch can (an fp16 branch, see below); res may arrive as fp16 from such a launch."""
     rows, d = res.shape[0], W.shape[0]
-    mixed = x_in.dtype == torch.bfloat16 and res.dtype == torch.float32
+    mixed = x_in.dtype == torch.bfloat16 and res.dtype in (torch.float32, torch.float16)
     Wt, sp = Wf(W, x_in, split)
     lo = getattr(W, "_bf16_lo", None) if (sp and mixed and rows >= 4096 and W.shape[1] >= 512 and W.shape[0] == 256) else None
     # (the long-K kernel's own admission rules, gemm_pipe.hip:gemm_pipe_try: K a multiple of 64, 16-byte aligned operands, row
@@ -209,7 +211,13 @@ def proj_ln_fwd(x_in, W, b, res, gamma, beta, p, seed, split=False, pos_next=Non
         ops.linear_fwd(x_in, W._bf16, b, tmp, W_lo=lo)
     else:
         ops.linear_fwd(x_in, Wt, b, tmp, split=sp)
-    y = torch.empty_like(res) if y_out is None else y_out      # residual-stream dtype (y_out: the caller's buffer, e.g. a row of hs)
+    if res.dtype == torch.float16 and tmp.dtype != torch.float16:      # (an fp16 stream only travels between fp16-branch launches)
+        res = res.float()
+    # The residual stream as IEEE fp16 between the encoder's LayerNorms (bf16 policy, fp16 branch): the stream is written once and
+    # read once per LayerNorm -- 104 + 104 MB of a launch's 364-470 MB at 102 080 rows -- and its only other reader is the bf16 operand
+    # copy y16 written beside it.  LayerNorm outputs are O(1): fp16 keeps 2^-12 relative, y16 2^-9.
+    ydt = torch.float16 if (stream16 and tmp.dtype == torch.float16 and y_out is None) else (torch.float32 if res.dtype == torch.float16 else res.dtype)
+    y = torch.empty(res.shape, dtype=ydt, device=res.device) if y_out is None else y_out      # (y_out: the caller's buffer, e.g. a row of hs)
     z = empty((rows, d), x_in.dtype, res)            # branch dtype
     mean = empty((rows,), torch.float32, res)
     rstd = empty((rows,), torch.float32, res)
@@ -248,7 +256,8 @@ def proj_ln_bwd(dy, x_in, W, gamma, saved, p, seed, gW, gb, ggamma, gbeta, gate_
 
 
 # ---- (d) FFN block -------------------------------------------------------------------------------
-def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False, pos_next=None, y_out=None, fn="relu"):
+def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=None, split=False, pos_next=None, y_out=None, fn="relu",
+            stream16=False):
     """x: residual stream; x16: the GEMM operand copy of it (== x in the pure modes).  fn: the FFN's activation
     (deformable_transformer.py:347-355): "relu" rides in the Linear's epilogue together with the dropout; "gelu" keeps the
     pre-activation (its derivative needs it) and runs activation + dropout as one element-wise pass (poet_gelu_fwd)."""
@@ -259,7 +268,7 @@ def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=N
     if fn == "relu":
         ops.linear_fwd(x16, Wt, b1, Hd, act=1, drop_p=p_h, seed=seed_h, split=sp)
     elif fn == "gelu":
-        pre = torch.empty_like(Hd)
+        pre = empty(Hd.shape, torch.float32, Hd)      # (fp32 also under bf16 storage: one rounding -- gelu's output -- instead of two)
         ops.linear_fwd(x16, Wt, b1, pre, split=sp)
         ops.gelu_fwd(pre, Hd, p_h, seed_h)
         extra = (pre, seed_h)
@@ -267,9 +276,9 @@ def ffn_fwd(x, x16, W1, b1, W2, b2, gamma, beta, p_h, p_o, seed_h, seed_o, act=N
         # ("glu": F.glu halves the hidden width and the reference's linear2 then fails on the shape, deformable_transformer.py:193-197)
         raise RuntimeError(f"activation {fn!r}: the FFN's second Linear takes d_ffn columns, glu leaves d_ffn / 2 (the reference fails here too)")
     if pos_next is not None:
-        y, y16, ln_saved, q_next = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, pos_next=pos_next)
+        y, y16, ln_saved, q_next = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, pos_next=pos_next, stream16=stream16)
         return y, y16, (Hd, ln_saved) + extra, q_next
-    y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, y_out=y_out)
+    y, y16, ln_saved = proj_ln_fwd(Hd, W2, b2, x, gamma, beta, p_o, seed_o, split=split, y_out=y_out, stream16=stream16)
     return y, y16, (Hd, ln_saved) + extra
 
 
@@ -298,7 +307,7 @@ ENC_PARAMS = ("self_attn.sampling_offsets.weight", "self_attn.sampling_offsets.b
 
 
 def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, training, act=None, split=False, q_in=None, emit_q=False,
-                  ffn_act="relu"):
+                  ffn_act="relu", stream_out16=False):
     """src (N*S,d): residual stream; src16: its GEMM-operand copy (== src in the pure modes); pos (N*S,d).
     q_in: `src + pos` when the previous layer's LayerNorm already produced it; emit_q: have this layer's last LayerNorm
     produce it for the next layer.  Returns (out, out16, saved[, q_next])."""
@@ -310,7 +319,7 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
         q = q_in
     else:
         q = empty(src.shape, src16.dtype, src)
-        ops.add(src, pos, q)
+        ops.add(src.float() if src.dtype == torch.float16 else src, pos, q)      # (an fp16 stream normally arrives with its q_in)
     # value maps in fp16 where their only readers take it (ops.v_f16: the shared-geometry gathers): 11 mantissa bits instead of 8 in
     # the same bytes, and the forward gather multiplies the halves straight out of the packed pair (v_fma_mix_f32: no unpack)
     v16 = (act or src16.dtype) == torch.bfloat16 and ops.v_f16(M, D, geom.L, npts, True)
@@ -319,25 +328,30 @@ def enc_layer_fwd(src, src16, pos, P_, ref, ref_bs, mask, geom, N, M, npts, p, t
     out_m, OA = sample_fwd(q, P_["self_attn.sampling_offsets.weight"], P_["self_attn.sampling_offsets.bias"],
                            P_["self_attn.attention_weights.weight"], P_["self_attn.attention_weights.bias"],
                            V, geom, ref, ref_bs, N, S, M, D, npts, act, split, grid_queries=True)
+    # (stream_out16: the caller takes the layer's output stream as fp16 -- every layer but the last; inside the layer the stream between
+    # the two LayerNorms is fp16 whenever the first one can store it)
     x1, x1_16, ln1 = proj_ln_fwd(out_m, P_["self_attn.output_proj.weight"], P_["self_attn.output_proj.bias"], src,
-                                 P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0], split)
+                                 P_["norm1.weight"], P_["norm1.bias"], pd, seeds[0], split, stream16=_ENV_FSTREAM)
     q_next = None
     if emit_q:
         x2, x2_16, ffn, q_next = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                                         P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, pos_next=pos, fn=ffn_act)
+                                         P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, pos_next=pos, fn=ffn_act,
+                                         stream16=_ENV_FSTREAM and stream_out16)
     else:
         x2, x2_16, ffn = ffn_fwd(x1, x1_16, P_["linear1.weight"], P_["linear1.bias"], P_["linear2.weight"], P_["linear2.bias"],
-                                 P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, fn=ffn_act)
+                                 P_["norm2.weight"], P_["norm2.bias"], pd, pd, seeds[1], seeds[2], act, split, fn=ffn_act,
+                                 stream16=_ENV_FSTREAM and stream_out16)
     saved = dict(src=src16, q=q, V=V, OA=OA, out_m=out_m, ln1=ln1, x1=x1_16, ffn=ffn, seeds=seeds, pd=pd)
     if emit_q:
         return x2, x2_16, saved, q_next
     return x2, x2_16, saved
 
 
-def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_level, dpos=None):
+def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_level, dpos=None, out_f32=False):
     """G: GradSink; pre: name prefix of this layer's params.  Returns d(src).  dpos: optional (N*S, d) fp32 OUTPUT that receives
     d(src + pos) of this layer's offsets | logits projection -- the gradient of a learned position encoding (then the query
-    gradient is its own product instead of a block of the stacked K = 1024 one)."""
+    gradient is its own product instead of a block of the stacked K = 1024 one).  out_f32: the caller needs d(src) in fp32 (layer 0:
+    the input projection's backward reads it) -- a bf16 gradient stream then ends at this layer's first LayerNorm."""
     S, d = geom.S, dx2.shape[1]
     D = d // M
     pd, seeds = sv["pd"], sv["seeds"]
@@ -366,7 +380,7 @@ def enc_layer_bwd(dx2, sv, P_, G, pre, ref, ref_bs, mask, geom, N, M, npts, g_le
                   g("norm2.weight"), g("norm2.bias"), stream_dtype=stream)
     dsrc, d_out_m = proj_ln_bwd(dx1, sv["out_m"], P_["self_attn.output_proj.weight"], P_["norm1.weight"], sv["ln1"], pd,
                                 seeds[0], g("self_attn.output_proj.weight"), g("self_attn.output_proj.bias"),
-                                g("norm1.weight"), g("norm1.bias"), stream_dtype=stream)
+                                g("norm1.weight"), g("norm1.bias"), stream_dtype=torch.float32 if (stream is not None and out_f32) else stream)
     # grid queries + bf16 storage + D = 16: the LDS-tiled scatter can hand over the value gradient in bf16 (packed bf16x2
     # atomics; its consumer, the value projection's backward, rounds it to bf16 anyway) -- half the atomics, zero-fill and read
     gv16 = (v2b and sv["OA"].dtype in (torch.bfloat16, torch.float16) and D == 16 and npts == 4 and geom.L * npts <= 16

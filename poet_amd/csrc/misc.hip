@@ -29,14 +29,15 @@ __device__ __forceinline__ float gelu_df(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.39894228040143268f;
 }
 
-template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ o, int64_t n,
+// TXI: storage of the kept pre-activation (fp32 where the bf16 policy hands the Linear's accumulators over unrounded), T: of y / dy / dx
+template <typename TXI, typename T, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const TXI* __restrict__ x, const T* __restrict__ dy, T* __restrict__ o, int64_t n,
                                                    uint32_t thresh, float dscale, uint32_t seed, const uint32_t* __restrict__ seed_dev) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     const uint32_t sd = seed ^ (seed_dev ? *seed_dev * 0x9E3779B1u : 0u);
     if (i + 8 <= n) {
         float a[8], g[8];
-        vec<T, 8>::ld(x + i, a);
+        vec<TXI, 8>::ld(x + i, a);
         if constexpr (BWD) vec<T, 8>::ld(dy + i, g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, cons
     } else {
         for (int64_t j = i; j < n; ++j) {
             const float keep = thresh ? (drop_keep(sd, (uint32_t)j, thresh) ? dscale : 0.f) : 1.f;
-            const float a = io<T>::ld(x + j);
+            const float a = io<TXI>::ld(x + j);
             io<T>::st(o + j, BWD ? io<T>::ld(dy + j) * keep * gelu_df(a) : gelu_f(a) * keep);
         }
     }
@@ -65,15 +66,17 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* _
     }
 }
 
-// zero-fill of `bytes` bytes at a 4-byte aligned address: 16-byte stores (4-byte head / tail pieces), 64 bytes per lane
+// zero-fill of `bytes` bytes at a 4-byte aligned address: a workgroup owns 16 KB; 16-byte stores, consecutive lanes on consecutive
+// 16-byte pieces (every store instruction of a wave covers 1 KB of whole lines -- with 64 contiguous bytes PER LANE each instruction
+// touched a quarter of 64 different 64-byte segments: 261 MB took 75 us = 3.5 TB/s); 4-byte pieces for an unaligned base / the tail
 __global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, int64_t words) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
-    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && i + 16 <= words) {
-        uint4* q = reinterpret_cast<uint4*>(p + i);
+    const int64_t b = (int64_t)blockIdx.x * 4096;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && b + 4096 <= words) {
+        uint4* q = reinterpret_cast<uint4*>(p + b) + threadIdx.x;
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+        q[0] = z; q[256] = z; q[512] = z; q[768] = z;
     } else {
-        for (int64_t j = i; j < words && j < i + 16; ++j) p[j] = 0u;
+        for (int64_t j = b + threadIdx.x; j < words && j < b + 4096; j += 256) p[j] = 0u;
     }
 }
 
@@ -798,29 +801,34 @@ extern "C" int poet_add(const void* a, const void* b, void* out, int64_t n, int 
     return POET_OK;
 }
 
-extern "C" int poet_gelu_fwd(const void* x, void* y, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+extern "C" int poet_gelu_fwd(const void* x, void* y, int64_t n, int dtype_x, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                             void* stream) {
     POET_CHECK(x && y && n > 0, POET_ERR_ARG, "gelu_fwd: bad args");
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "gelu_fwd: drop_p");
-    POET_CHECK(dtype == POET_F32 || dtype == POET_BF16, POET_ERR_UNSUPPORTED, "gelu_fwd: dtype %d", dtype);
+    POET_CHECK((dtype == POET_F32 || dtype == POET_BF16) && (dtype_x == dtype || dtype_x == POET_F32), POET_ERR_UNSUPPORTED,
+               "gelu_fwd: dtypes x %d, y %d", dtype_x, dtype);
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     dim3 grid(cdiv(n, 2048)), block(256);
-    if (dtype == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, false>), grid, block, 0, ST, (const float*)x, (const float*)nullptr, (float*)y, n, th, ds, seed, seed_dev);
-    else hipLaunchKernelGGL((gelu_kernel<bf16_t, false>), grid, block, 0, ST, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, th, ds, seed, seed_dev);
+    if (dtype == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, float, false>), grid, block, 0, ST, (const float*)x, (const float*)nullptr, (float*)y, n, th, ds, seed, seed_dev);
+    else if (dtype_x == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, bf16_t, false>), grid, block, 0, ST, (const float*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, th, ds, seed, seed_dev);
+    else hipLaunchKernelGGL((gelu_kernel<bf16_t, bf16_t, false>), grid, block, 0, ST, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, th, ds, seed, seed_dev);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }
 
-extern "C" int poet_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, float drop_p, uint32_t seed, const uint32_t* seed_dev,
-                             void* stream) {
+extern "C" int poet_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype_x, int dtype, float drop_p, uint32_t seed,
+                             const uint32_t* seed_dev, void* stream) {
     POET_CHECK(dy && x && dx && n > 0, POET_ERR_ARG, "gelu_bwd: bad args");
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "gelu_bwd: drop_p");
-    POET_CHECK(dtype == POET_F32 || dtype == POET_BF16, POET_ERR_UNSUPPORTED, "gelu_bwd: dtype %d", dtype);
+    POET_CHECK((dtype == POET_F32 || dtype == POET_BF16) && (dtype_x == dtype || dtype_x == POET_F32), POET_ERR_UNSUPPORTED,
+               "gelu_bwd: dtypes x %d, dy %d", dtype_x, dtype);
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     dim3 grid(cdiv(n, 2048)), block(256);
-    if (dtype == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, true>), grid, block, 0, ST, (const float*)x, (const float*)dy, (float*)dx, n, th, ds, seed, seed_dev);
-    else hipLaunchKernelGGL((gelu_kernel<bf16_t, true>), grid, block, 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, th, ds, seed, seed_dev);
+    if (dtype == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, float, true>), grid, block, 0, ST, (const float*)x, (const float*)dy, (float*)dx, n, th, ds, seed, seed_dev);
+    else if (dtype_x == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, bf16_t, true>), grid, block, 0, ST, (const float*)x, (const bf16_t*)dy, (bf16_t*)dx, n, th, ds, seed, seed_dev);
+    else hipLaunchKernelGGL((gelu_kernel<bf16_t, bf16_t, true>), grid, block, 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, th, ds, seed, seed_dev);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -9,10 +9,11 @@ namespace poet {
 
 constexpr int LN_MAXIT = 4;   // d <= 1024
 
-template <typename TX, typename TR, typename TZ = TX>
+// TRO: storage of y, the residual stream (= TR, the type of `res`, unless the encoder's fp16 stream starts or ends at this launch)
+template <typename TX, typename TR, typename TZ = TX, typename TRO = TR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const TR* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     TR* __restrict__ y, TZ* __restrict__ z, float* __restrict__ mean,
+                                                     TRO* __restrict__ y, TZ* __restrict__ z, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t rows, int d, float eps,
                                                      uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16,
                                                      const uint32_t* __restrict__ seed_dev,
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
             vec<float, 4>::ld(beta + c, b);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * g[e] + b[e];
-            vec<TR, 4>::st(y + row * d + c, o);
+            vec<TRO, 4>::st(y + row * d + c, o);
             if (y16) vec<bf16_t, 4>::st(y16 + row * d + c, o);
             if (z) vec<TZ, 4>::st(z + row * d + c, v[it]);
             if (q16) {                                    // the NEXT layer's query operand y + pos (deformable_transformer.py:201)
@@ -160,6 +161,80 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, 
         const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
         atomicAdd(dgamma + c, sg);
         atomicAdd(dbeta + c, sb);
+    }
+}
+
+// d = 256 (one 4-element vector per lane), R rows per wave iteration.  The kernel above keeps ONE row per wave in flight and lets
+// occupancy hide the latency: its time per row does not depend on the bytes of the row, so the bf16 gradient stream (208 instead of
+// 312 MB per launch) bought nothing there (66.8 -> 71.8 us).  Here the loads of R rows are issued before the first reduction.
+template <typename TX, typename TR, typename TRO, int R>
+__global__ __launch_bounds__(256) void ln_bwd256_kernel(const TR* __restrict__ dy, const TX* __restrict__ z,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, TRO* __restrict__ dz,
+                                                        TX* __restrict__ dx, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int64_t rows,
+                                                        uint32_t thresh, float dscale, uint32_t seed,
+                                                        const uint32_t* __restrict__ seed_dev) {
+    constexpr int d = 256;
+    __shared__ float red[2][4][d];
+    if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane * 4;
+    float gm[4], ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    vec<float, 4>::ld(gamma + c, gm);
+    const bool sep = dx && ((const void*)dx != (const void*)dz || thresh);
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * R; row0 < rows; row0 += (int64_t)gridDim.x * 4 * R) {
+        float a[R][4], zz[R][4], mu[R], rs[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = min(row0 + r, rows - 1);
+            vec<TR, 4>::ld(dy + row * d + c, a[r]);
+            vec<TX, 4>::ld(z + row * d + c, zz[r]);
+            mu[r] = mean[row]; rs[r] = rstd[row];
+        }
+        float c1[R], c2[R], g[R][4], xh[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = row0 + r < rows;
+            c1[r] = 0.f; c2[r] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float av = ok ? a[r][e] : 0.f;
+                xh[r][e] = (zz[r][e] - mu[r]) * rs[r];
+                ag[e] += av * xh[r][e];
+                ab[e] += av;
+                g[r][e] = av * gm[e];
+                c1[r] += g[r][e];
+                c2[r] += g[r][e] * xh[r][e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { c1[r] = wave_sum(c1[r]) * (1.f / d); c2[r] = wave_sum(c2[r]) * (1.f / d); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (row0 + r < rows) {
+                const int64_t row = row0 + r;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs[r] * (g[r][e] - c1[r] - xh[r][e] * c2[r]);
+                vec<TRO, 4>::st(dz + row * d + c, o);
+                if (sep) {
+                    if (thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c + e), thresh) ? o[e] * dscale : 0.f;
+                    }
+                    vec<TX, 4>::st(dx + row * d + c, o);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][wid][c + e] = ag[e]; red[1][wid][c + e] = ab[e]; }
+    __syncthreads();
+    {
+        const int cc = threadIdx.x;
+        atomicAdd(dgamma + cc, red[0][0][cc] + red[0][1][cc] + red[0][2][cc] + red[0][3][cc]);
+        atomicAdd(dbeta + cc, red[1][0][cc] + red[1][1][cc] + red[1][2][cc] + red[1][3][cc]);
     }
 }
 
@@ -462,11 +537,12 @@ using namespace poet;
 
 extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
                            float* mean, float* rstd, int64_t rows, int d, float eps, float drop_p, uint32_t seed,
-                           int dtype_x, int dtype_r, int dtype_z, void* y_bf16, const void* pos_bf16, void* q_bf16,
+                           int dtype_x, int dtype_r, int dtype_y, int dtype_z, void* y_bf16, const void* pos_bf16, void* q_bf16,
                            const uint32_t* seed_dev, void* stream) {
     POET_CHECK(x && gamma && beta && y, POET_ERR_ARG, "ln_fwd: null pointer");
     POET_CHECK((pos_bf16 == nullptr) == (q_bf16 == nullptr), POET_ERR_ARG, "ln_fwd: pos_bf16 and q_bf16 come together");
     if (dtype_z < 0) dtype_z = dtype_x;
+    if (dtype_y < 0) dtype_y = dtype_r;
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_fwd: d=%d unsupported", d);
     POET_CHECK(drop_p >= 0.f && drop_p < 1.f, POET_ERR_ARG, "ln_fwd: drop_p");
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
@@ -474,9 +550,18 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
     dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16)
-    if (dtype_x == POET_F16) {      // (round 6) the branch stored as IEEE fp16 by the projection (PoetGemmDesc.c_f16): fp32 stream, bf16 saved sum
-        POET_CHECK(dtype_r == POET_F32 && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED, "ln_fwd: an fp16 branch comes with an fp32 stream and a bf16 saved sum (%d,%d,%d)", dtype_x, dtype_r, dtype_z);
-        ln_fwd_kernel<f16_t, float, bf16_t><<<grid, block, 0, st>>>((const f16_t*)x, (const float*)res, gamma, beta, (float*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16);
+    if (dtype_x == POET_F16) {      // (round 6) the branch stored as IEEE fp16 by the projection (PoetGemmDesc.c_f16): fp32 or fp16 stream, bf16 saved sum
+        POET_CHECK((dtype_r == POET_F32 || dtype_r == POET_F16) && (dtype_y == POET_F32 || dtype_y == POET_F16) && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED,
+                   "ln_fwd: an fp16 branch comes with an fp32 / fp16 stream and a bf16 saved sum (x %d, res %d, y %d, z %d)", dtype_x, dtype_r, dtype_y, dtype_z);
+#define LN_FWD_H(TR, TRO) ln_fwd_kernel<f16_t, TR, bf16_t, TRO><<<grid, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16)
+        if (dtype_r == POET_F32 && dtype_y == POET_F32) LN_FWD_H(float, float);
+        else if (dtype_r == POET_F32) LN_FWD_H(float, f16_t);
+        else if (dtype_y == POET_F32) LN_FWD_H(f16_t, float);
+        else LN_FWD_H(f16_t, f16_t);
+#undef LN_FWD_H
+    } else if (dtype_y != dtype_r) {
+        set_error("ln_fwd: the stream changes its storage type only behind an fp16 branch (x %d, res %d, y %d)", dtype_x, dtype_r, dtype_y);
+        return POET_ERR_UNSUPPORTED;
     } else if (dtype_z == dtype_x) {
         POET_DT2(dtype_x, dtype_r, LN_FWD);
     } else {        // fp32 branch input (the GEMM's accumulators, never rounded to bf16) with the pre-norm sum saved in bf16 for backward
@@ -495,7 +580,8 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     POET_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= LN_MAXIT * 256, POET_ERR_UNSUPPORTED, "ln_bwd: d=%d unsupported", d);
     POET_CHECK(!(drop_p > 0.f && dx_out == dz_out), POET_ERR_ARG, "ln_bwd: dx_out must not alias dz_out when drop_p>0");
     POET_CHECK(!(dtype_x != dtype_dz && (dx_out == nullptr || dx_out == dz_out)), POET_ERR_ARG, "ln_bwd: mixed dtypes need a separate dx_out");
-    POET_CHECK(dtype_dz == dtype_r || (dtype_dz == POET_BF16 && dtype_x == POET_BF16), POET_ERR_UNSUPPORTED,
+    POET_CHECK(dtype_dz == dtype_r || (dtype_dz == POET_BF16 && dtype_x == POET_BF16) ||
+               (dtype_dz == POET_F32 && dtype_r == POET_BF16 && dtype_x == POET_BF16 && d == 256 && rows >= 4096), POET_ERR_UNSUPPORTED,
                "ln_bwd: dz dtype %d with (x, dy) dtypes (%d, %d)", dtype_dz, dtype_x, dtype_r);
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -505,9 +591,26 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     // of the epilogue: with the blocks' column sums stored to a workspace and added by a second launch the larger grids measured 81 / 76 / 90).
     // POET_LN_BWD_NB: the cap (A/B aid, read once).
     static const int cap = [] { const char* e = getenv("POET_LN_BWD_NB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    hipStream_t st = (hipStream_t)stream;
+    // d = 256 with 2-byte saved sums: R rows per wave iteration (POET_LN_BWD_R: 1 = the one-row kernel, A/B aid, read once)
+    static const int rper = [] { const char* e = getenv("POET_LN_BWD_R"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 || v == 8 ? v : 4; }();
+    if (d == 256 && (rper > 1 || (dtype_dz == POET_F32 && dtype_r == POET_BF16)) && rows >= 4096 && dtype_x == POET_BF16) {
+        int nb2 = cdiv(rows, 4 * rper);
+        if (nb2 > cap) nb2 = cap;
+        dim3 grid2(nb2), block2(256);
+#define LN_BWD256(TR, TRO, R) ln_bwd256_kernel<bf16_t, TR, TRO, R><<<grid2, block2, 0, st>>>((const TR*)dy, (const bf16_t*)z, mean, rstd, gamma, (TRO*)dz_out, (bf16_t*)dx_out, dgamma, dbeta, rows, th, sc, seed, seed_dev)
+#define LN_BWD256_R(TR, TRO) do { if (rper == 2) LN_BWD256(TR, TRO, 2); else if (rper == 8) LN_BWD256(TR, TRO, 8); else LN_BWD256(TR, TRO, 4); } while (0)
+        if (dtype_r == POET_F32 && dtype_dz == POET_F32) LN_BWD256_R(float, float);
+        else if (dtype_r == POET_F32) LN_BWD256_R(float, bf16_t);
+        else if (dtype_dz == POET_F32) LN_BWD256_R(bf16_t, float);      // (where the bf16 stream ends: layer 0 hands fp32 to the input projection)
+        else LN_BWD256_R(bf16_t, bf16_t);
+#undef LN_BWD256_R
+#undef LN_BWD256
+        POET_LAUNCH_CHECK();
+        return POET_OK;
+    }
     if (nb > cap) nb = cap;
     dim3 grid(nb), block(256);
-    hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(TX, TR) ln_bwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TR*)dy, (const TX*)z, mean, rstd, gamma, (TR*)dz_out, (TX*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev)
     if (dtype_dz != dtype_r)        // the bf16 gradient stream starts here: fp32 d(y) in, bf16 d(z) out (bf16 saved sum)
         ln_bwd_kernel<bf16_t, float, bf16_t><<<grid, block, 0, st>>>((const float*)dy, (const bf16_t*)z, mean, rstd, gamma, (bf16_t*)dz_out, (bf16_t*)dx_out, dgamma, dbeta, rows, d, th, sc, seed, seed_dev);

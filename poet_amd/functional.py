@@ -68,6 +68,7 @@ def enc_bucket_tag(n_layers: int, i: int) -> str:
     return f"2_encoder_{n_layers - 1 - i:02d}"
 
 
+_FSTREAM = {}        # (id(cfg), layer index) -> fp16 input stream of that encoder layer, left by the forward of the layer below
 _GSTREAM = {}        # (id(cfg), layer index) -> bf16 d(output) of that encoder layer, left by the backward of the layer above
 
 
@@ -82,9 +83,17 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.need_pos, ctx.pos_dtype = pos2.requires_grad, pos2.dtype          # a learned position encoding (position_encoding.py:87-112): backward returns d(pos)
         P_ = _pdict(names, params, "")
         emit = idx + 1 < cfg["n_layers"]
-        out = B.enc_layer_fwd(x, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
-                              cfg["training"], cfg.get("act"), cfg.get("split", False), q_in=q_in, emit_q=emit, ffn_act=cfg.get("ffn_act", "relu"))
+        # The fp16 residual stream (blocks.proj_ln_fwd) travels from layer to layer beside autograd, like the bf16 gradient stream in
+        # backward: autograd sees an unwritten fp32 placeholder of the stream's shape (graph connectivity only), the next layer picks the
+        # real rows up here.  The last layer writes fp32 (`memory`).
+        x_real = _FSTREAM.pop((id(cfg), idx), None)
+        out = B.enc_layer_fwd(x if x_real is None else x_real, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
+                              cfg["training"], cfg.get("act"), cfg.get("split", False), q_in=q_in, emit_q=emit, ffn_act=cfg.get("ffn_act", "relu"),
+                              stream_out16=emit)
         y, y16, sv = out[:3]
+        if y.dtype == torch.float16:
+            _FSTREAM[(id(cfg), idx + 1)] = y
+            y = torch.empty(y.shape, dtype=torch.float32, device=y.device)            # placeholder: never written, never read
         q_next = out[3] if emit and out[3] is not None else x.new_empty(0)
         ctx.saved, ctx.geom, ctx.cfg, ctx.idx, ctx.names, ctx.params = sv, geom, cfg, idx, names, params
         ctx.ref, ctx.mask, ctx.level_embed = ref, mask, level_embed
@@ -111,7 +120,7 @@ class EncoderLayerFn(torch.autograd.Function):
         if dy_real is None:
             dy_real = dy.contiguous()
         dx = B.enc_layer_bwd(dy_real, ctx.saved, _pdict(names, params, ""), G, "", ctx.ref, S * geom.L * 2, ctx.mask, geom,
-                             N, cfg["M"], cfg["P"], g_level, dpos=dpos)
+                             N, cfg["M"], cfg["P"], g_level, dpos=dpos, out_f32=(i == 0 or not ctx.need_x))
         if dx.dtype != torch.float32:
             if i > 0 and ctx.need_x:
                 _GSTREAM[(id(cfg), i - 1)] = dx

@@ -470,7 +470,7 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None, pos16=None, q16=None):
     lib = _lib.load()
     _lib.check(lib.poet_ln_fwd(_req(x, "x").data_ptr(), _ptr(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(z),
-                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y),
+                               _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y) if res is None else dcode(res), dcode(y),
                                -1 if z is None else dcode(z), _ptr(y16), _ptr(pos16), _ptr(q16),
                                _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_fwd")
     return y
@@ -578,9 +578,9 @@ def add(a, b, out):
 
 
 def gelu_fwd(x, y, drop_p=0.0, seed=0):
-    """y = dropout(gelu(x)) (erf form), same dtype."""
+    """y = dropout(gelu(x)) (erf form); x in y's dtype or fp32."""
     lib = _lib.load()
-    _lib.check(lib.poet_gelu_fwd(_req(x, "x").data_ptr(), y.data_ptr(), x.numel(), dcode(x), drop_p, seed & 0xFFFFFFFF,
+    _lib.check(lib.poet_gelu_fwd(_req(x, "x").data_ptr(), y.data_ptr(), x.numel(), dcode(x), dcode(y), drop_p, seed & 0xFFFFFFFF,
                                  _seed_dev() if drop_p > 0 else None, _stream()), "poet_gelu_fwd")
     return y
 
@@ -588,7 +588,7 @@ def gelu_fwd(x, y, drop_p=0.0, seed=0):
 def gelu_bwd(dy, x, dx, drop_p=0.0, seed=0):
     """dx = dy * mask / (1 - p) * gelu'(x): the mask is redrawn from (seed, element index)."""
     lib = _lib.load()
-    _lib.check(lib.poet_gelu_bwd(_req(dy, "dy").data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), dcode(x), drop_p, seed & 0xFFFFFFFF,
+    _lib.check(lib.poet_gelu_bwd(_req(dy, "dy").data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), dcode(x), dcode(dy), drop_p, seed & 0xFFFFFFFF,
                                  _seed_dev() if drop_p > 0 else None, _stream()), "poet_gelu_bwd")
     return dx
 

@@ -718,12 +718,13 @@ def test_layernorm_mixed(ops):
     _close(dx, zr.grad, torch.bfloat16, msg="mixed ln dx")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_gelu_dropout_forward_backward(ops, dtype):
+@pytest.mark.parametrize("dtype,xdtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+def test_gelu_dropout_forward_backward(ops, dtype, xdtype):
     """poet_gelu_fwd / poet_gelu_bwd (the FFN with activation="gelu", deformable_transformer.py:347-355): F.gelu (erf form) and its
-    derivative on the kept pre-activation; the backward redraws the forward's dropout mask."""
+    derivative on the kept pre-activation (stored in the output's type, or fp32 under bf16 storage); the backward redraws the forward's
+    dropout mask."""
     n = 5 * 2048 + 13
-    x = _rand(n, seed=180, scale=2.5).to(dtype)
+    x = _rand(n, seed=180, scale=2.5).to(xdtype)
     y = torch.empty(n, dtype=dtype, device="cuda")
     ops.gelu_fwd(dev(x), y)
     xr = x.float().requires_grad_()
@@ -818,6 +819,44 @@ def test_layernorm_fp16_branch(ops, rows):
     ref = F.layer_norm(x16.float() + res, (d,), gamma, beta, 1e-5)                   # (the last pass ran without dropout)
     assert (outs[0][0].cpu() - ref).abs().max().item() < 1e-5
     assert torch.equal(outs[0][2].cpu(), outs[0][0].cpu().to(torch.bfloat16))
+
+
+def test_zero_fill_sizes_and_alignments(ops):
+    """poet_zero: whole 16 KB blocks, ragged tails, bases that are only 4-byte aligned; nothing written outside [base, base + bytes)."""
+    for words, off in [(4096 * 3, 0), (4096 * 3 + 17, 0), (5, 0), (4096 * 2 + 1, 1), (4096 + 4095, 3), (70000, 2)]:
+        buf = torch.full((words + off + 8,), 7, dtype=torch.int32, device="cuda")
+        ops.zero_(buf[off:off + words])
+        assert bool((buf[off:off + words] == 0).all())
+        assert bool((buf[:off] == 7).all()) and bool((buf[off + words:] == 7).all())
+
+
+def test_layernorm_fp16_stream(ops):
+    """The encoder's residual stream stored as IEEE fp16 between its LayerNorms (poet_ln_fwd: dtype_r / dtype_y = POET_F16 behind an
+    fp16 branch): every combination of (res, y) storage equals the fp32-stream launch on the same values -- y rounded once to fp16,
+    the bf16 operand copy, the next layer's query copy, the saved sum and the statistics BIT FOR BIT."""
+    rows, d = 4096 + 5, 256
+    x16 = _rand(rows, d, seed=170, scale=3.0).to(torch.float16)
+    res16 = _rand(rows, d, seed=171).to(torch.float16)
+    gamma, beta = 1.0 + 0.1 * _rand(d, seed=172), 0.1 * _rand(d, seed=173)
+    pos = _rand(rows, d, seed=174).to(torch.bfloat16)
+
+    def run(res, ydt, drop):
+        y = torch.empty(rows, d, dtype=ydt, device="cuda")
+        z = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
+        y16, q16 = torch.empty_like(z), torch.empty_like(z)
+        mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+        ops.ln_fwd(dev(x16), dev(res), dev(gamma), dev(beta), y, z, mean, rstd, rows, d, 1e-5, drop, 4321, y16=y16, pos16=dev(pos), q16=q16)
+        return y, z, y16, q16, mean, rstd
+
+    for drop in (0.0, 0.1):
+        base = run(res16.float(), torch.float32, drop)
+        for res, ydt in ((res16, torch.float16), (res16, torch.float32), (res16.float(), torch.float16)):
+            got = run(res, ydt, drop)
+            assert torch.equal(got[0].float(), base[0].to(ydt).float())
+            for a, b in zip(got[1:], base[1:]):
+                assert torch.equal(a, b)
+    ref = F.layer_norm(x16.float() + res16.float(), (d,), gamma, beta, 1e-5)
+    assert (run(res16, torch.float16, 0.0)[0].float().cpu() - ref).abs().max().item() < 4e-3
 
 
 @pytest.mark.parametrize("shapes,m,dt", [([(12, 16), (6, 8), (3, 4)], 4, torch.float32), ([(30, 40), (15, 20), (8, 10), (4, 5)], 2, torch.bfloat16),
