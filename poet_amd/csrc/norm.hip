@@ -83,6 +83,81 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     }
 }
 
+// d = 256, R rows per wave iteration, grid-stride: the loads of R rows (branch, stream, position) are in flight before the first
+// reduction.  The one-row kernel above relies on occupancy alone; once the stream shrank to fp16 (260-366 MB per launch instead of
+// 364-470) it stopped following the bytes (-4.5 us per launch for -104 MB).  Same arithmetic per row, bit for bit.
+template <typename TX, typename TR, typename TZ, typename TRO, int R>
+__global__ __launch_bounds__(256) void ln_fwd256_kernel(const TX* __restrict__ x, const TR* __restrict__ res,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        TRO* __restrict__ y, TZ* __restrict__ z, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int64_t rows, float eps,
+                                                        uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16,
+                                                        const uint32_t* __restrict__ seed_dev,
+                                                        const bf16_t* __restrict__ pos, bf16_t* __restrict__ q16) {
+    constexpr int d = 256;
+    if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane * 4;
+    float g[4], b[4];
+    vec<float, 4>::ld(gamma + c, g);
+    vec<float, 4>::ld(beta + c, b);
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * R; row0 < rows; row0 += (int64_t)gridDim.x * 4 * R) {
+        float v[R][4], r[R][4], pp[R][4];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int64_t row = min(row0 + k, rows - 1);
+            vec<TX, 4>::ld(x + row * d + c, v[k]);
+            if (res) vec<TR, 4>::ld(res + row * d + c, r[k]);
+            if (q16) vec<bf16_t, 4>::ld(pos + row * d + c, pp[k]);
+        }
+        float s[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int64_t row = min(row0 + k, rows - 1);
+            s[k] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = v[k][e];
+                if (thresh) a = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c + e), thresh) ? a * dscale : 0.f;
+                if (res) a += r[k][e];
+                v[k][e] = a;
+                s[k] += a;
+            }
+        }
+        float mu[R], q[R], rs[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) mu[k] = wave_sum(s[k]) / (float)d;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            q[k] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = v[k][e] - mu[k]; q[k] += t * t; }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) rs[k] = rsqrtf(wave_sum(q[k]) / (float)d + eps);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (row0 + k < rows) {
+                const int64_t row = row0 + k;
+                if (lane == 0) {
+                    if (mean) mean[row] = mu[k];
+                    if (rstd) rstd[row] = rs[k];
+                }
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu[k]) * rs[k] * g[e] + b[e];
+                vec<TRO, 4>::st(y + row * d + c, o);
+                if (y16) vec<bf16_t, 4>::st(y16 + row * d + c, o);
+                if (z) vec<TZ, 4>::st(z + row * d + c, v[k]);
+                if (q16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pp[k][e] += o[e];
+                    vec<bf16_t, 4>::st(q16 + row * d + c, pp[k]);
+                }
+            }
+        }
+    }
+}
+
 // TRO: storage type of the stream gradient dz (= TR unless the encoder's bf16 gradient stream starts here: fp32 in, bf16 out)
 template <typename TX, typename TR, typename TRO = TR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TR* __restrict__ dy, const TX* __restrict__ z,
@@ -553,7 +628,18 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
     if (dtype_x == POET_F16) {      // (round 6) the branch stored as IEEE fp16 by the projection (PoetGemmDesc.c_f16): fp32 or fp16 stream, bf16 saved sum
         POET_CHECK((dtype_r == POET_F32 || dtype_r == POET_F16) && (dtype_y == POET_F32 || dtype_y == POET_F16) && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED,
                    "ln_fwd: an fp16 branch comes with an fp32 / fp16 stream and a bf16 saved sum (x %d, res %d, y %d, z %d)", dtype_x, dtype_r, dtype_y, dtype_z);
-#define LN_FWD_H(TR, TRO) ln_fwd_kernel<f16_t, TR, bf16_t, TRO><<<grid, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16)
+        // d = 256 at >= 4096 rows: R rows per wave iteration, 8 workgroups per CU (POET_LN_FWD_R: 1 = the one-row kernel; A/B aid, read once)
+        static const int rper = [] { const char* e = getenv("POET_LN_FWD_R"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 2; }();
+        static const int capf = [] { const char* e = getenv("POET_LN_FWD_NB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();      // (102 080 rows, fp16 stream: 512: 59 / 98 us, 1024: 50 / 68, 2048: 50 / 75, 4096: 46 / 67, all: 44 / 70)
+        const bool multi = d == 256 && rows >= 4096 && rper > 1;
+        int nbf = cdiv(rows, 4 * rper);
+        if (nbf > capf) nbf = capf;
+        dim3 gridm(nbf);
+#define LN_FWD_H(TR, TRO) do {                                                                                                          \
+        if (multi && rper == 2) ln_fwd256_kernel<f16_t, TR, bf16_t, TRO, 2><<<gridm, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16); \
+        else if (multi) ln_fwd256_kernel<f16_t, TR, bf16_t, TRO, 4><<<gridm, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16); \
+        else ln_fwd_kernel<f16_t, TR, bf16_t, TRO><<<grid, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16); \
+    } while (0)
         if (dtype_r == POET_F32 && dtype_y == POET_F32) LN_FWD_H(float, float);
         else if (dtype_r == POET_F32) LN_FWD_H(float, f16_t);
         else if (dtype_y == POET_F32) LN_FWD_H(f16_t, float);
@@ -595,8 +681,14 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
     // d = 256 with 2-byte saved sums: R rows per wave iteration (POET_LN_BWD_R: 1 = the one-row kernel, A/B aid, read once)
     static const int rper = [] { const char* e = getenv("POET_LN_BWD_R"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 || v == 8 ? v : 4; }();
     if (d == 256 && (rper > 1 || (dtype_dz == POET_F32 && dtype_r == POET_BF16)) && rows >= 4096 && dtype_x == POET_BF16) {
-        int nb2 = cdiv(rows, 4 * rper);
-        if (nb2 > cap) nb2 = cap;
+        // ~200 rows per workgroup: every workgroup ends with a 2 x 256-column LDS reduction and 512 atomics, so FEWER, longer-running
+        // workgroups win once several rows are in flight per wave (102 080 rows, bf16 stream, us: 256: 44, 384: 43, 512: 40, 768: 43,
+        // 1024: 45, 2048: 62; 51 200 rows: 512: 27, 1024: 35; 204 000 rows: 512: 87, 1024: 81)
+        static const int forced = [] { const char* e = getenv("POET_LN_BWD_NB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+        int nb2 = forced ? forced : (int)((rows / 200 + 128) / 256) * 256;
+        if (nb2 < 256) nb2 = 256;
+        if (nb2 > 1024 && !forced) nb2 = 1024;
+        if (nb2 > cdiv(rows, 4 * rper)) nb2 = cdiv(rows, 4 * rper);
         dim3 grid2(nb2), block2(256);
 #define LN_BWD256(TR, TRO, R) ln_bwd256_kernel<bf16_t, TR, TRO, R><<<grid2, block2, 0, st>>>((const TR*)dy, (const bf16_t*)z, mean, rstd, gamma, (TRO*)dz_out, (bf16_t*)dx_out, dgamma, dbeta, rows, th, sc, seed, seed_dev)
 #define LN_BWD256_R(TR, TRO) do { if (rper == 2) LN_BWD256(TR, TRO, 2); else if (rper == 8) LN_BWD256(TR, TRO, 8); else LN_BWD256(TR, TRO, 4); } while (0)
