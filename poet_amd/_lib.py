@@ -46,7 +46,7 @@ _PROTOS = {
                              i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_msda_fused_bwd": ([vp, i64, i64, i64, pi64, pi64, vp, i64, i32, vp, i64, vp, vp, vp, i64,
                              i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, pi64, vp], i32),
-    "poet_ln_fwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u32, i32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
+    "poet_ln_fwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], i32),
     "poet_ln_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u32, i32, i32, i32, vp, vp], i32),
     "poet_mha_fwd": ([vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, u32, vp, vp], i32),
     "poet_mha_bwd": ([vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, u32, vp, vp], i32),

@@ -422,9 +422,13 @@ bool gemm_pipe_try(const GemmK& g, hipStream_t st) {
         else pipe_launch<32, false, false, false, 5, 5, 1>(p, grid, st);
         return true;
     }
-    if (bout) {
-        if (acc) pipe_launch<32, true, false, true, 5, 5, 2>(p, grid, st);
-        else pipe_launch<32, true, false, false, 5, 5, 2>(p, grid, st);
+    if (bout) {                                                         // (POET_PIPE_CFG 1-3: the ring shapes of pipe_dispatch, A/B aid)
+        if (acc) {
+            if (cfg == 1) pipe_launch<64, true, false, true, 3, 2, 2>(p, grid, st);
+            else if (cfg == 2) pipe_launch<32, true, false, true, 6, 4, 2>(p, grid, st);
+            else if (cfg == 3) pipe_launch<32, true, false, true, 4, 6, 2>(p, grid, st);
+            else pipe_launch<32, true, false, true, 5, 5, 2>(p, grid, st);
+        } else pipe_launch<32, true, false, false, 5, 5, 2>(p, grid, st);
         return true;
     }
     switch (key) {

@@ -9,6 +9,36 @@ namespace poet {
 
 constexpr int LN_MAXIT = 4;   // d <= 1024
 
+// The SPLIT residual stream (round 6): between the encoder's LayerNorms the stream y is not stored as fp32 but as its bf16 head --
+// the operand copy y16 every LayerNorm writes anyway for the next GEMM -- plus the remainder y - float(y16) as IEEE fp16: the
+// remainder is <= 2^-9 |y|, so its 11 bits put the pair at 2^-20 relative (fp32 keeps 2^-24), and a LayerNorm writes 52 MB less
+// per launch at 102 080 rows.  (A plain fp16 stream saves twice that, measured -0.17 ms per step, but re-rolls every rounding
+// downstream: its 2^-12 is within a factor 3 of the branch's own bf16 noise once the branch is smaller than the stream, and the
+// all-layer maximum of the 1280x960 golden went 4.3e-3 -> 1.17e-2 in the arena pass.)
+template <typename T> struct is_f16 { static constexpr bool value = false; };
+template <> struct is_f16<f16_t> { static constexpr bool value = true; };
+// res[e] of 4 consecutive elements: plain load, or bf16 head + fp16 remainder
+template <typename TR>
+__device__ __forceinline__ void ld_stream4(const TR* __restrict__ res, const bf16_t* __restrict__ hi, int64_t at, float* r) {
+    vec<TR, 4>::ld(res + at, r);
+    if constexpr (is_f16<TR>::value) {
+        float h[4];
+        vec<bf16_t, 4>::ld(hi + at, h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] += h[e];
+    }
+}
+// y[e]: plain store, or the fp16 remainder against the bf16 head that vec<bf16_t, 4>::st writes for the same values
+template <typename TRO>
+__device__ __forceinline__ void st_stream4(TRO* __restrict__ y, int64_t at, const float* o) {
+    if constexpr (is_f16<TRO>::value) {
+        const uint32_t p0 = pack_bf2(o[0], o[1]), p1 = pack_bf2(o[2], o[3]);
+        const float rem[4] = {o[0] - __uint_as_float(p0 << 16), o[1] - __uint_as_float(p0 & 0xffff0000u),
+                              o[2] - __uint_as_float(p1 << 16), o[3] - __uint_as_float(p1 & 0xffff0000u)};
+        vec<f16_t, 4>::st(y + at, rem);
+    } else vec<TRO, 4>::st(y + at, o);
+}
+
 // TRO: storage of y, the residual stream (= TR, the type of `res`, unless the encoder's fp16 stream starts or ends at this launch)
 template <typename TX, typename TR, typename TZ = TX, typename TRO = TR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const TR* __restrict__ res,
@@ -17,7 +47,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
                                                      float* __restrict__ rstd, int64_t rows, int d, float eps,
                                                      uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16,
                                                      const uint32_t* __restrict__ seed_dev,
-                                                     const bf16_t* __restrict__ pos = nullptr, bf16_t* __restrict__ q16 = nullptr) {
+                                                     const bf16_t* __restrict__ pos = nullptr, bf16_t* __restrict__ q16 = nullptr,
+                                                     const bf16_t* __restrict__ res_hi = nullptr) {
     if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wid;
@@ -37,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
             }
             if (res) {
                 float r[4];
-                vec<TR, 4>::ld(res + row * d + c, r);
+                ld_stream4<TR>(res, res_hi, row * d + c, r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] += r[e];
             }
@@ -69,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
             vec<float, 4>::ld(beta + c, b);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * g[e] + b[e];
-            vec<TRO, 4>::st(y + row * d + c, o);
+            st_stream4<TRO>(y, row * d + c, o);
             if (y16) vec<bf16_t, 4>::st(y16 + row * d + c, o);
             if (z) vec<TZ, 4>::st(z + row * d + c, v[it]);
             if (q16) {                                    // the NEXT layer's query operand y + pos (deformable_transformer.py:201)
@@ -93,7 +124,8 @@ __global__ __launch_bounds__(256) void ln_fwd256_kernel(const TX* __restrict__ x
                                                         float* __restrict__ rstd, int64_t rows, float eps,
                                                         uint32_t thresh, float dscale, uint32_t seed, bf16_t* __restrict__ y16,
                                                         const uint32_t* __restrict__ seed_dev,
-                                                        const bf16_t* __restrict__ pos, bf16_t* __restrict__ q16) {
+                                                        const bf16_t* __restrict__ pos, bf16_t* __restrict__ q16,
+                                                        const bf16_t* __restrict__ res_hi) {
     constexpr int d = 256;
     if (seed_dev) seed ^= *seed_dev * 0x9E3779B1u;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane * 4;
@@ -106,7 +138,7 @@ __global__ __launch_bounds__(256) void ln_fwd256_kernel(const TX* __restrict__ x
         for (int k = 0; k < R; ++k) {
             const int64_t row = min(row0 + k, rows - 1);
             vec<TX, 4>::ld(x + row * d + c, v[k]);
-            if (res) vec<TR, 4>::ld(res + row * d + c, r[k]);
+            if (res) ld_stream4<TR>(res, res_hi, row * d + c, r[k]);
             if (q16) vec<bf16_t, 4>::ld(pos + row * d + c, pp[k]);
         }
         float s[R];
@@ -145,7 +177,7 @@ __global__ __launch_bounds__(256) void ln_fwd256_kernel(const TX* __restrict__ x
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu[k]) * rs[k] * g[e] + b[e];
-                vec<TRO, 4>::st(y + row * d + c, o);
+                st_stream4<TRO>(y, row * d + c, o);
                 if (y16) vec<bf16_t, 4>::st(y16 + row * d + c, o);
                 if (z) vec<TZ, 4>::st(z + row * d + c, v[k]);
                 if (q16) {
@@ -613,7 +645,7 @@ using namespace poet;
 extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
                            float* mean, float* rstd, int64_t rows, int d, float eps, float drop_p, uint32_t seed,
                            int dtype_x, int dtype_r, int dtype_y, int dtype_z, void* y_bf16, const void* pos_bf16, void* q_bf16,
-                           const uint32_t* seed_dev, void* stream) {
+                           const void* res_bf16, const uint32_t* seed_dev, void* stream) {
     POET_CHECK(x && gamma && beta && y, POET_ERR_ARG, "ln_fwd: null pointer");
     POET_CHECK((pos_bf16 == nullptr) == (q_bf16 == nullptr), POET_ERR_ARG, "ln_fwd: pos_bf16 and q_bf16 come together");
     if (dtype_z < 0) dtype_z = dtype_x;
@@ -627,7 +659,9 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
 #define LN_FWD(TX, TR) ln_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, (const TR*)res, gamma, beta, (TR*)y, (TX*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16)
     if (dtype_x == POET_F16) {      // (round 6) the branch stored as IEEE fp16 by the projection (PoetGemmDesc.c_f16): fp32 or fp16 stream, bf16 saved sum
         POET_CHECK((dtype_r == POET_F32 || dtype_r == POET_F16) && (dtype_y == POET_F32 || dtype_y == POET_F16) && dtype_z == POET_BF16, POET_ERR_UNSUPPORTED,
-                   "ln_fwd: an fp16 branch comes with an fp32 / fp16 stream and a bf16 saved sum (x %d, res %d, y %d, z %d)", dtype_x, dtype_r, dtype_y, dtype_z);
+                   "ln_fwd: an fp16 branch comes with an fp32 / split stream and a bf16 saved sum (x %d, res %d, y %d, z %d)", dtype_x, dtype_r, dtype_y, dtype_z);
+        POET_CHECK(dtype_r != POET_F16 || (res && res_bf16), POET_ERR_ARG, "ln_fwd: a split stream (dtype_r = POET_F16) is the pair (res_bf16, res)");
+        POET_CHECK(dtype_y != POET_F16 || y_bf16, POET_ERR_ARG, "ln_fwd: a split stream output (dtype_y = POET_F16) is the pair (y_bf16, y)");
         // d = 256 at >= 4096 rows: R rows per wave iteration, 8 workgroups per CU (POET_LN_FWD_R: 1 = the one-row kernel; A/B aid, read once)
         static const int rper = [] { const char* e = getenv("POET_LN_FWD_R"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 2; }();
         static const int capf = [] { const char* e = getenv("POET_LN_FWD_NB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();      // (102 080 rows, fp16 stream: 512: 59 / 98 us, 1024: 50 / 68, 2048: 50 / 75, 4096: 46 / 67, all: 44 / 70)
@@ -636,9 +670,9 @@ extern "C" int poet_ln_fwd(const void* x, const void* res, const float* gamma, c
         if (nbf > capf) nbf = capf;
         dim3 gridm(nbf);
 #define LN_FWD_H(TR, TRO) do {                                                                                                          \
-        if (multi && rper == 2) ln_fwd256_kernel<f16_t, TR, bf16_t, TRO, 2><<<gridm, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16); \
-        else if (multi) ln_fwd256_kernel<f16_t, TR, bf16_t, TRO, 4><<<gridm, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16); \
-        else ln_fwd_kernel<f16_t, TR, bf16_t, TRO><<<grid, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16); \
+        if (multi && rper == 2) ln_fwd256_kernel<f16_t, TR, bf16_t, TRO, 2><<<gridm, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16, (const bf16_t*)res_bf16); \
+        else if (multi) ln_fwd256_kernel<f16_t, TR, bf16_t, TRO, 4><<<gridm, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16, (const bf16_t*)res_bf16); \
+        else ln_fwd_kernel<f16_t, TR, bf16_t, TRO><<<grid, block, 0, st>>>((const f16_t*)x, (const TR*)res, gamma, beta, (TRO*)y, (bf16_t*)z_out, mean, rstd, rows, d, eps, th, sc, seed, (bf16_t*)y_bf16, seed_dev, (const bf16_t*)pos_bf16, (bf16_t*)q_bf16, (const bf16_t*)res_bf16); \
     } while (0)
         if (dtype_r == POET_F32 && dtype_y == POET_F32) LN_FWD_H(float, float);
         else if (dtype_r == POET_F32) LN_FWD_H(float, f16_t);

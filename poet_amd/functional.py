@@ -68,7 +68,7 @@ def enc_bucket_tag(n_layers: int, i: int) -> str:
     return f"2_encoder_{n_layers - 1 - i:02d}"
 
 
-_FSTREAM = {}        # (id(cfg), layer index) -> fp16 input stream of that encoder layer, left by the forward of the layer below
+_FSTREAM = {}        # (id(cfg), layer index) -> fp16 remainder of that encoder layer's input stream, left by the forward of the layer below
 _GSTREAM = {}        # (id(cfg), layer index) -> bf16 d(output) of that encoder layer, left by the backward of the layer above
 
 
@@ -83,9 +83,9 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.need_pos, ctx.pos_dtype = pos2.requires_grad, pos2.dtype          # a learned position encoding (position_encoding.py:87-112): backward returns d(pos)
         P_ = _pdict(names, params, "")
         emit = idx + 1 < cfg["n_layers"]
-        # The fp16 residual stream (blocks.proj_ln_fwd) travels from layer to layer beside autograd, like the bf16 gradient stream in
-        # backward: autograd sees an unwritten fp32 placeholder of the stream's shape (graph connectivity only), the next layer picks the
-        # real rows up here.  The last layer writes fp32 (`memory`).
+        # The split residual stream (blocks.proj_ln_fwd: bf16 head = x16, fp16 remainder) travels from layer to layer beside autograd,
+        # like the bf16 gradient stream in backward: autograd sees an unwritten fp32 placeholder of the stream's shape (graph
+        # connectivity only), the next layer picks the remainder rows up here.  The last layer writes fp32 (`memory`).
         x_real = _FSTREAM.pop((id(cfg), idx), None)
         out = B.enc_layer_fwd(x if x_real is None else x_real, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
                               cfg["training"], cfg.get("act"), cfg.get("split", False), q_in=q_in, emit_q=emit, ffn_act=cfg.get("ffn_act", "relu"),

@@ -467,11 +467,12 @@ def msda_fused_bwd(value, vstrides, geom: LevelGeom, offattn, ldq, logit_col, re
 
 
 # ---- norms -----------------------------------------------------------------------------------------
-def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None, pos16=None, q16=None):
+def ln_fwd(x, res, gamma, beta, y, z, mean, rstd, rows, d, eps=1e-5, drop_p=0.0, seed=0, y16=None, pos16=None, q16=None, res16=None):
+    """res16: the bf16 head of a split input stream (res = its fp16 remainder); an fp16 y is the remainder against y16."""
     lib = _lib.load()
     _lib.check(lib.poet_ln_fwd(_req(x, "x").data_ptr(), _ptr(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(z),
                                _ptr(mean), _ptr(rstd), rows, d, eps, drop_p, seed & 0xFFFFFFFF, dcode(x), dcode(y) if res is None else dcode(res), dcode(y),
-                               -1 if z is None else dcode(z), _ptr(y16), _ptr(pos16), _ptr(q16),
+                               -1 if z is None else dcode(z), _ptr(y16), _ptr(pos16), _ptr(q16), _ptr(res16),
                                _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_fwd")
     return y
 

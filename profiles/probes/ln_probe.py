@@ -40,9 +40,10 @@ for rdt, ydt in ((torch.float32, torch.float32), (torch.float32, torch.float16),
     y = torch.empty(rows, d, dtype=ydt, device=dev)
     es = lambda t: t.element_size()
     for q in (False, True):
-        fn = lambda: ops.ln_fwd(x16, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, 0.1, 7, y16=y16, pos16=pos if q else None, q16=q16 if q else None)
+        r16 = y16.clone() if rdt == torch.float16 else None                # (split stream: bf16 head + fp16 remainder)
+        fn = lambda: ops.ln_fwd(x16, res, gamma, beta, y, z, mean, rstd, rows, d, 1e-5, 0.1, 7, y16=y16, pos16=pos if q else None, q16=q16 if q else None, res16=r16)
         us = timeit(fn)
-        nbytes = rows * d * (2 + es(res) + es(y) + 2 + 2 + (4 if q else 0))
+        nbytes = rows * d * (2 + es(res) + (2 if r16 is not None else 0) + es(y) + 2 + 2 + (4 if q else 0))
         print(f"ln_fwd res {str(rdt)[6:]:8s} y {str(ydt)[6:]:8s} q16 {int(q)}: {us:7.1f} us  {nbytes / us / 1e3:7.0f} GB/s")
 
 zb = torch.randn(rows, d, generator=g).to(torch.bfloat16).to(dev)

@@ -830,33 +830,43 @@ def test_zero_fill_sizes_and_alignments(ops):
         assert bool((buf[:off] == 7).all()) and bool((buf[off + words:] == 7).all())
 
 
-def test_layernorm_fp16_stream(ops):
-    """The encoder's residual stream stored as IEEE fp16 between its LayerNorms (poet_ln_fwd: dtype_r / dtype_y = POET_F16 behind an
-    fp16 branch): every combination of (res, y) storage equals the fp32-stream launch on the same values -- y rounded once to fp16,
-    the bf16 operand copy, the next layer's query copy, the saved sum and the statistics BIT FOR BIT."""
+def test_layernorm_split_stream(ops):
+    """The encoder's residual stream between its LayerNorms as bf16 head + IEEE fp16 remainder (poet_ln_fwd: dtype_r / dtype_y =
+    POET_F16 behind an fp16 branch; the head is the operand copy y_bf16 / res_bf16).  Output: head + remainder reproduces the fp32
+    stream to 2^-19 relative, head, query copy, saved sum and statistics are BIT-identical to the fp32-stream launch; input: a split
+    res gives the outputs of the fp32 launch on float(head) + float(remainder) bit for bit."""
     rows, d = 4096 + 5, 256
     x16 = _rand(rows, d, seed=170, scale=3.0).to(torch.float16)
-    res16 = _rand(rows, d, seed=171).to(torch.float16)
+    res32 = _rand(rows, d, seed=171, scale=2.0)
+    res_hi = res32.to(torch.bfloat16)
+    res_lo = (res32 - res_hi.float()).to(torch.float16)
+    res_pair = res_hi.float() + res_lo.float()
+    assert (res_pair - res32).abs().max().item() <= 2.0 ** -19 * res32.abs().max().item()
     gamma, beta = 1.0 + 0.1 * _rand(d, seed=172), 0.1 * _rand(d, seed=173)
     pos = _rand(rows, d, seed=174).to(torch.bfloat16)
 
-    def run(res, ydt, drop):
+    def run(res, res16, ydt, drop):
         y = torch.empty(rows, d, dtype=ydt, device="cuda")
         z = torch.empty(rows, d, dtype=torch.bfloat16, device="cuda")
         y16, q16 = torch.empty_like(z), torch.empty_like(z)
         mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
-        ops.ln_fwd(dev(x16), dev(res), dev(gamma), dev(beta), y, z, mean, rstd, rows, d, 1e-5, drop, 4321, y16=y16, pos16=dev(pos), q16=q16)
+        ops.ln_fwd(dev(x16), dev(res), dev(gamma), dev(beta), y, z, mean, rstd, rows, d, 1e-5, drop, 4321, y16=y16, pos16=dev(pos), q16=q16,
+                   res16=None if res16 is None else dev(res16))
         return y, z, y16, q16, mean, rstd
 
     for drop in (0.0, 0.1):
-        base = run(res16.float(), torch.float32, drop)
-        for res, ydt in ((res16, torch.float16), (res16, torch.float32), (res16.float(), torch.float16)):
-            got = run(res, ydt, drop)
-            assert torch.equal(got[0].float(), base[0].to(ydt).float())
-            for a, b in zip(got[1:], base[1:]):
-                assert torch.equal(a, b)
-    ref = F.layer_norm(x16.float() + res16.float(), (d,), gamma, beta, 1e-5)
-    assert (run(res16, torch.float16, 0.0)[0].float().cpu() - ref).abs().max().item() < 4e-3
+        base = run(res_pair, None, torch.float32, drop)
+        for res, r16, ydt in ((res_lo, res_hi, torch.float16), (res_lo, res_hi, torch.float32), (res_pair, None, torch.float16)):
+            got = run(res, r16, ydt, drop)
+            for a_, b_ in zip(got[1:], base[1:]):
+                assert torch.equal(a_, b_)
+            if ydt == torch.float32:
+                assert torch.equal(got[0], base[0])
+            else:
+                back = got[2].float() + got[0].float()
+                assert (back - base[0]).abs().max().item() <= 2.0 ** -19 * base[0].abs().max().item()
+    with pytest.raises(Exception):                                      # a split input without its head is refused
+        run(res_lo, None, torch.float32, 0.0)
 
 
 @pytest.mark.parametrize("shapes,m,dt", [([(12, 16), (6, 8), (3, 4)], 4, torch.float32), ([(30, 40), (15, 20), (8, 10), (4, 5)], 2, torch.bfloat16),
