@@ -68,8 +68,9 @@ def enc_bucket_tag(n_layers: int, i: int) -> str:
     return f"2_encoder_{n_layers - 1 - i:02d}"
 
 
-_FSTREAM = {}        # (id(cfg), layer index) -> fp16 remainder of that encoder layer's input stream, left by the forward of the layer below
-_GSTREAM = {}        # (id(cfg), layer index) -> bf16 d(output) of that encoder layer, left by the backward of the layer above
+# The side channels of the encoder's streams live in the cfg dict all layers of ONE forward share (encoder_forward makes it):
+#   cfg["_fstream"][i]: fp16 remainder of layer i's input stream, left by the forward of layer i - 1 (POET_FSTREAM_SPLIT=1);
+#   cfg["_gstream"][i]: bf16 d(output) of layer i, left by the backward of layer i + 1.
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -86,13 +87,13 @@ class EncoderLayerFn(torch.autograd.Function):
         # The split residual stream (blocks.proj_ln_fwd: bf16 head = x16, fp16 remainder) travels from layer to layer beside autograd,
         # like the bf16 gradient stream in backward: autograd sees an unwritten fp32 placeholder of the stream's shape (graph
         # connectivity only), the next layer picks the remainder rows up here.  The last layer writes fp32 (`memory`).
-        x_real = _FSTREAM.pop((id(cfg), idx), None)
+        x_real = cfg.get("_fstream", {}).pop(idx, None)
         out = B.enc_layer_fwd(x if x_real is None else x_real, x16, pos2, P_, ref, S * geom.L * 2, mask, geom, N, cfg["M"], cfg["P"], cfg["p"],
                               cfg["training"], cfg.get("act"), cfg.get("split", False), q_in=q_in, emit_q=emit, ffn_act=cfg.get("ffn_act", "relu"),
                               stream_out16=emit)
         y, y16, sv = out[:3]
         if y.dtype == torch.float16:
-            _FSTREAM[(id(cfg), idx + 1)] = y
+            cfg.setdefault("_fstream", {})[idx + 1] = y
             y = torch.empty(y.shape, dtype=torch.float32, device=y.device)            # placeholder: never written, never read
         q_next = out[3] if emit and out[3] is not None else x.new_empty(0)
         ctx.saved, ctx.geom, ctx.cfg, ctx.idx, ctx.names, ctx.params = sv, geom, cfg, idx, names, params
@@ -116,14 +117,14 @@ class EncoderLayerFn(torch.autograd.Function):
         # The bf16 gradient stream (blocks.enc_layer_bwd) is handed from layer to layer beside autograd: the layer above left its
         # d(input) here and gave autograd an unwritten fp32 placeholder of the same shape (autograd would cast a bf16 gradient of an
         # fp32 tensor back to fp32: a 156 MB pass per layer).  Layer 0 converts once for the input projection.
-        dy_real = _GSTREAM.pop((id(cfg), i), None)
+        dy_real = cfg.get("_gstream", {}).pop(i, None)
         if dy_real is None:
             dy_real = dy.contiguous()
         dx = B.enc_layer_bwd(dy_real, ctx.saved, _pdict(names, params, ""), G, "", ctx.ref, S * geom.L * 2, ctx.mask, geom,
                              N, cfg["M"], cfg["P"], g_level, dpos=dpos, out_f32=(i == 0 or not ctx.need_x))
         if dx.dtype != torch.float32:
             if i > 0 and ctx.need_x:
-                _GSTREAM[(id(cfg), i - 1)] = dx
+                cfg.setdefault("_gstream", {})[i - 1] = dx
                 dx = torch.empty(dx.shape, dtype=torch.float32, device=dx.device)        # placeholder: never written, never read
             else:
                 dx32 = torch.empty(dx.shape, dtype=torch.float32, device=dx.device)
