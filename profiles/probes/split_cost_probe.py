@@ -1,0 +1,45 @@
+"""What does the second MFMA of the split-bf16 forward products cost today?  The encoder's five forward Linears at 102 080 rows, split
+weights (fp32 master, bf16 hi + lo: the policy) against ONE bf16 product per fragment (`bf16_nosplit`) -- the matrix work an fp16-weight
+form (single IEEE fp16 weight image, the bf16 activations converted to fp16 in registers: exact) would have.
+    python profiles/probes/split_cost_probe.py [rows]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from poet_amd import ops
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 102080
+dev = "cuda"
+g = torch.Generator().manual_seed(0)
+
+
+def timeit(fn, reps=5, n=20):
+    for _ in range(3):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / n)
+    return sorted(ts)[len(ts) // 2]
+
+
+for name, K, N, odt, kw in (("value / output proj (fp16 out)", 256, 256, torch.float16, {}),
+                            ("offsets | logits (fp16 out)", 256, 768, torch.float16, {}),
+                            ("FFN1 (bf16 out, relu + dropout)", 256, 1024, torch.bfloat16, dict(act=1, drop_p=0.1, seed=3)),
+                            ("FFN2 (fp16 out, K = 1024)", 1024, 256, torch.float16, {})):
+    x = torch.randn(rows, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    w16 = w.to(torch.bfloat16)
+    wlo = (w - w16.float()).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(dev)
+    out = torch.empty(rows, N, dtype=odt, device=dev)
+    if K == 1024:
+        t_split = timeit(lambda: ops.linear_fwd(x, w16, b, out, W_lo=wlo))
+        t_one = timeit(lambda: ops.linear_fwd(x, w16, b, out))
+    else:
+        t_split = timeit(lambda: ops.linear_fwd(x, w, b, out, split=True, **kw))
+        t_one = timeit(lambda: ops.linear_fwd(x, w16, b, out, **kw))
+    print(f"{name:36s} split {t_split:7.1f} us   one product {t_one:7.1f} us   ({t_split - t_one:+.1f})")

@@ -178,6 +178,31 @@ def main():
             FL.clear(); FL[k] = True; FL["split_w"] = False
             measure("only " + k)
         return
+    if os.environ.get("W16TEST"):
+        # (round 6) what would ONE fp16 product per fragment cost in parity?  A = today's policy (split-bf16 weights, fp16 offsets | logits /
+        # value maps / LayerNorm branch operands); B = the encoder's forward weights as single IEEE fp16 values (the bf16 activation
+        # operands convert to fp16 exactly, so an f16 MFMA would take them as they are stored); C = B with the activation operands
+        # stored in fp16 as well.  `tmp1` / `tmp2`: the projection outputs the LayerNorms read.
+        f16_today = ("off", "logit", "V", "tmp1", "tmp2")
+        encw = ("Wv", "Woa", "Wo", "W1", "W2")
+        pols = {"A today (split weights)": (f16_today, ()),
+                "B encoder weights single fp16": (f16_today + encw, ()),
+                "C B + activation operands fp16": (f16_today + encw + ("src16", "x16", "q", "Hd", "out_m"), ())}
+        for rep in range(int(os.environ.get("REPS", "3"))):
+            if rep:
+                g = torch.Generator().manual_seed(rep)
+                for f in feats:
+                    f.mul_(1 + 3e-7 * torch.randn(f.shape, generator=g))
+                FL.clear()
+                t_ref, r_ref = run(model, samples, targets)
+                mem_ref = cap["mem"]
+            for tag, (f16s, exact) in pols.items():
+                FL.clear()
+                for k in ALL: FL[k] = k not in exact
+                for k in f16s: FL[k] = "f16"
+                FL["split_w"] = True
+                measure(f"rep{rep} {tag}")
+        return
     if os.environ.get("W2TEST"):
         for rep in range(3):
             if rep:
