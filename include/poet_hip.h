@@ -121,7 +121,11 @@ typedef struct PoetGemmDesc {
                               v_mfma_f32_16x16x32_bf16 per fragment pair, so the WEIGHT enters with 16 mantissa bits while
                               the activation operand stays plain bf16 (needs b_dtype f32, compute bf16, b_kmajor 0).  Weight
                               rounding is the same perturbation for every token and does not average out downstream the way
-                              per-token activation rounding does: DESIGN.md section 3. */
+                              per-token activation rounding does: DESIGN.md section 3.
+                              2 (experimental, round 6; K = 256, >= 4096 rows, 2-byte C): ONE image of the fp32 weight rounded to
+                              IEEE fp16 (2^-12) and one v_mfma_f32_16x16x32_f16 per fragment pair, the bf16 activation fragments
+                              converted to fp16 in registers (exact; magnitudes past 65504 saturate).  Kernels without this form
+                              treat 2 as 1. */
     int32_t c_f16;         /* 1 with c_dtype = POET_BF16: the 2-byte outputs are written as IEEE fp16 instead of bfloat16 (plain or
                               head-major stores; no add_src / gate_ref).  Was reserved0 (= 0) up to ABI version 2. */
     void* workspace;       /* optional scratch owned by the caller (16-byte aligned); used by the weight-gradient form to merge its

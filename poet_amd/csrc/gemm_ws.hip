@@ -83,8 +83,25 @@ template <> struct run8<float> {
 // SPLIT (PoetGemmDesc.b_split): W arrives as the fp32 master and lives in LDS as TWO bf16 images, hi = bf16(W) and
 // lo = bf16(W - hi); every activation fragment meets both (two MFMAs), so the weight carries 16 mantissa bits at no extra HBM
 // traffic -- the matrix pipe of these HBM-bound kernels is ~25 % busy without it.
-template <typename TC, int KIND, bool WKM, int FM, int NTH, bool SPLIT = false, int BN = 128>
+// WM = 2 (PoetGemmDesc.b_split = 2, round 6, experimental): ONE image of the fp32 master rounded to IEEE fp16 (2^-12: the emulated policy
+// loses 1 % against the split, tests/tools/prec_ablate.py W16TEST) and ONE v_mfma_f32_16x16x32_f16 per fragment pair; the bf16 activation
+// fragment converts to fp16 in registers -- exactly, 8 -> 11 mantissa bits (v_cvt_pkrtz: magnitudes past 65504 saturate) -- 12 VALU
+// per 16-byte fragment against the 8 matrix instructions it then feeds.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 f16x2r_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8_t bf8_to_f16x8(const uint4 v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)));
+    return __builtin_bit_cast(f16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
+}
+
+template <typename TC, int KIND, bool WKM, int FM, int NTH, int WM = 0, int BN = 128>
 __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(const GemmK p) {
+    constexpr bool SPLIT = WM == 1, F16W = WM == 2;
+    static_assert(!F16W || !WKM, "fp16 weights are a forward ([N,K] weight) feature");
     constexpr int KS = 8, NWV = NTH / 64;
     constexpr int K = KS * 32, PITCH = K * 2, FNT = BN / 16, NQ = BN / 64, NV = run8<TC>::NV;
     constexpr int LO = SPLIT ? BN * PITCH : 0;                           // byte offset of the lo image
@@ -143,6 +160,24 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
                                             pack_bf2(wv[i].z - __uint_as_float(hi.y << 16), wv[i].w - __uint_as_float(hi.y & 0xffff0000u)));
                 *reinterpret_cast<uint2*>(smem + ws_sw<PITCH>(rho, kc * 8)) = hi;
                 *reinterpret_cast<uint2*>(smem + LO + ws_sw<PITCH>(rho, kc * 8)) = lo;
+            }
+        }
+    } else if constexpr (F16W) {                                        // fp32 W[n][k] -> one IEEE fp16 image
+        const float* Bf = reinterpret_cast<const float*>(d.B);
+        constexpr int CPR = K / 4, NCH = BN * CPR, GRP = 8;
+        static_assert(NCH % (NTH * GRP) == 0, "fp16 W staging");
+#pragma unroll 1
+        for (int base = 0; base < NCH; base += NTH * GRP) {
+            float4 wv[GRP];
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                wv[i] = *reinterpret_cast<const float4*>(Bf + (int64_t)(n0 + ws_perm(rho)) * d.ldb + kc * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int idx = base + tid + i * NTH, rho = idx / CPR, kc = idx - rho * CPR;
+                *reinterpret_cast<uint2*>(smem + ws_sw<PITCH>(rho, kc * 8)) = make_uint2(pack_h2(wv[i].x, wv[i].y), pack_h2(wv[i].z, wv[i].w));
             }
         }
     } else if constexpr (!WKM) {                                        // W[n][k], k contiguous
@@ -231,6 +266,17 @@ __global__ __launch_bounds__(NTH, (NTH >= 1024 ? 4 : 2)) void gemm_ws_kernel(con
         for (int fm = 0; fm < FM; ++fm) qn[fm] = A + (int64_t)arow(un, fm) * d.lda + g * 8;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
+            if constexpr (F16W) {
+                f16x8_t ah[FM];
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) ah[fm] = bf8_to_f16x8(a[fm][kk]);
+#pragma unroll
+                for (int jn = 0; jn < FNT; ++jn) {
+                    const f16x8_t wf = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(wl[kk & 3] + jn * 16 * PITCH + (kk >> 2) * 256));
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) acc[fm][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, ah[fm], acc[fm][jn], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int jn = 0; jn < FNT; ++jn) {
                 const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wl[kk & 3] + jn * 16 * PITCH + (kk >> 2) * 256));
@@ -798,10 +844,10 @@ bool wsk_kind(const GemmK& p, hipStream_t st) {
     }
 }
 
-template <typename TC, int KIND, bool WKM, int FM, int NTH, bool SPLIT = false, int BN = 128>
+template <typename TC, int KIND, bool WKM, int FM, int NTH, int WM = 0, int BN = 128>
 void ws_launch_cfg(const GemmK& p, int nblocks, hipStream_t st) {
-    constexpr int LDS = (SPLIT ? 2 : 1) * BN * (8 * 64) + BN * 4;
-    auto kern = gemm_ws_kernel<TC, KIND, WKM, FM, NTH, SPLIT, BN>;
+    constexpr int LDS = (WM == 1 ? 2 : 1) * BN * (8 * 64) + BN * 4;
+    auto kern = gemm_ws_kernel<TC, KIND, WKM, FM, NTH, WM, BN>;
     static unsigned long long attr_done = 0;          // per instantiation and device
     lds_attr_once(reinterpret_cast<const void*>(kern), LDS, attr_done);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTH), LDS, st, p);
@@ -840,8 +886,8 @@ template <typename TC, int KIND>
 bool ws_launch_split(const GemmK& p, hipStream_t st) {
     static const int narrow = [] { const char* e = getenv("POET_WS_SPLIT_NARROW"); return e ? atoi(e) : 2; }();
     if (p.d.N <= 256) {
-        if (narrow == 2) ws_launch_cfg<TC, KIND, false, 1, 512, true, 128>(p, ws_blocks(p.d.N, 128, 1), st);
-        else ws_launch_cfg<TC, KIND, false, 1, 512, true, 64>(p, ws_blocks(p.d.N, 64, 2), st);
+        if (narrow == 2) ws_launch_cfg<TC, KIND, false, 1, 512, 1, 128>(p, ws_blocks(p.d.N, 128, 1), st);
+        else ws_launch_cfg<TC, KIND, false, 1, 512, 1, 64>(p, ws_blocks(p.d.N, 64, 2), st);
         return true;
     }
     if constexpr (sizeof(TC) == 4 && (KIND & (WS_ADD | WS_GATE))) return false;
@@ -866,9 +912,17 @@ bool ws_launch_split(const GemmK& p, hipStream_t st) {
                 return true;
             }
         }
-        ws_launch_cfg<TC, KIND, false, 2, 512, true, 128>(p, ws_blocks(p.d.N, 128, 1), st);
+        ws_launch_cfg<TC, KIND, false, 2, 512, 1, 128>(p, ws_blocks(p.d.N, 128, 1), st);
         return true;
     }
+}
+
+// single fp16 weight image (b_split = 2): the LDS footprint and the shapes of the single-image bf16 form
+template <typename TC, int KIND>
+bool ws_launch_w16(const GemmK& p, int nblocks, hipStream_t st) {
+    if (p.d.N <= 256) ws_launch_cfg<TC, KIND, false, 1, 512, 2, 128>(p, nblocks, st);
+    else ws_launch_cfg<TC, KIND, false, 2, 256, 2, 128>(p, nblocks, st);
+    return true;
 }
 
 // the epilogue kinds that occur on the path: forward {plain, +residual, +row mask}, input gradient {plain, ReLU gate,
@@ -882,10 +936,20 @@ bool ws_kind(const GemmK& p, int nblocks, hipStream_t st) {
         // generic kernel
         // (round 6: + the row-masked head-major form = the encoder's fp16 value maps, split or single-image weights)
         if (d.c_f16) {
+            if (d.b_split == 2) return kind == 0 ? ws_launch_w16<f16_t, 0>(p, nblocks, st) : kind == WS_MASK ? ws_launch_w16<f16_t, WS_MASK>(p, nblocks, st) : false;
             if (d.b_split) return kind == 0 ? ws_launch_split<f16_t, 0>(p, st) : kind == WS_MASK ? ws_launch_split<f16_t, WS_MASK>(p, st) : false;
             if (d.b_kmajor) return false;
             return kind == 0 ? ws_launch<f16_t, 0, false>(p, nblocks, st) : kind == WS_MASK ? ws_launch<f16_t, WS_MASK, false>(p, nblocks, st) : false;
         }
+    }
+    if (d.b_split == 2) {
+        if constexpr (sizeof(TC) == 2) {
+            switch (kind) {
+                case 0: return ws_launch_w16<TC, 0>(p, nblocks, st);
+                case WS_MASK: return ws_launch_w16<TC, WS_MASK>(p, nblocks, st);
+                default: return false;
+            }
+        } else return false;
     }
     if (d.b_split) {
         switch (kind) {
@@ -945,6 +1009,7 @@ bool gemm_ws_try(const GemmK& p, hipStream_t st) {
     if (d.N % 128 != 0 || d.M < 4096) return false;
     if (!p.a_vec || !p.b_vec || !p.c_vec) return false;
     if (d.out_mode == 1 && d.hm_D % 8 != 0) return false;
+    if (d.K != 256 && d.b_split == 2) return false;                     // (the fp16-weight form exists at K = 256 only)
     if (d.K != 256) {                                                   // K = 512 / 768 / 1024 ...: the K-chunked kernel
         static const int no_wsk = [] { const char* e = getenv("POET_GEMM_NO_WSK"); return e && atoi(e) ? 1 : 0; }();
         // (single-weight forms are still faster on the tiled kernel: the W chunk restaging of a one-workgroup-per-CU kernel is

@@ -271,6 +271,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, M: int, N: int, K
     return Cout
 
 
+_W16 = os.environ.get("POET_W16", "0") not in ("", "0")
+
+
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, *, act=0,
                drop_p=0.0, seed=0, row_mask=None, add_src=None, head_major=None, ldc=None, ldx=None, split=False, W_lo=None):
     """out[rows, N] = act(x[rows, K] @ W[N, K]^T + b).  x / out may be column slices (ldx / ldc).
@@ -278,9 +281,13 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], out:
     bf16 images the optimiser maintains (PoetGemmDesc.B_lo: the long-K kernel, one pass over x)."""
     rows = x.numel() // x.shape[-1] if ldx is None else x.shape[0]
     N, K = W.shape
+    bs = split or W_lo is not None
+    if (_W16 and split and W_lo is None and K == 256 and rows >= 4096 and N % 128 == 0 and x.dtype == torch.bfloat16 and add_src is None
+            and out.dtype in (torch.bfloat16, torch.float16)):
+        bs = 2          # (experimental, POET_W16=1) one IEEE fp16 image of the master, one f16 MFMA per fragment pair: gemm_ws.hip WM = 2
     return gemm(x, W, out, rows, N, K, lda=ldx or K, ldb=K, ldc=ldc or N, bias=b, act=act, drop_p=drop_p, seed=seed,
                 row_mask=row_mask, add_src=add_src, ld_add=(ldc or N), head_major=head_major,
-                b_split=split or W_lo is not None, B_lo=W_lo, compute=BF16 if (split or W_lo is not None) else None)
+                b_split=bs, B_lo=W_lo, compute=BF16 if (split or W_lo is not None) else None)
 
 
 def linear_dx(dy: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, rows: int, ldy=None, add_src=None,

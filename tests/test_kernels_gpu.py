@@ -821,6 +821,44 @@ def test_layernorm_fp16_branch(ops, rows):
     assert torch.equal(outs[0][2].cpu(), outs[0][0].cpu().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("N,act,dp,f16out,rows", [(256, 0, 0.0, True, 4096 + 37), (768, 0, 0.0, True, 8192), (1024, 1, 0.0, False, 5000), (1024, 1, 0.1, False, 4096),
+                                                  (256, 0, 0.0, False, 4100)])
+def test_gemm_fp16_weight_form(ops, N, act, dp, f16out, rows):
+    """PoetGemmDesc.b_split = 2 (experimental, POET_W16=1): the fp32 master as ONE IEEE fp16 image, one f16 MFMA per fragment pair, the
+    bf16 activation fragments converted to fp16 in registers.  Against fp64 on (bf16 x, fp16-rounded W): within one rounding of the
+    2-byte output; the dropout mask equals the split form's; rows past the end untouched; and the WEIGHT error against the fp32
+    master is 8x below a single bf16 image's."""
+    x = _rand(rows, 256, seed=500 + N).to(torch.bfloat16)
+    w = _rand(N, 256, seed=501, scale=1 / 16)
+    b = _rand(N, seed=502)
+    odt = torch.float16 if f16out else torch.bfloat16
+    outs = {}
+    for mode in (True, False):
+        ops._W16 = mode
+        try:
+            buf = torch.full((rows + 3, N), 7.0, dtype=odt, device="cuda")
+            ops.linear_fwd(dev(x), dev(w), dev(b), buf[:rows], split=True, act=act, drop_p=dp, seed=99)
+        finally:
+            ops._W16 = False
+        assert bool((buf[rows:] == 7.0).all())
+        outs[mode] = buf[:rows].float().cpu()
+    ref = x.double() @ w.to(torch.float16).double().t() + b.double()
+    if act:
+        ref = ref.clamp_min(0)
+    keep = torch.ones_like(ref, dtype=torch.bool)
+    if dp > 0:
+        keep = (outs[False] != 0) | (ref.float() <= 1e-3)               # the split form's mask (the counter is a function of seed, row, column)
+        assert bool(((outs[True] != 0) | (ref.float() <= 1e-3) == keep).all())
+        ref = torch.where(outs[False] != 0, ref / (1 - dp), torch.zeros_like(ref))
+    ulp = 2.0 ** (-10 if f16out else -7)
+    err = (outs[True].double() - ref).abs()
+    assert float(err.max()) <= ulp * float(ref.abs().max()) + 1e-5, float(err.max())
+    exact = x.double() @ w.double().t() + b.double()                     # weight rounding only (no output rounding): fp16 against bf16 images
+    e16 = ((x.double() @ w.to(torch.float16).double().t() + b.double()) - exact).abs().max()
+    eb = ((x.double() @ w.to(torch.bfloat16).double().t() + b.double()) - exact).abs().max()
+    assert float(e16) < float(eb) / 4
+
+
 def test_zero_fill_sizes_and_alignments(ops):
     """poet_zero: whole 16 KB blocks, ragged tails, bases that are only 4-byte aligned; nothing written outside [base, base + bytes)."""
     for words, off in [(4096 * 3, 0), (4096 * 3 + 17, 0), (5, 0), (4096 * 2 + 1, 1), (4096 + 4095, 3), (70000, 2)]:
