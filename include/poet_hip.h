@@ -314,6 +314,9 @@ int poet_add(const void* a, const void* b, void* out, int64_t n, int dtype_a, in
 int poet_add_rowvec(void* x, const float* vec, int batch, int64_t batch_stride_rows, int64_t row0, int64_t rows,
                     int cols, int dtype, void* stream);
 int poet_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* (ABI v6) a_bf16 = bf16(a), sum_bf16 = bf16(a + b): the operand copy of the fp32 stream and the first encoder layer's query operand
+ * `src + pos` (deformable_transformer.py:201) in one pass; a fp32, b bf16. */
+int poet_add_cast(const float* a, const void* b_bf16, void* sum_bf16, void* a_bf16, int64_t n, void* stream);
 /* (ABI v6) y = dropout(gelu(x)) and dx = dy * mask / (1 - p) * gelu'(x), element-wise, erf form (F.gelu): the FFN with
  * `activation="gelu"` (deformable_transformer.py:347-355,193-197,269-273).  dtype (y, dy, dx): POET_F32 or POET_BF16; dtype_x (the
  * kept pre-activation): = dtype, or POET_F32 under bf16 storage (the Linear's accumulators handed over unrounded).  The dropout mask

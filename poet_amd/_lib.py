@@ -59,6 +59,7 @@ _PROTOS = {
     "poet_enc_ref_points": ([vp, pi64, vp, i32, i32, i32, vp], i32),
     "poet_add": ([vp, vp, vp, i64, i32, i32, i32, vp], i32),
     "poet_cast": ([vp, vp, i64, i32, i32, vp], i32),
+    "poet_add_cast": ([vp, vp, vp, vp, i64, vp], i32),
     "poet_gelu_fwd": ([vp, vp, i64, i32, i32, f32, u32, vp, vp], i32),
     "poet_gelu_bwd": ([vp, vp, vp, i64, i32, i32, f32, u32, vp, vp], i32),
     "poet_zero": ([vp, i64, vp], i32),

@@ -54,6 +54,28 @@ __global__ __launch_bounds__(256) void gelu_kernel(const TXI* __restrict__ x, co
     }
 }
 
+// the head of the encoder in the bf16 policy: the stream's operand copy x16 = bf16(x) and the first layer's query operand
+// q = bf16(x + pos) in ONE pass over the fp32 stream (was a cast and an add: the 104 MB stream read twice); same arithmetic, bit for bit
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ sum,
+                                                       bf16_t* __restrict__ a16, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        float x[8], y[8];
+        vec<float, 8>::ld(a + i, x);
+        vec<bf16_t, 8>::ld(b + i, y);
+        vec<bf16_t, 8>::st(a16 + i, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        vec<bf16_t, 8>::st(sum + i, x);
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            const float v = a[j];
+            io<bf16_t>::st(a16 + j, v);
+            io<bf16_t>::st(sum + j, v + io<bf16_t>::ld(b + j));
+        }
+    }
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
@@ -829,6 +851,15 @@ extern "C" int poet_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n,
     if (dtype == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, float, true>), grid, block, 0, ST, (const float*)x, (const float*)dy, (float*)dx, n, th, ds, seed, seed_dev);
     else if (dtype_x == POET_F32) hipLaunchKernelGGL((gelu_kernel<float, bf16_t, true>), grid, block, 0, ST, (const float*)x, (const bf16_t*)dy, (bf16_t*)dx, n, th, ds, seed, seed_dev);
     else hipLaunchKernelGGL((gelu_kernel<bf16_t, bf16_t, true>), grid, block, 0, ST, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, th, ds, seed, seed_dev);
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
+extern "C" int poet_add_cast(const float* a, const void* b_bf16, void* sum_bf16, void* a_bf16, int64_t n, void* stream) {
+    POET_CHECK(a && b_bf16 && sum_bf16 && a_bf16 && n > 0, POET_ERR_ARG, "add_cast: bad args");
+    POET_CHECK(((reinterpret_cast<uintptr_t>(a) & 31) | (reinterpret_cast<uintptr_t>(b_bf16) & 15) | (reinterpret_cast<uintptr_t>(sum_bf16) & 15) |
+                (reinterpret_cast<uintptr_t>(a_bf16) & 15)) == 0, POET_ERR_ARG, "add_cast: operands must be 16-byte (fp32: 32-byte) aligned");
+    hipLaunchKernelGGL(add_cast_kernel, dim3(cdiv(n, 2048)), dim3(256), 0, ST, a, (const bf16_t*)b_bf16, (bf16_t*)sum_bf16, (bf16_t*)a_bf16, n);
     POET_LAUNCH_CHECK();
     return POET_OK;
 }

@@ -140,21 +140,30 @@ class EncoderLayerFn(torch.autograd.Function):
         return (dx if ctx.need_x else None, None, None, dpos, G.ret[-1], None, None, None, None, None, None, *G.ret[:-1])
 
 
+_ADD_CAST = __import__("os").environ.get("POET_NO_ADD_CAST", "0") in ("", "0")       # (A/B aid, read at import)
+
+
 def encoder_forward(src, pos, level_embed, ref, mask, geom, cfg, layers_named):
     """src (N,S,d) residual-stream dtype; pos (N,S,d).  layers_named: per layer (names, params).  Returns (memory, memory16,
     per-layer stream tensors [input, out_0, ..., out_{n-1}]) -- the handles the graphed trainer segments backward at."""
     N, S, d = src.shape
     x = src.reshape(N * S, d)
     act = cfg.get("act") or src.dtype
+    pos2 = pos.reshape(N * S, d)
+    q = None
     if act != x.dtype:
         x16 = torch.empty((N * S, d), dtype=act, device=src.device)
-        ops.cast(x.detach(), x16)
+        if (_ADD_CAST and x.dtype == torch.float32 and act == torch.bfloat16 and pos2.dtype == torch.bfloat16 and pos2.is_contiguous() and not pos2.requires_grad
+                and x.is_contiguous() and x.data_ptr() % 32 == 0 and pos2.data_ptr() % 16 == 0):
+            # the operand copy of the stream and the first layer's `src + pos` in one pass over the fp32 stream
+            q = torch.empty((N * S, d), dtype=act, device=src.device)
+            ops.add_cast(x.detach(), pos2, q, x16)
+        else:
+            ops.cast(x.detach(), x16)
     else:
         x16 = x.detach()
-    pos2 = pos.reshape(N * S, d)
     cfg = dict(cfg, N=N)
     outs = [x]
-    q = None
     for i, (names, params) in enumerate(layers_named):
         x, x16, q = EncoderLayerFn.apply(x, x16, q, pos2, level_embed, ref, mask, geom, cfg, i, names, *params)
         if q.numel() == 0:

@@ -601,6 +601,13 @@ def gelu_bwd(dy, x, dx, drop_p=0.0, seed=0):
     return dx
 
 
+def add_cast(a, b16, sum16, a16):
+    """a16 = bf16(a), sum16 = bf16(a + b16) in one pass (a fp32; the rest bf16, contiguous)."""
+    lib = _lib.load()
+    _lib.check(lib.poet_add_cast(_req(a, "a").data_ptr(), b16.data_ptr(), sum16.data_ptr(), a16.data_ptr(), a.numel(), _stream()), "poet_add_cast")
+    return sum16, a16
+
+
 def cast(src, dst):
     lib = _lib.load()
     _lib.check(lib.poet_cast(_req(src, "src").data_ptr(), dst.data_ptr(), src.numel(), dcode(src), dcode(dst), _stream()), "poet_cast")

@@ -859,6 +859,21 @@ def test_gemm_fp16_weight_form(ops, N, act, dp, f16out, rows):
     assert float(e16) < float(eb) / 4
 
 
+def test_add_cast_equals_cast_and_add(ops):
+    """poet_add_cast (the encoder's head: operand copy of the fp32 stream + the first layer's `src + pos` in one pass) == poet_cast and
+    poet_add, bit for bit; ragged tail."""
+    n = 37 * 2048 + 24 + 5
+    a = _rand(n + 3, seed=600, scale=3.0)[:n].contiguous()
+    b = _rand(n, seed=601).to(torch.bfloat16)
+    ad, bd = dev(a), dev(b)
+    a16, s16 = torch.empty(n, dtype=torch.bfloat16, device="cuda"), torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    ops.add_cast(ad, bd, s16, a16)
+    ra, rs = torch.empty_like(a16), torch.empty_like(s16)
+    ops.cast(ad, ra)
+    ops.add(ad, bd, rs)
+    assert torch.equal(a16, ra) and torch.equal(s16, rs)
+
+
 def test_zero_fill_sizes_and_alignments(ops):
     """poet_zero: whole 16 KB blocks, ragged tails, bases that are only 4-byte aligned; nothing written outside [base, base + bytes)."""
     for words, off in [(4096 * 3, 0), (4096 * 3 + 17, 0), (5, 0), (4096 * 2 + 1, 1), (4096 + 4095, 3), (70000, 2)]:
