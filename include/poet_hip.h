@@ -370,6 +370,8 @@ int poet_groupnorm_fwd(const void* x, const float* gamma, const float* beta, voi
                        float* scratch, int64_t scratch_floats /* optional caller-owned scratch (contents undefined afterwards):
                            with N * 32 * 64 floats (forward) / N * 32 * 512 floats (backward) and C = 256, G = 32 the
                            whole-row kernels run (two launches, coalesced); without it one workgroup per (image, group) */,
+                       void* x_bf16_copy /* (ABI v6) optional, with an fp32 x: bf16(x) in x's own layout -- the operand copy the backward
+                           reads -- written in the same pass (was a separate poet_cast over the conv output) */,
                        void* stream);
 int poet_groupnorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma,
                        void* dx, float* dgamma, float* dbeta,

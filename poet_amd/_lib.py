@@ -72,7 +72,7 @@ _PROTOS = {
     "poet_tokens_to_nchw": ([vp, vp, i32, i32, i32, i64, i64, i32, i32, vp], i32),
     "poet_im2col3x3s2": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "poet_col2im3x3s2_add": ([vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i32, i32, vp], i32),
-    "poet_groupnorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, i32, vp, i64, vp], i32),
+    "poet_groupnorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, i32, vp, i64, vp, vp], i32),
     "poet_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, vp, i64, vp], i32),
     "poet_pose_finish_fwd": ([vp, vp, vp, vp, vp, i32, i32, vp], i32),
     "poet_pose_finish_bwd": ([vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ beta, TY* __restrict__ y,
                                                      float* __restrict__ stats, int HW, int C, int G,
                                                      int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride,
-                                                     float eps) {
+                                                     float eps, bf16_t* __restrict__ xc16) {
     __shared__ float sm[4];
     int n, g;
     gn_block_to_ng(blockIdx.x, gridDim.x / G, G, n, g);
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* __restrict__ x, co
     const bool vec8 = (cpg == 8);
     const T* xb = x + ((int64_t)n * x_stride + x_off) * C + g * cpg;
     TY* yb = y + ((int64_t)n * y_stride + y_off) * C + g * cpg;
+    bf16_t* cb = xc16 ? xc16 + ((int64_t)n * x_stride + x_off) * C + g * cpg : nullptr;      // bf16 copy of the INPUT, same layout as x
     float s = 0.f, q = 0.f;
     for (int hw = threadIdx.x; hw < HW; hw += 256) {
         float v[GN_MAXCPG];
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* __restrict__ x, co
     for (int hw = threadIdx.x; hw < HW; hw += 256) {
         float v[GN_MAXCPG];
         gn_ld<T>(xb + (int64_t)hw * C, v, cpg, vec8);
+        if (cb) gn_st<bf16_t>(cb + (int64_t)hw * C, v, cpg, vec8);
         for (int c = 0; c < cpg; ++c) v[c] = (v[c] - mu) * rs * gm[c] + bt[c];
         gn_st<TY>(yb + (int64_t)hw * C, v, cpg, vec8);
     }
@@ -507,7 +509,8 @@ __global__ __launch_bounds__(256) void gn_rows_stats_kernel(const T* __restrict_
 template <typename T, typename TY>
 __global__ __launch_bounds__(256) void gn_rows_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             TY* __restrict__ y, float* __restrict__ stats, const float* __restrict__ part,
-                                                            int HW, int nblk, int nsb, int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride, float eps) {
+                                                            int HW, int nblk, int nsb, int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride, float eps,
+                                                            bf16_t* __restrict__ xc16) {
     __shared__ float smu[32], srs[32];
     const int n = blockIdx.x / nblk, blk = blockIdx.x % nblk, g = threadIdx.x & 31, rl = threadIdx.x >> 5;
     if (threadIdx.x < 32) {
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(256) void gn_rows_apply_kernel(const T* __restrict_
     vec<float, 8>::ld(beta + g * 8, bt);
     const T* xb = x + ((int64_t)n * x_stride + x_off) * 256 + g * 8;
     TY* yb = y + ((int64_t)n * y_stride + y_off) * 256 + g * 8;
+    bf16_t* cb = xc16 ? xc16 + ((int64_t)n * x_stride + x_off) * 256 + g * 8 : nullptr;        // bf16 copy of the INPUT (what backward reads), same layout as x
     const int rend = min(HW, (blk + 1) * GN_RB);
     int r = blk * GN_RB + rl;
     for (; r + 24 < rend; r += 32) {                                // 4 rows in flight per thread
@@ -539,6 +543,7 @@ __global__ __launch_bounds__(256) void gn_rows_apply_kernel(const T* __restrict_
         for (int u = 0; u < 4; ++u) vec<T, 8>::ld(xb + (int64_t)(r + 8 * u) * 256, v[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (cb) vec<bf16_t, 8>::st(cb + (int64_t)(r + 8 * u) * 256, v[u]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[u][c] = (v[u][c] - mu) * rs * gm[c] + bt[c];
             vec<TY, 8>::st(yb + (int64_t)(r + 8 * u) * 256, v[u]);
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(256) void gn_rows_apply_kernel(const T* __restrict_
     for (; r < rend; r += 8) {
         float v[8];
         vec<T, 8>::ld(xb + (int64_t)r * 256, v);
+        if (cb) vec<bf16_t, 8>::st(cb + (int64_t)r * 256, v);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = (v[c] - mu) * rs * gm[c] + bt[c];
         vec<TY, 8>::st(yb + (int64_t)r * 256, v);
@@ -748,8 +754,10 @@ extern "C" int poet_ln_bwd(const void* dy, const void* z, const float* mean, con
 
 extern "C" int poet_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int N,
                                   int HW, int C, int G, int64_t x_off, int64_t x_stride, int64_t y_off, int64_t y_stride,
-                                  float eps, int dtype_x, int dtype_y, float* scratch, int64_t scratch_floats, void* stream) {
+                                  float eps, int dtype_x, int dtype_y, float* scratch, int64_t scratch_floats, void* x_bf16_copy, void* stream) {
     POET_CHECK(x && gamma && beta && y && stats, POET_ERR_ARG, "groupnorm_fwd: null pointer");
+    POET_CHECK(!x_bf16_copy || (dtype_x == POET_F32 && (reinterpret_cast<uintptr_t>(x_bf16_copy) & 15) == 0), POET_ERR_ARG,
+               "groupnorm_fwd: x_bf16_copy goes with an fp32 x and a 16-byte aligned buffer");
     POET_CHECK(N > 0 && HW > 0 && G > 0 && C % G == 0 && C / G <= GN_MAXCPG, POET_ERR_ARG, "groupnorm_fwd: bad dims (C/G must be <= 8)");
     hipStream_t st = (hipStream_t)stream;
     {
@@ -760,7 +768,7 @@ extern "C" int poet_groupnorm_fwd(const void* x, const float* gamma, const float
 #define GN_ROWS_FWD(TX, TR)                                                                                                              \
             do {                                                                                                                         \
                 gn_rows_stats_kernel<TX><<<dim3(N * nsb), dim3(256), 0, st>>>((const TX*)x, scratch, HW, nsb, rb, x_off, x_stride);     \
-                gn_rows_apply_kernel<TX, TR><<<dim3(N * nblk), dim3(256), 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, scratch, HW, nblk, nsb, x_off, x_stride, y_off, y_stride, eps); \
+                gn_rows_apply_kernel<TX, TR><<<dim3(N * nblk), dim3(256), 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, scratch, HW, nblk, nsb, x_off, x_stride, y_off, y_stride, eps, (bf16_t*)x_bf16_copy); \
             } while (0)
             POET_DT2(dtype_x, dtype_y, GN_ROWS_FWD);
 #undef GN_ROWS_FWD
@@ -769,7 +777,7 @@ extern "C" int poet_groupnorm_fwd(const void* x, const float* gamma, const float
         }
     }
     dim3 grid(N * G), block(256);
-#define GN_FWD(TX, TR) gn_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, HW, C, G, x_off, x_stride, y_off, y_stride, eps)
+#define GN_FWD(TX, TR) gn_fwd_kernel<TX, TR><<<grid, block, 0, st>>>((const TX*)x, gamma, beta, (TR*)y, stats, HW, C, G, x_off, x_stride, y_off, y_stride, eps, (bf16_t*)x_bf16_copy)
     POET_DT2(dtype_x, dtype_y, GN_FWD);
 #undef GN_FWD
     POET_LAUNCH_CHECK();

@@ -553,8 +553,7 @@ class InputProjFn(torch.autograd.Function):
                         pre32 = torch.empty((N, HW, d), dtype=torch.float32, device=src.device)
                         ops.linear_fwd(f2, torch.cat([W.view(d, C), W.view(d, C)], 1), b, pre32.view(N * HW, d), split=True)
                         stats = torch.empty((N, n_groups, 2), dtype=torch.float32, device=src.device)
-                        ops.groupnorm_fwd(pre32, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S)
-                        ops.cast(pre32, pre)
+                        ops.groupnorm_fwd(pre32, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S, x16=pre)      # (+ the bf16 copy backward reads)
                         saved.append((f2, None, pre, stats))
                         continue
                     f16 = torch.empty((N * HW, C), dtype=torch.bfloat16, device=src.device)
@@ -589,8 +588,7 @@ class InputProjFn(torch.autograd.Function):
                     col = torch.empty((N * HW, C * 9), dtype=torch.bfloat16, device=src.device)     # (backward's operand copy)
                     ops.cast(col32, col)
                     stats = torch.empty((N, n_groups, 2), dtype=torch.float32, device=src.device)
-                    ops.groupnorm_fwd(pre32, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S)
-                    ops.cast(pre32, pre)
+                    ops.groupnorm_fwd(pre32, gw, gb, src, stats, N, HW, d, n_groups, 0, HW, geom.starts[lvl], S, x16=pre)
                     saved.append((None, col, pre, stats))
                     continue
                 col = torch.empty((N * HW, C * 9), dtype=act_dtype, device=src.device)

@@ -491,11 +491,12 @@ def ln_bwd(dy, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, rows, d, drop_p=0.0,
                                seed & 0xFFFFFFFF, dcode(z), dcode(dy), dcode(dz), _seed_dev() if drop_p > 0 else None, _stream()), "poet_ln_bwd")
 
 
-def groupnorm_fwd(x, gamma, beta, y, stats, N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps=1e-5):
+def groupnorm_fwd(x, gamma, beta, y, stats, N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps=1e-5, x16=None):
+    """x16: optional bf16 copy of an fp32 x, same layout, written in the same pass."""
     lib = _lib.load()
     _lib.check(lib.poet_groupnorm_fwd(_req(x, "x").data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                       N, HW, Cc, G, x_off, x_stride, y_off, y_stride, eps, dcode(x), dcode(y),
-                                      _workspace(x.device).data_ptr(), _WORKSPACE_BYTES // 4, _stream()),
+                                      _workspace(x.device).data_ptr(), _WORKSPACE_BYTES // 4, _ptr(x16), _stream()),
                "poet_groupnorm_fwd")
 
 

@@ -414,7 +414,10 @@ def test_groupnorm(ops, dtype):
     beta = 0.1 * _rand(C, seed=32)
     y = torch.zeros(N, S, C, dtype=dtype, device="cuda")
     stats = torch.empty(N, G, 2, device="cuda")
-    ops.groupnorm_fwd(dev(x), dev(gamma), dev(beta), y, stats, N, HW, C, G, 0, HW, off, S)
+    x16 = torch.empty(N, HW, C, dtype=torch.bfloat16, device="cuda") if dtype == torch.float32 else None
+    ops.groupnorm_fwd(dev(x), dev(gamma), dev(beta), y, stats, N, HW, C, G, 0, HW, off, S, x16=x16)
+    if x16 is not None:                                                 # (the bf16 copy of an fp32 input, written in the same pass)
+        assert torch.equal(x16.cpu(), x.to(torch.bfloat16))
     xr = x.float().permute(0, 2, 1).contiguous().requires_grad_()       # (N,C,HW)
     g32, b32 = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
     yr = F.group_norm(xr, G, g32, b32, 1e-5)
@@ -1845,7 +1848,10 @@ def test_groupnorm_whole_row_kernels(ops, xdt, ydt, HW, monkeypatch):
     beta = 0.1 * _rand(C, seed=332)
     y = torch.zeros(N, S, C, dtype=ydt, device="cuda")
     stats = torch.empty(N, G, 2, device="cuda")
-    ops.groupnorm_fwd(dev(x), dev(gamma), dev(beta), y, stats, N, HW, C, G, 0, HW, off, S)
+    x16 = torch.empty(N, HW, C, dtype=torch.bfloat16, device="cuda") if xdt == torch.float32 else None
+    ops.groupnorm_fwd(dev(x), dev(gamma), dev(beta), y, stats, N, HW, C, G, 0, HW, off, S, x16=x16)
+    if x16 is not None:
+        assert torch.equal(x16.cpu(), x.to(torch.bfloat16))
     xr = x.float().permute(0, 2, 1).contiguous().requires_grad_()
     g32, b32 = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
     yr = F.group_norm(xr, G, g32, b32, 1e-5)
