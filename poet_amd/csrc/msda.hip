@@ -299,9 +299,10 @@ __device__ __forceinline__ float dot8(const float (&a)[8], const Raw8<TB>& b) {
 // (query, head), so a lane loads the two rows of ONE x corner; with T = (1-fy) d0 + fy d1 of that corner
 //   d/d(attn) = sum_x wx T,   d/d(px) = aw (T[x1] - T[x0]),   d/d(py) = aw sum_x wx (d1 - d0)
 // are all plain sums over the group's 2*tpg lanes.
+// (bid, nb: the block index / count of THIS part -- the kernel's own, or its share of a combined launch, see msda_bwd_both_kernel)
 template <typename TV, typename TQ, int L, int P, bool FUSED>
-__global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
-    const int64_t t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // same L2 argument as the forward
+__device__ __forceinline__ void msda_bwd_body(const MsdaP& p, int64_t bid, int64_t nb) {
+    const int64_t t = xcd_contiguous_block(bid, nb) * 256 + threadIdx.x;      // same L2 argument as the forward
     if (t >= p.total * 2) return;
     const int g2 = p.groups * 2, gl = 2 * p.tpg;
     const int64_t row = t / g2;
@@ -374,6 +375,8 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) {
         }
     }
 }
+template <typename TV, typename TQ, int L, int P, bool FUSED>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(const MsdaP p) { msda_bwd_body<TV, TQ, L, P, FUSED>(p, blockIdx.x, gridDim.x); }
 
 // ---- shared-geometry gathers: the encoder's shape (M = 16 heads x D = 16, L = 4 levels x P = 4 points, bf16) --------------
 // The general gather kernels above are VALU bound, and half of their VALU time is sample GEOMETRY computed redundantly: the 4
@@ -711,8 +714,8 @@ __device__ __forceinline__ void gv16_add(bf16_t* pc, int c, float v) {
 // floats, so every atomic wave-instruction covers whole contiguous 4*D-byte segments (coalesced into a few L2 atomic
 // requests) instead of 64 scattered dwords.  The softmax / corner arithmetic is recomputed per lane (it is tiny).
 template <typename TQ, int L, int P, bool FUSED>
-__global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void msda_bwd_dv_body(const MsdaP& p, int64_t bid) {
+    const int64_t t = bid * 256 + threadIdx.x;
     if (t >= p.total * 8) return;
     const int64_t rm = t / p.D;
     const int c = (int)(t - rm * p.D);
@@ -749,6 +752,18 @@ __global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) {
             if (cn.w11 != 0.f) add(cn.o11, ag * cn.w11);
         }
     }
+}
+template <typename TQ, int L, int P, bool FUSED>
+__global__ __launch_bounds__(256) void msda_bwd_dv_kernel(const MsdaP p) { msda_bwd_dv_body<TQ, L, P, FUSED>(p, blockIdx.x); }
+
+// The decoder's backward (a few hundred queries: both kernels are latency chains of ~18 us on a handful of workgroups) as ONE launch: the
+// first `nv` workgroups run the value-gradient scatter, the rest d(offsets | logits) -- the two parts are independent, and branches of a
+// replayed graph do not overlap on this stack, so sharing a launch is the only way they run side by side.  Same code, same
+// results.
+template <typename TV, typename TQ, int L, int P, bool FUSED>
+__global__ __launch_bounds__(256) void msda_bwd_both_kernel(const MsdaP p, int nv) {
+    if ((int)blockIdx.x < nv) msda_bwd_dv_body<TQ, L, P, FUSED>(p, blockIdx.x);
+    else msda_bwd_body<TV, TQ, L, P, FUSED>(p, (int64_t)blockIdx.x - nv, (int64_t)gridDim.x - nv);
 }
 
 // d(value) for GRID queries (encoder self-attention: query q IS pixel q of the flattened levels): LDS-privatised
@@ -1447,6 +1462,13 @@ static void launch_p(const MsdaP& p, int P, hipStream_t st) {
         if (!dv_done && p.grid_queries && p.Lq == p.S) dv_done = launch_dv_tiled<TQ, L>(p, P, st);
     }
     if (p.q_f16 && BWD && !dv_done) { g_f16_refused = true; return; }
+    if constexpr (BWD && sizeof(TQ) == 4) {     // fp32 offsets | logits = the decoder's form: the general kernels run both parts -- as one launch
+        static const bool no_both = [] { const char* e = getenv("POET_MSDA_NO_BOTH"); return e && atoi(e); }();       // (A/B aid, read once)
+        if (!dv_done && (p.parts & 1) && P == 4 && !no_both && !p.v_f16 && (int64_t)gridv.x + gridf.x < (1ll << 20)) {
+            hipLaunchKernelGGL((msda_bwd_both_kernel<TV, TQ, L, 4, FUSED>), dim3(gridv.x + gridf.x), block, 0, st, p, (int)gridv.x);
+            return;
+        }
+    }
     if (BWD && !dv_done) {
         if (P == 4) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 4, FUSED>), gridv, block, 0, st, p);
         else if (P == 2) hipLaunchKernelGGL((msda_bwd_dv_kernel<TQ, L, 2, FUSED>), gridv, block, 0, st, p);
