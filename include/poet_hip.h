@@ -173,6 +173,11 @@ int poet_linear_bwd(const void* dy, int64_t ldy, const void* x, int64_t ldx, con
  * the weight / bias gradient of the same nn.Linear of every decoder layer (models/deformable_transformer.py:253-292). */
 int poet_gemm_dw_list(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n,
                       int n_out, int k_in, int rows, int64_t ldy, int64_t ldx, int64_t ldw, void* stream);
+/* (ABI v6) the same for n_lists <= 8 such lists of DIFFERENT shapes in one launch -- every deferred weight gradient of the decoder stack:
+ * list j has n problems dw[j * n + i][n_out[j], k_in[j]] += dy[j * n + i][rows, n_out[j]]^T x[j * n + i][rows, k_in[j]] (row strides ldy[j],
+ * ldx[j]; dw contiguous; db as above, entries may be NULL); k_in a multiple of 4, x rows 16-byte aligned, else POET_ERR_UNSUPPORTED. */
+int poet_gemm_dw_multi(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n_lists, int n,
+                       const int* n_out, const int* k_in, int rows, const int64_t* ldy, const int64_t* ldx, void* stream);
 enum { POET_GEMM_PATH_NONE = 0, POET_GEMM_PATH_TILED = 1, POET_GEMM_PATH_STREAM = 2, POET_GEMM_PATH_DW = 3, POET_GEMM_PATH_SMALL = 4,
        POET_GEMM_PATH_PIPE = 5 /* deep-pipeline kernel: plain bf16 x bf16 -> fp32 (+=) products with N = 256, K >= 512 */ };
 int poet_gemm_last_path(void);

@@ -38,6 +38,8 @@ _PROTOS = {
     "poet_hip_last_error": ([], C.c_char_p),
     "poet_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "poet_gemm_dw_list": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, vp], i32),
+    "poet_gemm_dw_multi": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, C.POINTER(i32), C.POINTER(i32), i32,
+                            C.POINTER(i64), C.POINTER(i64), vp], i32),
     "poet_gemm_last_path": ([], i32),
     "poet_linear_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, f32, i64, i32, vp, i64, vp], i32),
     "poet_msda_fwd": ([vp, pi64, pi64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),

@@ -28,6 +28,8 @@ bool gemm_pipe_try(const GemmK& p, hipStream_t st);
 // latency-oriented fp32 kernel for the <= 1024-row decoder / head Linears (gemm_small.hip)
 bool gemm_small_try(const GemmK& p, hipStream_t st);
 // dW[i] += Y[i]^T X[i] (+ column sums of Y[i]) for n <= 8 fp32 problems of one shape, rows <= 1024, in one launch
+bool gemm_small_dw_multi(const float* const* Y, const float* const* X, float* const* C, float* const* ysum, int nl, int n, const int* n_out,
+                         const int* k_in, int rows, const int64_t* ldy, const int64_t* ldx, hipStream_t st);
 bool gemm_small_dw_list(const float* const* Y, const float* const* X, float* const* C, float* const* ysum, int n, int n_out, int k_in,
                         int rows, int64_t ldy, int64_t ldx, int64_t ldc, hipStream_t st);
 

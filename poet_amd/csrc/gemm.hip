@@ -610,6 +610,18 @@ extern "C" int poet_gemm(const PoetGemmDesc* desc, void* stream) {
     return POET_OK;
 }
 
+extern "C" int poet_gemm_dw_multi(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n_lists, int n,
+                                  const int* n_out, const int* k_in, int rows, const int64_t* ldy, const int64_t* ldx, void* stream) {
+    using namespace poet;
+    POET_CHECK(dy && x && dw && n_out && k_in && ldy && ldx && n_lists >= 1 && n_lists <= 8 && n >= 1 && n <= 8, POET_ERR_ARG,
+               "poet_gemm_dw_multi: 1..8 lists of 1..8 problems");
+    POET_CHECK(rows > 0 && rows <= 1024, POET_ERR_UNSUPPORTED, "poet_gemm_dw_multi: rows %d not in 1..1024", rows);
+    POET_CHECK(gemm_small_dw_multi(dy, x, dw, db, n_lists, n, n_out, k_in, rows, ldy, ldx, reinterpret_cast<hipStream_t>(stream)),
+               POET_ERR_UNSUPPORTED, "poet_gemm_dw_multi: unsupported problem (null operand, unaligned x, k_in not a multiple of 4)");
+    POET_LAUNCH_CHECK();
+    return POET_OK;
+}
+
 extern "C" int poet_gemm_dw_list(const float* const* dy, const float* const* x, float* const* dw, float* const* db, int n,
                                  int n_out, int k_in, int rows, int64_t ldy, int64_t ldx, int64_t ldw, void* stream) {
     using namespace poet;

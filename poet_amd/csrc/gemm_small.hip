@@ -373,6 +373,31 @@ __global__ __launch_bounds__(1024) void gemm_small_dw64_list_kernel(const DwList
     small_dw64_body(one, part, bsum);
 }
 
+// ---- ... and for up to DW_MULTI_MAX such lists of DIFFERENT shapes in one launch: every deferred weight gradient of the decoder ----
+// (7 Linears x 5 layers: as 7 launches of ~16 us each they were latency chains on a few dozen workgroups, one after the other; as block
+// ranges of ONE launch they overlap.  grid.y = list * n + problem, grid.x = the largest list's tile count: the others' surplus exits.)
+constexpr int DW_MULTI_MAX = 8;
+struct DwMulti {
+    DwList l[DW_MULTI_MAX];
+    int n;                                                              // problems per list
+};
+__global__ __launch_bounds__(1024) void gemm_small_dw64_multi_kernel(const DwMulti mm) {
+    extern __shared__ __attribute__((aligned(16))) float part[];
+    __shared__ float bsum[16 * 16];
+    typedef const __attribute__((address_space(4))) DwMulti* kernarg_t;
+    kernarg_t ka = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const int j = blockIdx.y / ka->n, z = blockIdx.y - j * ka->n;
+    DwOne one;
+    one.d.M = ka->l[j].M; one.d.N = ka->l[j].N; one.d.K = ka->l[j].K;
+    if ((int)blockIdx.x >= ((one.d.M + 15) >> 4) * ((one.d.N + BKM_TN - 1) / BKM_TN)) return;
+    one.d.A = ka->l[j].Y[z]; one.d.B = ka->l[j].X[z]; one.d.C = ka->l[j].C[z]; one.d.bias = ka->l[j].ysum[z];
+    one.d.lda = ka->l[j].lda; one.d.ldb = ka->l[j].ldb; one.d.ldc = ka->l[j].ldc;
+    // (small_dw64_body offsets by blockIdx.y * stride: zero strides, the pointers above are the problem's own)
+    one.d.strideA = one.d.strideB = one.d.strideC = one.d.stride_bias = 0;
+    (void)mm;
+    small_dw64_body(one, part, bsum);
+}
+
 // n2 a multiple of 4, X rows 16-byte aligned, <= 1024 rows (16 waves): the 16 x 64 tiling
 static bool dw64_ok(const void* X, int64_t ldx, int n2, int rows) {
     static const int off = [] { const char* e = getenv("POET_SMALL_NO_DW64"); return e && atoi(e) ? 1 : 0; }();
@@ -400,6 +425,30 @@ bool gemm_small_dw_list(const float* const* Y, const float* const* X, float* con
     }
     const int tiles = ((n_out + 15) >> 4) * ((k_in + 15) >> 4);
     hipLaunchKernelGGL(gemm_small_dw_list_kernel, dim3(tiles, n), dim3(256), 0, st, l);
+    return true;
+}
+
+bool gemm_small_dw_multi(const float* const* Y, const float* const* X, float* const* C, float* const* ysum, int nl, int n, const int* n_out,
+                         const int* k_in, int rows, const int64_t* ldy, const int64_t* ldx, hipStream_t st) {
+    if (nl < 1 || nl > DW_MULTI_MAX || n < 1 || n > DW_LIST_MAX || rows > 1024) return false;
+    DwMulti m{};
+    m.n = n;
+    int tiles = 0;
+    for (int j = 0; j < nl; ++j) {
+        DwList& l = m.l[j];
+        for (int i = 0; i < n; ++i) {
+            const int k = j * n + i;
+            if (!Y[k] || !X[k] || !C[k]) return false;
+            if (!dw64_ok(X[k], ldx[j], k_in[j], rows)) return false;
+            l.Y[i] = Y[k]; l.X[i] = X[k]; l.C[i] = C[k]; l.ysum[i] = ysum ? ysum[k] : nullptr;
+        }
+        l.M = n_out[j]; l.N = k_in[j]; l.K = rows; l.lda = ldy[j]; l.ldb = ldx[j]; l.ldc = k_in[j];
+        tiles = max(tiles, ((n_out[j] + 15) >> 4) * ((k_in[j] + BKM_TN - 1) / BKM_TN));
+    }
+    const int nw = max(4, (rows + 63) / 64);
+    static unsigned long long attr_done = 0;
+    lds_attr_once(reinterpret_cast<const void*>(gemm_small_dw64_multi_kernel), 64 * 1024, attr_done);
+    hipLaunchKernelGGL(gemm_small_dw64_multi_kernel, dim3(tiles, nl * n), dim3(64 * nw), (size_t)nw * 4096, st, m);
     return true;
 }
 

@@ -335,6 +335,9 @@ def _splitk_for(M, N, K):
     return max(1, min(-(-1024 // tiles), -(-K // (512 if big else 128))))
 
 
+_DW_MULTI = os.environ.get("POET_NO_DW_MULTI", "0") in ("", "0")       # (A/B aid, read at import)
+
+
 class defer_small_dw:
     """`with ops.defer_small_dw() as D:` around the backward of a STACK of identical layers (the decoder): the weight / bias
     gradients of <= 1024-row fp32 Linears are recorded instead of launched (`D.next_layer()` before each layer), and
@@ -368,6 +371,22 @@ class defer_small_dw:
             return
         lib = _lib.load()
         n = len(layers)
+        nl = len(layers[0])
+        # every Linear of every layer in ONE launch (poet_gemm_dw_multi: the lists are block ranges of one grid and overlap, where one
+        # launch per Linear ran 7 latency chains of ~16 us one after the other): same rows everywhere, k_in % 4 == 0, 16-byte aligned x
+        r0 = layers[0]
+        if (_DW_MULTI and 1 < nl <= 8 and all(r[4] == r0[0][4] for r in r0) and all(r[2].shape[1] % 4 == 0 and (r[6] or r[2].shape[1]) % 4 == 0 for r in r0)
+                and all(rec[1].data_ptr() % 16 == 0 for l in layers for rec in l)):
+            flat = [l[j] for j in range(nl) for l in layers]              # list-major: entry j * n + i
+            big = C.c_void_p * (nl * n)
+            has_db = any(r[3] is not None for r in flat)
+            rc = lib.poet_gemm_dw_multi(big(*[r[0].data_ptr() for r in flat]), big(*[r[1].data_ptr() for r in flat]), big(*[r[2].data_ptr() for r in flat]),
+                                        big(*[(r[3].data_ptr() if r[3] is not None else None) for r in flat]) if has_db else None, nl, n,
+                                        (C.c_int * nl)(*[r[2].shape[0] for r in r0]), (C.c_int * nl)(*[r[2].shape[1] for r in r0]), r0[0][4],
+                                        (C.c_int64 * nl)(*[(r[5] or r[2].shape[0]) for r in r0]), (C.c_int64 * nl)(*[(r[6] or r[2].shape[1]) for r in r0]),
+                                        _stream())
+            if rc == 0:
+                return
         arr = C.c_void_p * n
         for j in range(len(layers[0])):
             recs = [l[j] for l in layers]

@@ -1699,6 +1699,37 @@ def test_gemm_dw_list_matches_loop(ops):
     assert (g1.cpu() - dy_a.cpu().t() @ x_a.cpu()).abs().max().item() < 2e-3 and (g2.cpu() - dy_b.cpu().t() @ x_a.cpu()).abs().max().item() < 2e-3
 
 
+def test_gemm_dw_multi_lists_of_different_shapes(ops):
+    """poet_gemm_dw_multi (every deferred weight gradient of the decoder stack as block ranges of ONE launch): the seven Linears of a
+    decoder layer with their real shapes (FFN 256 <-> 1024, the 768-wide offsets | logits pair, in-projection slices of a packed
+    buffer, one without a bias gradient), 5 layers -- bit-identical to one launch per (layer, Linear); POET_NO_DW_MULTI's per-Linear
+    lists are the fallback (k_in % 4 != 0 takes it)."""
+    rows, nl = 320, 5
+    shapes = [(256, 1024, True), (1024, 256, True), (256, 256, True), (768, 256, True), (256, 256, False), (512, 256, True), (256, 256, True)]
+    res = {}
+    for mode in ("loop", "deferred"):
+        grads = []
+        ctx = ops.defer_small_dw() if mode == "deferred" else contextlib.nullcontext()
+        with ctx as D:
+            for i in range(nl):
+                if D is not None:
+                    D.next_layer()
+                for j, (n_out, k_in, bias) in enumerate(shapes):
+                    dy = dev(_rand(rows, n_out + 64, seed=700 + 10 * i + j))
+                    x = dev(_rand(rows, k_in, seed=800 + 10 * i + j))
+                    gW = torch.full((n_out, k_in), 0.5, device="cuda")
+                    gb = torch.full((n_out,), 0.25, device="cuda") if bias else None
+                    ops.linear_dw(dy[:, 32:32 + n_out], x, gW, rows=rows, ldy=n_out + 64, db=gb)
+                    grads += [gW] + ([gb] if bias else [])
+        torch.cuda.synchronize()
+        res[mode] = [t.cpu() for t in grads]
+    assert len(res["loop"]) == len(res["deferred"])
+    for a, b in zip(res["loop"], res["deferred"]):
+        assert torch.equal(a, b)
+    dy0, x0 = _rand(rows, 256 + 64, seed=700), _rand(rows, 1024, seed=800)
+    assert (res["deferred"][0] - (0.5 + dy0[:, 32:32 + 256].t() @ x0)).abs().max().item() < 5e-3
+
+
 # ------------------------------------------------------------------------------------------- on-device matcher
 def test_lsa_boxes_matches_scipy_including_ties(ops):
     """poet_lsa_boxes == scipy.optimize.linear_sum_assignment on the fp32 L1 box cost (models/matcher.py:60-75,158-229): random
